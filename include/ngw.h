@@ -1,0 +1,181 @@
+/* ngw.h — C-ABI of the MI355X-native batched step()/reset() hot path of gym-novel-gridworlds.
+ *
+ * The reference has no FFI of its own: its hot path sits behind the OpenAI-gym `gym.Env`
+ * Python API (reference: gym_novel_gridworlds/envs/pogostick_v1_env.py:86 reset, :230 step,
+ * :214 get_observation; envs/bow_v1_env.py same lines; novelty_wrappers.py:117-213 AxeMedium,
+ * :991-1034 AddItem, :1586 inject_novelty).  This header is the boundary a maintainer would bind
+ * from Python with ctypes (stub shown in INTEGRATION.md): plain pointers and sizes only.
+ *
+ * One handle = N independent environments resident on ONE GPU (one process per GPU; shard by
+ * creating one handle per rank with `env_index_base = rank * N`).  All state lives in HBM as
+ * structure-of-arrays; the observation buffers ARE the state (ping-pong pair), see DESIGN.md.
+ *
+ * Every function returns 0 on success or a negative NGW_E_* code; ngw_last_error() gives the
+ * thread-local message.  A handle is not thread-safe (one host thread per handle), matching the
+ * single-threaded reference.
+ */
+#ifndef NGW_H
+#define NGW_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGW_ABI_VERSION 1
+
+#define NGW_MAX_ITEMS 24        /* reference asserts len(items) <= max_items = 20 (pogostick_v1_env.py:75,220) */
+#define NGW_MAX_ACTIONS 48
+#define NGW_MAX_RECIPES 8
+#define NGW_MAX_RECIPE_INPUTS 8
+#define NGW_MAX_START_ITEMS 8
+#define NGW_MAX_MAP_SIZE 64     /* S; the LDS-resident kernel supports S*S <= 4096 */
+
+/* error codes */
+#define NGW_OK 0
+#define NGW_E_INVALID_ARG (-1)
+#define NGW_E_HIP (-2)           /* a HIP runtime call failed; no CPU fallback exists */
+#define NGW_E_INVALID_ACTION (-3)/* reference: ValueError "<a> is not in list" (pogostick_v1_env.py:236) */
+#define NGW_E_PLACEMENT (-4)     /* reference: AssertionError "Cannot place items, increase map size!" (:167) */
+#define NGW_E_NO_DEVICE (-5)
+
+/* device-side sticky error flags (ngw_error_flags) */
+#define NGW_F_INVALID_ACTION 1u
+#define NGW_F_PLACEMENT 2u
+
+/* action kinds (act_kind[]); act_arg[] = recipe index (CRAFT) or item id (SELECT) */
+enum { NGW_ACT_FORWARD = 0, NGW_ACT_LEFT = 1, NGW_ACT_RIGHT = 2, NGW_ACT_BREAK = 3, NGW_ACT_PLACE = 4,
+       NGW_ACT_EXTRACT = 5, NGW_ACT_CRAFT = 6, NGW_ACT_SELECT = 7 };
+
+/* info['message'] codes; the host formats the string (reference strings cited in spec.py) */
+enum { NGW_MSG_NONE = 0, NGW_MSG_BLOCK_IN_PATH = 1, NGW_MSG_CANNOT_BREAK = 2 /* arg = item */,
+       NGW_MSG_PLACED = 3 /* arg = item */, NGW_MSG_ALREADY_EXISTS = 4 /* arg = front item */,
+       NGW_MSG_NOT_IN_INVENTORY = 5, NGW_MSG_EXTRACT_NO_SRC = 6, NGW_MSG_EXTRACT_NOT_NEAR = 7,
+       NGW_MSG_MISSING_ITEMS = 8 /* arg = recipe<<8 | mask over recipe inputs in dict order */,
+       NGW_MSG_NEED_TABLE = 9, NGW_MSG_CRAFTED = 10 /* arg = crafted item */ };
+
+/* packed per-env info word produced by the step kernel:
+ *   bit 0 result | bit 1 done | bits 2..7 cost code | bits 8..15 message code | bits 16..31 message arg */
+#define NGW_INFO_RESULT(w) ((w) & 1u)
+#define NGW_INFO_DONE(w) (((w) >> 1) & 1u)
+#define NGW_INFO_COST(w) (((w) >> 2) & 63u)
+#define NGW_INFO_MSG(w) (((w) >> 8) & 255u)
+#define NGW_INFO_ARG(w) ((w) >> 16)
+
+/* Immutable environment specification, compiled on the host from (env id, map_size, novelty args)
+ * into flat integer look-up tables (SURVEY.md §8(a) a2 "LUT set").  `cost_*` fields are CODES into
+ * the host-side step_cost table (the reference mixes Python float and int step costs,
+ * pogostick_v1_env.py:257-470; 27.906975 is not float32-representable, so values never enter the GPU). */
+typedef struct ngw_spec {
+    int32_t abi_version;                 /* = NGW_ABI_VERSION */
+    int32_t map_size;                    /* S  (pogostick_v1_env.py:30) */
+    int32_t n_items;                     /* K  incl. air(0) and wall (set_items_id :200-212) */
+    int32_t n_actions;                   /* A = len(actions_id) (:52-68); may exceed action_space.n with novelties */
+    int32_t n_recipes;                   /* R */
+    int32_t reward_step;                 /* -1  (:239) */
+    int32_t reward_done;                 /* 50  (:82, forced while inv[goal] >= 1, :354-357) */
+    int32_t craft_reward;                /* 10 Pogostick (:455) / 50 Bow (bow_v1_env.py:424) */
+    uint8_t act_kind[NGW_MAX_ACTIONS];
+    uint8_t act_arg[NGW_MAX_ACTIONS];
+    uint8_t breakable[NGW_MAX_ITEMS];    /* item not in unbreakable_items (:41,:283) */
+    uint8_t entity[NGW_MAX_ITEMS];       /* item in entities, picked up by grab_entities (:538-554) */
+    int8_t break_reward[NGW_MAX_ITEMS];  /* +10 for tree_log else -1 (:288-289) */
+    uint8_t wall_item, table_item, goal_item, n_entities;
+    /* recipes (:56-59, craft :413-474) */
+    uint8_t recipe_in[NGW_MAX_RECIPES][NGW_MAX_ITEMS];        /* required quantity per item id */
+    uint8_t recipe_n_in[NGW_MAX_RECIPES];
+    uint8_t recipe_in_item[NGW_MAX_RECIPES][NGW_MAX_RECIPE_INPUTS]; /* inputs in dict order (message order) */
+    uint8_t recipe_out_item[NGW_MAX_RECIPES];
+    uint8_t recipe_out_qty[NGW_MAX_RECIPES];
+    uint8_t recipe_needs_table[NGW_MAX_RECIPES];             /* len(input) > 1 (:444) */
+    uint8_t cost_missing[NGW_MAX_RECIPES], cost_no_table[NGW_MAX_RECIPES], cost_ok[NGW_MAX_RECIPES];
+    /* fixed-action cost codes */
+    uint8_t cost_forward, cost_turn, cost_break, cost_place, cost_extract, cost_select;
+    /* Place_<item> (:295-314): place `place_item` in front; +place_reward iff a 4-neighbour of the front cell is place_near */
+    uint8_t place_item, place_near;
+    int8_t place_reward;
+    /* Extract_* (Pogostick :315-331, Bow bow_v1_env.py:293-304) */
+    uint8_t ext_src, ext_near /* 0 = no adjacency requirement */, ext_out, ext_qty, ext_consume, ext_cost_ok;
+    int8_t ext_reward;
+    /* Break override of the axe novelties (novelty_wrappers.py:144-183); axe_item = 0 -> base Break */
+    uint8_t axe_item, axe_cost, axe_qty;
+    int8_t axe_reward;
+    /* reset (:86-157): items placed in insertion order of items_quantity */
+    uint8_t n_start;
+    uint8_t start_item[NGW_MAX_START_ITEMS];
+    uint8_t start_qty[NGW_MAX_START_ITEMS];
+    /* AddItem second reset pass (novelty_wrappers.py:1013-1034); additem_item = 0 -> disabled */
+    uint8_t additem_item, additem_pct_lo, additem_pct_hi;
+    /* AxeEasy: item present in the inventory after every reset (novelty_wrappers.py:29-35); item 0 = none */
+    uint8_t inv_start_item, inv_start_qty;
+    uint8_t _pad[1];
+} ngw_spec;
+
+typedef struct ngw_handle ngw_handle;
+
+int ngw_abi_version(void);
+int ngw_spec_size(void);            /* sizeof(ngw_spec), checked by the host binding */
+const char* ngw_last_error(void);
+/* Number of visible GPUs (hipGetDeviceCount); 0 when there is none. */
+int ngw_device_count(void);
+
+/* Creates n_envs environments on GPU `device`.  `seed` keys the per-env counter-based reset streams
+ * (Philox4x32-10, counter = (word block, episode, global env index)); `env_index_base` is the global index
+ * of local env 0 so results do not depend on how envs are sharded over GPUs.  Replaces
+ * `gym.make(id)` + attribute edits + `inject_novelty` (gym_novel_gridworlds/__init__.py:57-60). State is
+ * undefined until ngw_reset / ngw_set_state. */
+int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, int64_t env_index_base,
+               ngw_handle** out);
+int ngw_destroy(ngw_handle* h);
+
+/* autoreset = 0 reproduces the reference (sticky done, no time limit).  autoreset = 1 (classic gym.vector
+ * "same-step" form): every call steps every env; an env whose step ended with done, or whose step_count
+ * reached `horizon` (> 0), is reset in the same call and the observation returned is the new episode's first
+ * one; reward/info are the terminal step's, done = 1 for both endings (info bit 1 set only for goal-done). */
+int ngw_set_autoreset(ngw_handle* h, int autoreset, int horizon);
+/* Run the handle's kernels on an external hipStream_t (e.g. torch's current stream); NULL = own stream. */
+int ngw_set_stream(ngw_handle* h, void* hip_stream);
+
+/* reset(): pogostick_v1_env.py:86-157 (+ AddItem.reset).  mask = NULL resets all envs, else mask[i] != 0. */
+int ngw_reset(ngw_handle* h, const uint8_t* mask_host);
+/* step(action_id): pogostick_v1_env.py:230-367 / AxeMedium.step.  Host actions are validated first
+ * (NGW_E_INVALID_ACTION, nothing stepped - the reference raises before touching state). */
+int ngw_step(ngw_handle* h, const int32_t* actions_host);
+/* Same with actions already in HBM; an out-of-range id sets NGW_F_INVALID_ACTION and leaves that env untouched. */
+int ngw_step_device(ngw_handle* h, const int32_t* actions_dev);
+/* Fused bench mode: T steps in one launch with on-device uniform actions
+ * a = (philox(action_seed; t, env) * A) >> 32; state stays in LDS/registers between steps.  The observation
+ * of every step is written to the current observation buffers (last one survives). */
+int ngw_rollout(ngw_handle* h, int32_t n_steps, uint64_t action_seed, int64_t t0);
+
+/* get_observation(): pogostick_v1_env.py:214-228, batched: map i8 [N,S,S], agent_location i32 [N,2] (r,c),
+ * agent_facing_id i32 [N], inventory_items_quantity i32 [N,K] in items_id order.  Any pointer may be NULL. */
+int ngw_get_obs(ngw_handle* h, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv);
+/* (reward, done, info) of the last step: pogostick_v1_env.py:354-367. */
+int ngw_get_step_out(ngw_handle* h, int32_t* reward, uint8_t* done, uint8_t* result, uint8_t* cost_code,
+                     uint16_t* msg_code, uint16_t* msg_arg);
+/* Full state of envs [first, first+count): the observation arrays plus selected item id (0 = ''),
+ * step_count and episode counter.  Checkpoint/restore and oracle-state injection
+ * (reference: direct attribute mutation, tests/keyboard_interface.py:93-100). */
+int ngw_get_state(ngw_handle* h, int64_t first, int64_t count, int8_t* map, int32_t* loc, int32_t* facing,
+                  int32_t* inv, int32_t* selected, int32_t* step_count, uint32_t* episode);
+int ngw_set_state(ngw_handle* h, int64_t first, int64_t count, const int8_t* map, const int32_t* loc,
+                  const int32_t* facing, const int32_t* inv, const int32_t* selected,
+                  const int32_t* step_count, const uint32_t* episode);
+
+/* Device pointers of the CURRENT observation / output buffers (valid until the next step or reset). */
+int ngw_obs_device_ptrs(ngw_handle* h, void** map, void** loc, void** facing, void** inv);
+int ngw_out_device_ptrs(ngw_handle* h, void** reward, void** done, void** info);
+int ngw_sync(ngw_handle* h);
+/* Reads and clears the sticky device error flags (NGW_F_*). */
+int ngw_error_flags(ngw_handle* h, uint32_t* flags);
+/* Average device time of the last `ngw_step*`/`ngw_rollout` launches since the previous call, measured with
+ * HIP events on the handle's stream (bench.py roofline leg).  Returns launches counted in *n. */
+int ngw_kernel_time(ngw_handle* h, double* total_ms, int64_t* n);
+int ngw_set_timing(ngw_handle* h, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGW_H */

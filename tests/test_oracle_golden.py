@@ -1,0 +1,137 @@
+"""Pins the CPU oracle (oracle/ngw_oracle.c) and the spec compiler against golden vectors captured from the
+imported reference (tests/golden, generator gen_golden.py).  CPU only."""
+import zlib
+
+import numpy as np
+import pytest
+
+import ngw_testlib as T
+from gym_novel_gridworlds_amd.spec import make_spec
+from oracle.ngw_oracle import MT19937, Oracle
+
+ALL = list(T.CFGS)
+
+
+@pytest.mark.parametrize('cfg', ALL)
+def test_spec_tables_match_reference(cfg):
+    """G1: ids, action tables, recipes, start items, entities (pogostick_v1_env.py:26-84 + novelty constructors)."""
+    ref = T.spec_json()['cfgs'][cfg]
+    spec = T.build_spec(cfg)
+    assert spec.items_id == ref['items_id']
+    assert spec.actions_id == ref['actions_id']
+    assert spec.action_space_n == ref['action_space_n'] == ref['base_action_space_n']
+    assert [[k, v] for k, v in spec.items_quantity.items()] == ref['items_quantity']
+    assert sorted(spec.entities) == ref['entities']
+    assert sorted(spec.unbreakable_items) == ref['unbreakable_items']
+    assert spec.goal_item_to_craft == ref['goal_item_to_craft']
+    assert (spec.reward_intermediate, spec.reward_done) == (ref['reward_intermediate'], ref['reward_done'])
+    for name, rec in ref['recipes'].items():
+        assert [[k, v] for k, v in spec.recipes[name]['input'].items()] == rec['input']
+        assert [[k, v] for k, v in spec.recipes[name]['output'].items()] == rec['output']
+    assert set(spec.recipes) == set(ref['recipes'])
+    spec.compile()
+
+
+@pytest.mark.parametrize('cfg', ALL)
+def test_reset_mt19937_matches_reference(cfg):
+    """G2: np.random.seed(s); reset() x3 -> identical map / agent / facing and identical stream position."""
+    g = T.golden(cfg)
+    spec = T.build_spec(cfg)
+    o = Oracle(spec.compile(), 1)
+    for seed in range(len(g['rs_next_word'])):
+        mt = MT19937(seed)
+        for j in range(3):
+            assert o.reset_mt(mt) == 0
+            assert (o.st.map[0] == g['rs_map'][seed, j]).all(), (cfg, seed, j)
+            assert (o.st.loc[0] == g['rs_loc'][seed, j]).all() and o.st.facing[0] == g['rs_facing'][seed, j]
+            assert not o.st.inv.any() and o.st.selected[0] == 0 and o.st.step_count[0] == 0
+        assert mt.next() == g['rs_next_word'][seed], (cfg, seed)
+
+
+@pytest.mark.parametrize('cfg', ALL)
+def test_traces_match_reference(cfg):
+    """G3: lock-step random traces incl. inventory injections, sticky done, re-resets."""
+    assert T.replay_traces(cfg, T.OracleBackend) > 0
+
+
+@pytest.mark.parametrize('cfg', ALL)
+def test_single_steps_match_reference(cfg):
+    """G4: one step from thousands of injected states (every action x front block x inventory profile)."""
+    assert T.replay_single_steps(cfg, T.OracleBackend) > 0
+
+
+@pytest.mark.parametrize('cfg', [c for c in ALL if T.spec_json()['cfgs'][c]['n_solved']])
+def test_solved_episodes_match_reference(cfg):
+    """G5: scripted-solver episodes reaching done (pick-up + select + axe break where present)."""
+    assert T.replay_solved(cfg, T.OracleBackend) > 0
+
+
+def test_placement_exhaustion_matches_reference():
+    """Small maps: same seeds succeed / raise 'Cannot place items, increase map size!' (pogostick_v1_env.py:167)."""
+    for e in T.spec_json()['exhaustion']:
+        spec = make_spec(e['env_id'], e['S'])
+        o = Oracle(spec.compile(), 1)
+        mt = MT19937(e['seed'])
+        rc = o.reset_mt(mt)
+        assert (rc == 0) == e['ok'], e
+        if e['ok']:
+            assert zlib.crc32(o.st.map[0].tobytes()) == e['crc']
+            assert o.st.loc[0].tolist() == e['loc'] and o.st.facing[0] == e['facing']
+            assert mt.next() == e['next_word']
+        else:
+            assert e['error'] == 'Cannot place items, increase map size!'
+
+
+def test_random_action_loop_matches_reference():
+    """C1 (BASELINE config 1): tests/random_action.py:51-64 loop shape - actions, map_size changes and resets all
+    drawn from the ONE global MT19937 stream."""
+    g = dict(np.load(T.GOLDEN + '/c1loop.npz'))
+    k = 0
+    while 'c%d_action' % k in g:
+        p = 'c%d_' % k
+        mt = MT19937(k)
+        spec = make_spec(T.POGO, 10)
+        A = spec.action_space_n
+        o = Oracle(spec.compile(), 1)
+        assert o.reset_mt(mt) == 0
+        assert (o.st.map[0] == g[p + 'map0']).all()
+        j = 0
+        for i in range(50):
+            a = mt.bounded(A - 1)                       # action_space.sample() -> np.random.randint(A)
+            assert a == g[p + 'action'][i]
+            o.step(np.array([a], np.int32))
+            out = dict(reward=o.reward, done=o.done, result=o.result, cost_code=o.cost_code, msg_code=o.msg_code,
+                       msg_arg=o.msg_arg)
+            T.check_outs(spec, out, 0, a, g[p + 'reward'][i], g[p + 'done'][i], g[p + 'result'][i], g[p + 'cost'][i],
+                         g[p + 'cost_is_int'][i], g[p + 'msg'][i], 'c1loop %d step %d' % (k, i))
+            assert zlib.crc32(o.st.map[0].tobytes()) == g[p + 'crc'][i]
+            assert (o.st.loc[0] == g[p + 'loc'][i]).all() and o.st.facing[0] == g[p + 'facing'][i]
+            assert (o.st.inv[0] == g[p + 'inv'][i]).all() and o.st.selected[0] == g[p + 'sel'][i]
+            if (i + 1) % 10 == 0:
+                j += 1
+                S = 10 + mt.bounded(9)                  # np.random.randint(low=10, high=20, size=1)
+                assert S == g[p + 'sizes'][j]
+                spec = make_spec(T.POGO, S)
+                o = Oracle(spec.compile(), 1)
+                assert o.reset_mt(mt) == 0
+                assert (o.st.map[0] == g[p + 'map%d' % j]).all()
+        assert mt.next() == g[p + 'next_word'][0]
+        k += 1
+    assert k == 6
+
+
+def test_invalid_action_is_flagged():
+    """Reference raises ValueError('<a> is not in list') before touching state (pogostick_v1_env.py:236)."""
+    for cfg in ('pogo10', 'axe10'):
+        ref = T.spec_json()['cfgs'][cfg]
+        spec = T.build_spec(cfg)
+        be = T.OracleBackend(spec, 1)
+        g = T.golden(cfg)
+        be.load(0, g['rs_map'][0, 0], g['rs_loc'][0, 0], g['rs_facing'][0, 0])
+        before = {k: v.copy() for k, v in be.state().items()}
+        for a, exc, text in ref['invalid_action_errors']:
+            assert exc == 'ValueError' and text == '%d is not in list' % a
+            out = be.step(np.array([a], np.int32))
+            assert out['flags'] == 1
+            for k, v in be.state().items():
+                assert (v == before[k]).all()
