@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py - env-steps/sec of the batched step()/reset() hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload C2|C3|C4|C5] [--mode step|rollout]
+
+A "step" is ONE batched env step over the whole resident batch: the step kernel advances every env, resets the ones
+whose episode ended (done, or horizon H = 100) and writes the new observation batch.  Inputs (state + int32 actions)
+are resident in HBM when the timed region starts.  Default workload C2 = BASELINE.json configs[1]:
+NovelGridworld-Pogostick-v1, 65 536 envs per GPU, 10x10 map.  N > 1: one process per GPU (torchrun), envs sharded by
+global env index, no data-path collective (envs are independent) -> weak scaling.
+
+The JSON line also carries
+  roofline      algorithmic bytes per env-step (2*S*S + 12*K + 45) * envs per launch / the step
+                kernel's average duration measured with HIP events on the kernel's own stream, vs 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (oracle/ngw_oracle.c, a port - the Python reference cannot travel to the GPU box)
+                timed on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+
+POGO, BOW = 'NovelGridworld-Pogostick-v1', 'NovelGridworld-Bow-v1'
+WORKLOADS = {   # name -> (env id, map size, novelty, envs per GPU, description)
+    'C2': (POGO, 10, None, 65536, 'NovelGridworld-Pogostick-v1, 65536 envs/GPU, 10x10'),
+    'C3': (BOW, 20, None, 65536, 'NovelGridworld-Bow-v1, 65536 envs/GPU, 20x20'),
+    'C4': (POGO, 10, ('axe', 'medium', 'wooden', ''), 32768, "Pogostick-v1 + inject_novelty('axe','medium','wooden'), 32768 envs/GPU, 10x10"),
+    'C5': (POGO, 32, ('additem', 'hard', 'arrow', ''), 65536, "Pogostick-v1 + inject_novelty('additem','hard','arrow'), 65536 envs/GPU, 32x32"),
+}
+HORIZON = 100                  # per-episode step cap of the reference's evaluation scripts (tests/test.py:30, enjoy.py:107)
+ACTION_SEED = 1234
+
+
+def algorithmic_bytes(S, K):
+    return 2 * S * S + 12 * K + 45
+
+
+def cpu_baseline(spec, budget_s=12.0):
+    """Oracle timed on the host cores: same workload shape (uniform actions, autoreset, H = 100), bounded sample."""
+    from oracle import ngw_oracle as orc
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    out = {}
+    for label, threads in (('1core', 1), ('allcores', cores)):
+        used = orc.set_threads(threads)
+        n = 4096 * max(1, used)
+        o = orc.Oracle(spec.compile(), n, seed=0, autoreset=True, horizon=HORIZON)
+        o.reset()
+        o.rollout(5, ACTION_SEED, 0)                       # warm-up
+        t0, steps, T = time.perf_counter(), 0, 100
+        while True:
+            o.rollout(T, ACTION_SEED, 5 + steps)
+            steps += T
+            dt = time.perf_counter() - t0
+            if dt > budget_s / 2 or steps >= 2000:
+                break
+        out[label] = dict(value=n * steps / dt, cores=used, sample='%d envs x %d steps in %.1f s' % (n, steps, dt))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=1000)
+    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--workload', default='C2', choices=sorted(WORKLOADS))
+    ap.add_argument('--mode', default='step', choices=['step', 'rollout'])
+    ap.add_argument('--envs', type=int, default=0, help='envs per GPU (default: the workload\'s)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from gym_novel_gridworlds_amd import VecNovelGridworld, apply_novelty, make_spec
+    env_id, S, nov, n_default, desc = WORKLOADS[args.workload]
+    n = args.envs or n_default
+    spec = make_spec(env_id, S)
+    if nov:
+        apply_novelty(spec, *nov)
+    K, A = len(spec.items_id), len(spec.actions_id)
+    v = VecNovelGridworld(spec=spec, num_envs=n, device=local_rank, seed=0, autoreset=True, horizon=HORIZON,
+                          env_index_base=rank * n)
+    v.reset()
+    steps, warmup = args.steps, args.warmup
+
+    acts = None
+    if args.mode == 'step':
+        # i.i.d. uniform int32 actions over len(actions_id), seed 1234 (+rank), resident in HBM before the timed region
+        g = torch.Generator(device='cuda')
+        g.manual_seed(ACTION_SEED + rank)
+        ring = min(steps + warmup, 1024)
+        acts = torch.randint(0, A, (ring, n), dtype=torch.int32, device='cuda', generator=g)
+        ptrs = [acts[i].data_ptr() for i in range(ring)]
+
+    def run(k, t_base):
+        if args.mode == 'step':
+            for i in range(k):
+                v.step_device(ptrs[(t_base + i) % len(ptrs)])
+        else:
+            v.rollout(k, ACTION_SEED, t_base)
+
+    def fence():
+        v.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(warmup, 0)
+    fence()
+    t0 = time.perf_counter()
+    run(steps, warmup)
+    fence()
+    dt = time.perf_counter() - t0
+    assert v.error_flags() == 0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # roofline leg: per-launch HIP-event timing on the kernel's stream (second pass, same inputs)
+    v.set_timing(True)
+    if args.mode == 'step':
+        done_k = 0
+        while done_k < steps:
+            k = min(2048, steps - done_k)
+            run(k, warmup + steps + done_k)
+            v.sync()
+            done_k += k
+    else:
+        run(steps, warmup + steps)
+    k_ms, k_n = v.kernel_time()
+    v.set_timing(False)
+    steps_per_launch = 1 if args.mode == 'step' else steps
+    launch_ms = k_ms / max(k_n, 1)
+    B = algorithmic_bytes(S, K)
+    achieved = B * n * steps_per_launch / (launch_ms * 1e-3) / 1e9
+    roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel': 'ngw_kernel',
+                'kernel_ms_avg': round(launch_ms, 6), 'launches_timed': int(k_n),
+                'algorithmic_bytes_per_env_step': B, 'env_steps_per_launch': n * steps_per_launch}
+    pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc)).get('%s_%s' % (args.workload, args.mode))
+        if rec:
+            roofline['traffic'] = rec['hbm_bytes_per_launch']
+            roofline['traffic_source'] = rec['source']
+
+    if rank == 0:
+        total = n * world * steps
+        line = {
+            'metric': 'env-steps/sec', 'value': round(total / dt, 1), 'unit': 'env-steps/s', 'n_gpus': world,
+            'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 6), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8/int32', 'data': 'synthetic',
+            'config': {'workload': desc, 'name': args.workload, 'envs_per_gpu': n, 'global_envs': n * world,
+                       'map_size': S, 'n_items': K, 'n_actions': A, 'horizon': HORIZON, 'autoreset': 'same-step',
+                       'mode': 'one launch per batched step, actions in HBM' if args.mode == 'step'
+                               else 'fused rollout: all steps in one launch, actions generated in-kernel',
+                       'parallelism': 'envs sharded x%d, no collective' % world},
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(spec)
+            line['cpu_baseline'] = {'value': round(cb['allcores']['value'], 1), 'unit': 'env-steps/s',
+                                    'cores': cb['allcores']['cores'], 'kind': 'port', 'sample': cb['allcores']['sample'],
+                                    'one_core_value': round(cb['1core']['value'], 1)}
+        print(json.dumps(line), flush=True)
+    v.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

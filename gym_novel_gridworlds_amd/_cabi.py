@@ -1,0 +1,98 @@
+"""ctypes binding of the C-ABI in include/ngw.h (libngw_hip.so = HIP kernels + host glue).
+
+This is the only way into the hot path: if the library is missing, cannot be loaded, or no GPU is visible,
+the failure is loud - there is no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .spec import NgwSpec
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libngw_hip.so')
+
+E_INVALID_ARG, E_HIP, E_INVALID_ACTION, E_PLACEMENT, E_NO_DEVICE = -1, -2, -3, -4, -5
+
+# every symbol include/ngw.h declares (checked by tests/test_cabi_symbols.py against the header text)
+SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_count', 'ngw_create', 'ngw_destroy',
+           'ngw_set_autoreset', 'ngw_set_stream', 'ngw_reset', 'ngw_step', 'ngw_step_device', 'ngw_rollout',
+           'ngw_get_obs', 'ngw_get_step_out', 'ngw_get_state', 'ngw_set_state', 'ngw_obs_device_ptrs',
+           'ngw_out_device_ptrs', 'ngw_sync', 'ngw_error_flags', 'ngw_kernel_time', 'ngw_set_timing']
+
+_lib = None
+
+
+class NgwError(RuntimeError):
+    pass
+
+
+def _ptr(arr, dtype):
+    """Host pointer of a C-contiguous ndarray of `dtype`, or NULL for None."""
+    if arr is None:
+        return None
+    assert isinstance(arr, np.ndarray) and arr.dtype == dtype and arr.flags['C_CONTIGUOUS'], \
+        "expected a C-contiguous %s array" % np.dtype(dtype).name
+    return arr.ctypes.data_as(C.c_void_p)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NgwError("HIP extension %s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C gym_novel_gridworlds_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64, and a
+    # second copy (the system one this library would otherwise pull in) leaves whichever initialises later without
+    # GPUs.  Importing torch first makes the dynamic linker bind libngw_hip.so to torch's already-loaded runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, i64, u64, i32 = C.c_void_p, C.c_int64, C.c_uint64, C.c_int32
+    L.ngw_abi_version.restype = C.c_int
+    L.ngw_spec_size.restype = C.c_int
+    L.ngw_last_error.restype = C.c_char_p
+    L.ngw_device_count.restype = C.c_int
+    L.ngw_create.argtypes = [C.POINTER(NgwSpec), i64, C.c_int, u64, i64, C.POINTER(vp)]
+    L.ngw_destroy.argtypes = [vp]
+    L.ngw_set_autoreset.argtypes = [vp, C.c_int, C.c_int]
+    L.ngw_set_stream.argtypes = [vp, vp]
+    L.ngw_reset.argtypes = [vp, vp]
+    L.ngw_step.argtypes = [vp, vp]
+    L.ngw_step_device.argtypes = [vp, vp]
+    L.ngw_rollout.argtypes = [vp, i32, u64, i64]
+    L.ngw_get_obs.argtypes = [vp, vp, vp, vp, vp]
+    L.ngw_get_step_out.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.ngw_get_state.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp]
+    L.ngw_set_state.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp]
+    L.ngw_obs_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.ngw_out_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.ngw_sync.argtypes = [vp]
+    L.ngw_error_flags.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.ngw_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
+    L.ngw_set_timing.argtypes = [vp, C.c_int]
+    if L.ngw_spec_size() != C.sizeof(NgwSpec):
+        raise NgwError("ngw_spec layout mismatch: library %d bytes, binding %d bytes" % (L.ngw_spec_size(), C.sizeof(NgwSpec)))
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().ngw_last_error().decode('utf-8', 'replace')
+
+
+def check(rc):
+    """Map C-ABI return codes to the exception types the reference raises (SURVEY.md §8(b) Errors)."""
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == E_INVALID_ACTION:
+        raise ValueError(msg)                                   # pogostick_v1_env.py:236
+    if rc == E_PLACEMENT:
+        raise AssertionError(msg)                               # pogostick_v1_env.py:167
+    if rc == E_INVALID_ARG:
+        raise ValueError(msg)
+    raise NgwError("ngw C-ABI call failed (%d): %s" % (rc, msg))

@@ -1,0 +1,464 @@
+// ngw_abi.cpp — host side of the C-ABI declared in include/ngw.h (HIP runtime only; no torch types).
+//
+// Owns the device buffers of a handle, validates arguments, launches ngw_kernel (ngw_kernels.hip) and moves
+// observations / outputs / state between HBM and caller-provided host arrays.  There is NO CPU execution path:
+// without a GPU every entry point that computes returns NGW_E_NO_DEVICE / NGW_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ngw.h"
+#include "ngw_device.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(NGW_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));     \
+    } while (0)
+
+constexpr int kTimingRing = 8192;
+
+}  // namespace
+
+struct ngw_handle {
+    ngw_spec spec;
+    int64_t n = 0, n_pad = 0, env_base = 0;
+    int device = 0;
+    uint64_t seed = 0;
+    int autoreset = 0, horizon = 0;
+    int cur = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    NgwBufs b{};
+    NgwLaunch proto{};           // layout fields filled once
+    size_t lds_bytes = 0;
+    int32_t* actions_dev = nullptr;   // staging for host actions
+    uint8_t* mask_dev = nullptr;
+    std::vector<void*> allocs;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    int ev_used = 0;
+    double t_total_ms = 0.0;
+    int64_t t_n = 0;
+};
+
+namespace {
+
+int check_spec(const ngw_spec* s) {
+    if (!s) return fail(NGW_E_INVALID_ARG, "spec is NULL");
+    if (s->abi_version != NGW_ABI_VERSION) return fail(NGW_E_INVALID_ARG, "spec abi_version %d != %d", s->abi_version, NGW_ABI_VERSION);
+    if (s->map_size < 5 || s->map_size > NGW_MAX_MAP_SIZE) return fail(NGW_E_INVALID_ARG, "map_size %d outside [5, %d]", s->map_size, NGW_MAX_MAP_SIZE);
+    if (s->n_items < 2 || s->n_items > NGW_MAX_ITEMS) return fail(NGW_E_INVALID_ARG, "n_items %d out of range", s->n_items);
+    if (s->n_actions < 1 || s->n_actions > NGW_MAX_ACTIONS) return fail(NGW_E_INVALID_ARG, "n_actions %d out of range", s->n_actions);
+    if (s->n_recipes < 0 || s->n_recipes > NGW_MAX_RECIPES) return fail(NGW_E_INVALID_ARG, "n_recipes %d out of range", s->n_recipes);
+    if (s->n_start > NGW_MAX_START_ITEMS) return fail(NGW_E_INVALID_ARG, "n_start %d out of range", s->n_start);
+    const int K = s->n_items;
+    auto item_ok = [&](int i) { return i >= 0 && i < K; };
+    if (!item_ok(s->wall_item) || !item_ok(s->table_item) || !item_ok(s->goal_item) || !item_ok(s->place_item) ||
+        !item_ok(s->place_near) || !item_ok(s->ext_src) || !item_ok(s->ext_near) || !item_ok(s->ext_out) ||
+        !item_ok(s->axe_item) || !item_ok(s->additem_item) || !item_ok(s->inv_start_item))
+        return fail(NGW_E_INVALID_ARG, "spec item id out of range");
+    for (int a = 0; a < s->n_actions; a++) {
+        const int kind = s->act_kind[a], arg = s->act_arg[a];
+        if (kind > NGW_ACT_SELECT) return fail(NGW_E_INVALID_ARG, "action %d has unknown kind %d", a, kind);
+        if (kind == NGW_ACT_CRAFT && arg >= s->n_recipes) return fail(NGW_E_INVALID_ARG, "action %d: recipe %d out of range", a, arg);
+        if (kind == NGW_ACT_SELECT && !item_ok(arg)) return fail(NGW_E_INVALID_ARG, "action %d: item %d out of range", a, arg);
+    }
+    for (int r = 0; r < s->n_recipes; r++) {
+        if (s->recipe_n_in[r] > NGW_MAX_RECIPE_INPUTS || !item_ok(s->recipe_out_item[r]))
+            return fail(NGW_E_INVALID_ARG, "recipe %d malformed", r);
+        for (int j = 0; j < s->recipe_n_in[r]; j++)
+            if (!item_ok(s->recipe_in_item[r][j])) return fail(NGW_E_INVALID_ARG, "recipe %d input out of range", r);
+    }
+    for (int j = 0; j < s->n_start; j++)
+        if (!item_ok(s->start_item[j])) return fail(NGW_E_INVALID_ARG, "start item out of range");
+    if (s->additem_item && !(s->additem_pct_lo < s->additem_pct_hi && s->additem_pct_hi - s->additem_pct_lo <= 32 && s->additem_pct_hi <= 100))
+        return fail(NGW_E_INVALID_ARG, "additem percent range invalid");
+    return NGW_OK;
+}
+
+template <typename T>
+int dev_alloc(ngw_handle* h, T** p, size_t count) {
+    void* q = nullptr;
+    size_t bytes = count * sizeof(T);
+    HIP_TRY(hipMalloc(&q, bytes));
+    HIP_TRY(hipMemsetAsync(q, 0, bytes, h->stream));
+    h->allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return NGW_OK;
+}
+
+int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, const uint8_t* mask_dev, uint64_t action_seed, int64_t t0) {
+    NgwLaunch a = h->proto;
+    a.b = h->b;
+    a.cur = h->cur;
+    a.mode = mode;
+    a.n_steps = n_steps;
+    a.actions = actions_dev;
+    a.reset_mask = mask_dev;
+    a.autoreset = h->autoreset;
+    a.horizon = h->horizon;
+    a.action_seed = action_seed;
+    a.t0 = t0;
+    const unsigned grid = (unsigned)(h->n_pad / NGW_EPB);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing && h->ev_used + 2 <= (int)h->ev.size()) {
+        e0 = h->ev[h->ev_used++];
+        e1 = h->ev[h->ev_used++];
+        HIP_TRY(hipEventRecord(e0, h->stream));
+    }
+    HIP_TRY(ngw_launch(&h->spec, &a, grid, h->lds_bytes, h->stream));
+    if (e1) HIP_TRY(hipEventRecord(e1, h->stream));
+    h->cur = (h->cur + n_steps) & 1;
+    return NGW_OK;
+}
+
+int drain_timing(ngw_handle* h) {
+    if (h->ev_used == 0) return NGW_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int i = 0; i + 1 < h->ev_used; i += 2) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        h->t_total_ms += ms;
+        h->t_n += 1;
+    }
+    h->ev_used = 0;
+    return NGW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ngw_abi_version(void) { return NGW_ABI_VERSION; }
+int ngw_spec_size(void) { return (int)sizeof(ngw_spec); }
+const char* ngw_last_error(void) { return g_err; }
+
+int ngw_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, int64_t env_index_base, ngw_handle** out) {
+    if (!out) return fail(NGW_E_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (int rc = check_spec(spec)) return rc;
+    if (n_envs < 1) return fail(NGW_E_INVALID_ARG, "n_envs must be >= 1");
+    if (env_index_base < 0) return fail(NGW_E_INVALID_ARG, "env_index_base must be >= 0");
+    int ndev = ngw_device_count();
+    if (ndev < 1) return fail(NGW_E_NO_DEVICE, "no HIP device visible: this library has no CPU path");
+    if (device < 0 || device >= ndev) return fail(NGW_E_INVALID_ARG, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    ngw_handle* h = new ngw_handle();
+    h->spec = *spec;
+    h->n = n_envs;
+    h->n_pad = (n_envs + NGW_EPB - 1) / NGW_EPB * NGW_EPB;
+    h->device = device;
+    h->seed = seed;
+    h->env_base = env_index_base;
+    auto bail = [&](int rc) { ngw_destroy(h); return rc; };
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(NGW_E_HIP, "hipStreamCreate failed"));
+    h->own_stream = true;
+
+    const int S = spec->map_size, S2 = S * S, K = spec->n_items;
+    const size_t np = (size_t)h->n_pad;
+    int rc = NGW_OK;
+    for (int i = 0; i < 2 && !rc; i++) {
+        if (!rc) rc = dev_alloc(h, &h->b.map[i], np * S2);
+        if (!rc) rc = dev_alloc(h, &h->b.loc[i], np * 2);
+        if (!rc) rc = dev_alloc(h, &h->b.facing[i], np);
+        if (!rc) rc = dev_alloc(h, &h->b.inv[i], np * K);
+    }
+    if (!rc) rc = dev_alloc(h, &h->b.selected, np);
+    if (!rc) rc = dev_alloc(h, &h->b.step_count, np);
+    if (!rc) rc = dev_alloc(h, &h->b.episode, np);
+    if (!rc) rc = dev_alloc(h, &h->b.reward, np);
+    if (!rc) rc = dev_alloc(h, &h->b.done, np);
+    if (!rc) rc = dev_alloc(h, &h->b.info, np);
+    if (!rc) rc = dev_alloc(h, &h->b.flags, 1);
+    if (!rc) rc = dev_alloc(h, &h->actions_dev, np);
+    if (!rc) rc = dev_alloc(h, &h->mask_dev, np);
+    if (!rc && spec->additem_item) rc = dev_alloc(h, &h->b.perm, np * S2);
+    if (rc) return bail(rc);
+
+    // launch layout
+    NgwLaunch& p = h->proto;
+    p.n = h->n; p.n_pad = h->n_pad; p.env_base = h->env_base; p.seed = seed;
+    p.S = S; p.S2 = S2; p.K = K;
+    const int S2r = (S2 + 3) / 4;                       // dwords per map, rounded up
+    const int MSdw = (S2r & 1) ? S2r : S2r + 1;         // odd dword stride -> conflict-free per-lane cell reads
+    p.MS = ((S2 & 3) == 0 && (S2r & 1)) ? S2 : MSdw * 4;
+    const uint32_t div = ((S2 & 3) == 0) ? (uint32_t)(S2 / 4) : (uint32_t)S2;
+    p.magic = (uint32_t)((0x100000000ull + div - 1) / div);
+    p.CW = ((S - 4) * (S - 4) + 31) / 32;
+    uint32_t off = (uint32_t)(NGW_EPB * p.MS / 4);
+    off = (off + 3u) & ~3u;
+    p.off_inv = off; off += (uint32_t)(K * NGW_EPB);
+    p.off_cand = off; off += (uint32_t)(p.CW * NGW_EPB);
+    p.off_spec = off; off += (uint32_t)(sizeof(ngw_spec) / 4);
+    h->lds_bytes = (size_t)off * 4;
+    if (h->lds_bytes > 160 * 1024) return bail(fail(NGW_E_INVALID_ARG, "map_size %d needs %zu B of LDS per wavefront (> 160 KiB)", S, h->lds_bytes));
+    for (int i = 0; i < 32; i++) p.addq[i] = (double)(spec->additem_pct_lo + i) / 100.0;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(NGW_E_HIP, "stream sync failed after allocation"));
+    *out = h;
+    return NGW_OK;
+}
+
+int ngw_destroy(ngw_handle* h) {
+    if (!h) return NGW_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void* p : h->allocs) (void)hipFree(p);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return NGW_OK;
+}
+
+int ngw_set_autoreset(ngw_handle* h, int autoreset, int horizon) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (horizon < 0) return fail(NGW_E_INVALID_ARG, "horizon must be >= 0");
+    h->autoreset = autoreset ? 1 : 0;
+    h->horizon = horizon;
+    return NGW_OK;
+}
+
+int ngw_set_stream(ngw_handle* h, void* hip_stream) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->own_stream) { HIP_TRY(hipStreamDestroy(h->stream)); h->own_stream = false; }
+    if (hip_stream) {
+        h->stream = static_cast<hipStream_t>(hip_stream);
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    return NGW_OK;
+}
+
+int ngw_reset(ngw_handle* h, const uint8_t* mask_host) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    const uint8_t* m = nullptr;
+    if (mask_host) {
+        HIP_TRY(hipMemcpyAsync(h->mask_dev, mask_host, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));   // mask_host may be pageable and reused by the caller
+        m = h->mask_dev;
+    }
+    return launch(h, NGW_MODE_RESET, 1, nullptr, m, 0, 0);
+}
+
+int ngw_step(ngw_handle* h, const int32_t* actions_host) {
+    if (!h || !actions_host) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    const int A = h->spec.n_actions;
+    for (int64_t i = 0; i < h->n; i++)
+        if (actions_host[i] < 0 || actions_host[i] >= A)
+            return fail(NGW_E_INVALID_ACTION, "%d is not in list", (int)actions_host[i]);   // pogostick_v1_env.py:236
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->actions_dev, actions_host, (size_t)h->n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return launch(h, NGW_MODE_STEP, 1, h->actions_dev, nullptr, 0, 0);
+}
+
+int ngw_step_device(ngw_handle* h, const int32_t* actions_dev) {
+    if (!h || !actions_dev) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    return launch(h, NGW_MODE_STEP, 1, actions_dev, nullptr, 0, 0);
+}
+
+int ngw_rollout(ngw_handle* h, int32_t n_steps, uint64_t action_seed, int64_t t0) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (n_steps < 1) return fail(NGW_E_INVALID_ARG, "n_steps must be >= 1");
+    HIP_TRY(hipSetDevice(h->device));
+    return launch(h, NGW_MODE_ROLLOUT, n_steps, nullptr, nullptr, action_seed, t0);
+}
+
+int ngw_sync(ngw_handle* h) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NGW_OK;
+}
+
+#define D2H(dst, src, bytes)                                                                             \
+    do {                                                                                                 \
+        if (dst) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, h->stream));        \
+    } while (0)
+
+int ngw_get_obs(ngw_handle* h, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)h->n, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
+    const int c = h->cur;
+    D2H(map, h->b.map[c], n * S2);
+    D2H(loc, h->b.loc[c], n * 2 * sizeof(int32_t));
+    D2H(facing, h->b.facing[c], n * sizeof(int32_t));
+    D2H(inv, h->b.inv[c], n * K * sizeof(int32_t));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NGW_OK;
+}
+
+int ngw_get_step_out(ngw_handle* h, int32_t* reward, uint8_t* done, uint8_t* result, uint8_t* cost_code, uint16_t* msg_code, uint16_t* msg_arg) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)h->n;
+    D2H(reward, h->b.reward, n * sizeof(int32_t));
+    D2H(done, h->b.done, n);
+    std::vector<uint32_t> info;
+    const bool want_info = result || cost_code || msg_code || msg_arg;
+    if (want_info) {
+        info.resize(n);
+        HIP_TRY(hipMemcpyAsync(info.data(), h->b.info, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (want_info)
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t w = info[i];
+            if (result) result[i] = (uint8_t)NGW_INFO_RESULT(w);
+            if (cost_code) cost_code[i] = (uint8_t)NGW_INFO_COST(w);
+            if (msg_code) msg_code[i] = (uint16_t)NGW_INFO_MSG(w);
+            if (msg_arg) msg_arg[i] = (uint16_t)NGW_INFO_ARG(w);
+        }
+    return NGW_OK;
+}
+
+int ngw_get_state(ngw_handle* h, int64_t first, int64_t count, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv,
+                  int32_t* selected, int32_t* step_count, uint32_t* episode) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (first < 0 || count < 0 || first + count > h->n) return fail(NGW_E_INVALID_ARG, "env range [%lld, +%lld) out of bounds", (long long)first, (long long)count);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)count, f = (size_t)first, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
+    const int c = h->cur;
+    D2H(map, h->b.map[c] + f * S2, n * S2);
+    D2H(loc, h->b.loc[c] + f * 2, n * 2 * sizeof(int32_t));
+    D2H(facing, h->b.facing[c] + f, n * sizeof(int32_t));
+    D2H(inv, h->b.inv[c] + f * K, n * K * sizeof(int32_t));
+    D2H(step_count, h->b.step_count + f, n * sizeof(int32_t));
+    D2H(episode, h->b.episode + f, n * sizeof(uint32_t));
+    std::vector<uint8_t> sel;
+    if (selected) {
+        sel.resize(n);
+        HIP_TRY(hipMemcpyAsync(sel.data(), h->b.selected + f, n, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (selected)
+        for (size_t i = 0; i < n; i++) selected[i] = sel[i];
+    return NGW_OK;
+}
+
+#define H2D(dst, src, bytes)                                                                             \
+    do {                                                                                                 \
+        if (src) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, h->stream));        \
+    } while (0)
+
+int ngw_set_state(ngw_handle* h, int64_t first, int64_t count, const int8_t* map, const int32_t* loc, const int32_t* facing,
+                  const int32_t* inv, const int32_t* selected, const int32_t* step_count, const uint32_t* episode) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (first < 0 || count < 0 || first + count > h->n) return fail(NGW_E_INVALID_ARG, "env range [%lld, +%lld) out of bounds", (long long)first, (long long)count);
+    const int S = h->proto.S, K = h->proto.K;
+    const size_t n = (size_t)count, f = (size_t)first, S2 = (size_t)h->proto.S2;
+    // the kernel indexes LUTs and the map with these values: reject anything that could go out of bounds
+    if (map)
+        for (size_t i = 0; i < n * S2; i++)
+            if (map[i] < 0 || map[i] >= K) return fail(NGW_E_INVALID_ARG, "map cell value %d outside [0, %d)", (int)map[i], K);
+    if (loc)
+        for (size_t i = 0; i < n; i++)
+            if (loc[2 * i] < 1 || loc[2 * i] > S - 2 || loc[2 * i + 1] < 1 || loc[2 * i + 1] > S - 2)
+                return fail(NGW_E_INVALID_ARG, "agent_location (%d, %d) outside the walled interior", loc[2 * i], loc[2 * i + 1]);
+    if (facing)
+        for (size_t i = 0; i < n; i++)
+            if (facing[i] < 0 || facing[i] > 3) return fail(NGW_E_INVALID_ARG, "agent_facing_id %d outside [0, 3]", facing[i]);
+    std::vector<uint8_t> sel;
+    if (selected) {
+        sel.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            if (selected[i] < 0 || selected[i] >= K) return fail(NGW_E_INVALID_ARG, "selected item %d outside [0, %d)", selected[i], K);
+            sel[i] = (uint8_t)selected[i];
+        }
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const int c = h->cur;
+    H2D(h->b.map[c] + f * S2, map, n * S2);
+    H2D(h->b.loc[c] + f * 2, loc, n * 2 * sizeof(int32_t));
+    H2D(h->b.facing[c] + f, facing, n * sizeof(int32_t));
+    H2D(h->b.inv[c] + f * K, inv, n * K * sizeof(int32_t));
+    H2D(h->b.step_count + f, step_count, n * sizeof(int32_t));
+    H2D(h->b.episode + f, episode, n * sizeof(uint32_t));
+    if (selected) HIP_TRY(hipMemcpyAsync(h->b.selected + f, sel.data(), n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NGW_OK;
+}
+
+int ngw_obs_device_ptrs(ngw_handle* h, void** map, void** loc, void** facing, void** inv) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    const int c = h->cur;
+    if (map) *map = h->b.map[c];
+    if (loc) *loc = h->b.loc[c];
+    if (facing) *facing = h->b.facing[c];
+    if (inv) *inv = h->b.inv[c];
+    return NGW_OK;
+}
+
+int ngw_out_device_ptrs(ngw_handle* h, void** reward, void** done, void** info) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (reward) *reward = h->b.reward;
+    if (done) *done = h->b.done;
+    if (info) *info = h->b.info;
+    return NGW_OK;
+}
+
+int ngw_error_flags(ngw_handle* h, uint32_t* flags) {
+    if (!h || !flags) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(flags, h->b.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemsetAsync(h->b.flags, 0, sizeof(uint32_t), h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NGW_OK;
+}
+
+int ngw_set_timing(ngw_handle* h, int enable) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    if (enable && h->ev.empty()) {
+        h->ev.resize(kTimingRing);
+        for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
+    }
+    if (int rc = drain_timing(h)) return rc;
+    h->timing = enable != 0;
+    h->t_total_ms = 0.0;
+    h->t_n = 0;
+    return NGW_OK;
+}
+
+int ngw_kernel_time(ngw_handle* h, double* total_ms, int64_t* n) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    if (int rc = drain_timing(h)) return rc;
+    if (total_ms) *total_ms = h->t_total_ms;
+    if (n) *n = h->t_n;
+    h->t_total_ms = 0.0;
+    h->t_n = 0;
+    return NGW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// ngw_device.h — launch descriptor shared by the kernel TU (ngw_kernels.hip) and the C-ABI TU (ngw_abi.cpp).
+#ifndef NGW_DEVICE_H
+#define NGW_DEVICE_H
+#include <stdint.h>
+
+#include "../../include/ngw.h"
+
+#define NGW_EPB 64            /* envs per workgroup = one CDNA wavefront, one lane per env */
+
+enum { NGW_MODE_STEP = 0, NGW_MODE_RESET = 1, NGW_MODE_ROLLOUT = 2 };
+
+/* Device buffers of one handle.  map/loc/facing/inv are the batched observation AND the state (ping-pong pair);
+ * selected / step_count / episode are updated in place (each env is owned by exactly one lane). */
+struct NgwBufs {
+    int8_t* map[2];       /* [n_pad][S*S]  */
+    int32_t* loc[2];      /* [n_pad][2]    */
+    int32_t* facing[2];   /* [n_pad]       */
+    int32_t* inv[2];      /* [n_pad][K]    */
+    uint8_t* selected;    /* [n_pad] item id, 0 = ''  */
+    int32_t* step_count;  /* [n_pad] */
+    uint32_t* episode;    /* [n_pad] reset counter, keys the Philox stream */
+    int32_t* reward;      /* [n_pad] */
+    uint8_t* done;        /* [n_pad] */
+    uint32_t* info;       /* [n_pad] packed, see NGW_INFO_* */
+    uint32_t* flags;      /* [1] sticky NGW_F_* */
+    uint16_t* perm;       /* [S*S][n_pad] AddItem shuffle scratch, or nullptr */
+};
+
+struct NgwLaunch {
+    NgwBufs b;
+    int64_t n, n_pad, env_base, t0;
+    uint64_t seed, action_seed;
+    const int32_t* actions;      /* device, NGW_MODE_STEP */
+    const uint8_t* reset_mask;   /* device or nullptr, NGW_MODE_RESET */
+    int32_t cur, mode, n_steps, autoreset, horizon;
+    int32_t S, S2, MS, K, CW;    /* MS = LDS bytes per env map (MS/4 odd), CW = candidate mask words */
+    uint32_t magic;              /* ceil(2^32 / (S2/4)) (or / S2 for odd S): exact division of chunk offsets */
+    uint32_t off_inv, off_cand, off_spec;   /* LDS dword offsets */
+    double addq[32];             /* AddItem: pct / 100.0 for pct in [pct_lo, pct_hi) as the host's IEEE double */
+};
+
+#ifdef __cplusplus
+extern "C"
+#endif
+hipError_t ngw_launch(const ngw_spec* sp, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream);
+
+#endif

@@ -1,0 +1,211 @@
+"""VecNovelGridworld - N concurrent environments on one MI355X behind the reference's step()/reset() contract.
+
+Batched mirror of the reference `gym.Env` surface (gym_novel_gridworlds/envs/pogostick_v1_env.py):
+`reset()` :86, `step(action_id)` :230 -> `(obs, reward, done, info)`, `get_observation()` :214 with the Dict
+observation of map / agent_location / agent_facing_id / inventory_items_quantity, plus `inject_novelty`
+semantics through `novelty=`.  All computation happens in the HIP kernels behind the C-ABI (`_cabi.py`)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _cabi
+from .novelty import apply_novelty
+from .spec import F_INVALID_ACTION, F_PLACEMENT, STEP_COSTS, EnvSpec, make_spec
+
+_COST_F64 = np.array([float(c) for c in STEP_COSTS], np.float64)
+PLACEMENT_MESSAGE = "Cannot place items, increase map size!"          # pogostick_v1_env.py:167
+
+
+class _DevArray:
+    """Zero-copy view of a device buffer for torch.as_tensor (CUDA array interface, also honoured on ROCm)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (int(ptr), False),
+                                         'version': 2, 'strides': None}
+
+
+class VecNovelGridworld:
+    def __init__(self, env_id='NovelGridworld-Pogostick-v1', num_envs=1, map_size=None, novelty=None, device=0,
+                 seed=0, autoreset=False, horizon=0, env_index_base=0, spec=None):
+        if spec is None:
+            spec = make_spec(env_id, map_size)
+            if novelty:
+                novs = [novelty] if isinstance(novelty[0], str) else list(novelty)
+                for nv in novs:
+                    apply_novelty(spec, *nv)
+        assert isinstance(spec, EnvSpec)
+        self.spec = spec
+        self.cspec = spec.compile()
+        self.num_envs = int(num_envs)
+        self.device = int(device)
+        self.seed = int(seed)
+        self.map_size = spec.map_size
+        self.n_items = len(spec.items_id)
+        self.items_id = dict(spec.items_id)
+        self.actions_id = dict(spec.actions_id)
+        self.single_action_space_n = spec.action_space_n
+        self._h = C.c_void_p()
+        L = _cabi.lib()
+        _cabi.check(L.ngw_create(C.byref(self.cspec), self.num_envs, self.device, self.seed, int(env_index_base),
+                                 C.byref(self._h)))
+        self.autoreset, self.horizon = bool(autoreset), int(horizon)
+        _cabi.check(L.ngw_set_autoreset(self._h, int(self.autoreset), self.horizon))
+        N, S, K = self.num_envs, self.map_size, self.n_items
+        self._obs = {'map': np.zeros((N, S, S), np.int8), 'agent_location': np.zeros((N, 2), np.int32),
+                     'agent_facing_id': np.zeros(N, np.int32), 'inventory_items_quantity': np.zeros((N, K), np.int32)}
+        self._reward = np.zeros(N, np.int32)
+        self._done = np.zeros(N, np.uint8)
+        self._result = np.zeros(N, np.uint8)
+        self._cost = np.zeros(N, np.uint8)
+        self._msg = np.zeros(N, np.uint16)
+        self._arg = np.zeros(N, np.uint16)
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            _cabi.lib().ngw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def set_autoreset(self, autoreset, horizon=0):
+        self.autoreset, self.horizon = bool(autoreset), int(horizon)
+        _cabi.check(_cabi.lib().ngw_set_autoreset(self._h, int(self.autoreset), self.horizon))
+
+    def set_stream(self, hip_stream_ptr):
+        _cabi.check(_cabi.lib().ngw_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    # ------------------------------------------------------------------ reference surface, batched
+    def reset(self, mask=None, copy=False):
+        """reset() for all envs (or mask != 0).  Returns the Dict observation (host arrays)."""
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, np.uint8)
+            assert m.shape == (self.num_envs,)
+        _cabi.check(_cabi.lib().ngw_reset(self._h, _cabi._ptr(m, np.uint8)))
+        self._raise_flags()
+        return self.get_observation(copy)
+
+    def step(self, actions, copy=False):
+        """step(action_id) for every env: (obs, reward[N] i32, done[N] bool, info) with host arrays.
+
+        info = {'result' bool[N], 'step_cost' f64[N], 'step_cost_code', 'message_code', 'message_arg'};
+        `messages(info, actions)` formats the reference's strings lazily."""
+        a = np.ascontiguousarray(actions, np.int32)
+        assert a.shape == (self.num_envs,)
+        _cabi.check(_cabi.lib().ngw_step(self._h, _cabi._ptr(a, np.int32)))
+        self._last_actions = a
+        obs = self.get_observation(copy)
+        reward, done, info = self.get_step_out(copy)
+        self._raise_flags()
+        return obs, reward, done, info
+
+    def get_observation(self, copy=False):
+        o = self._obs
+        _cabi.check(_cabi.lib().ngw_get_obs(self._h, _cabi._ptr(o['map'], np.int8), _cabi._ptr(o['agent_location'], np.int32),
+                                            _cabi._ptr(o['agent_facing_id'], np.int32),
+                                            _cabi._ptr(o['inventory_items_quantity'], np.int32)))
+        return {k: v.copy() for k, v in o.items()} if copy else o
+
+    def get_step_out(self, copy=False):
+        _cabi.check(_cabi.lib().ngw_get_step_out(self._h, _cabi._ptr(self._reward, np.int32), _cabi._ptr(self._done, np.uint8),
+                                                 _cabi._ptr(self._result, np.uint8), _cabi._ptr(self._cost, np.uint8),
+                                                 _cabi._ptr(self._msg, np.uint16), _cabi._ptr(self._arg, np.uint16)))
+        info = {'result': self._result.astype(bool), 'step_cost': _COST_F64[self._cost], 'step_cost_code': self._cost,
+                'message_code': self._msg, 'message_arg': self._arg}
+        reward, done = self._reward, self._done.astype(bool)
+        if copy:
+            reward = reward.copy()
+            info = {k: v.copy() for k, v in info.items()}
+        return reward, done, info
+
+    def messages(self, info, actions):
+        return [self.spec.format_message(int(a), int(c), int(g))
+                for a, c, g in zip(actions, info['message_code'], info['message_arg'])]
+
+    def step_costs(self, info):
+        """step_cost as the reference's Python objects (float or int)."""
+        return [STEP_COSTS[int(c)] for c in info['step_cost_code']]
+
+    # ------------------------------------------------------------------ device-resident path
+    def step_device(self, actions_ptr):
+        """One batched step with int32 actions already in HBM (`actions_ptr` = device address, e.g. tensor.data_ptr())."""
+        _cabi.check(_cabi.lib().ngw_step_device(self._h, C.c_void_p(int(actions_ptr))))
+
+    def rollout(self, n_steps, action_seed=1234, t0=0):
+        """Fused mode: n_steps steps in one launch with on-device uniform actions."""
+        _cabi.check(_cabi.lib().ngw_rollout(self._h, int(n_steps), int(action_seed), int(t0)))
+
+    def sync(self):
+        _cabi.check(_cabi.lib().ngw_sync(self._h))
+
+    def error_flags(self):
+        f = C.c_uint32(0)
+        _cabi.check(_cabi.lib().ngw_error_flags(self._h, C.byref(f)))
+        return f.value
+
+    def _raise_flags(self):
+        f = self.error_flags()
+        if f & F_PLACEMENT:
+            raise AssertionError(PLACEMENT_MESSAGE)
+        if f & F_INVALID_ACTION:
+            raise ValueError("action id outside [0, %d) is not in list" % len(self.actions_id))
+
+    def device_observation(self):
+        """Current observation buffers as torch tensors (zero copy; valid until the next step/reset)."""
+        import torch
+        p = [C.c_void_p() for _ in range(4)]
+        _cabi.check(_cabi.lib().ngw_obs_device_ptrs(self._h, *[C.byref(x) for x in p]))
+        N, S, K = self.num_envs, self.map_size, self.n_items
+        dev = 'cuda:%d' % self.device
+        return {'map': torch.as_tensor(_DevArray(p[0].value, (N, S, S), '|i1'), device=dev),
+                'agent_location': torch.as_tensor(_DevArray(p[1].value, (N, 2), '<i4'), device=dev),
+                'agent_facing_id': torch.as_tensor(_DevArray(p[2].value, (N,), '<i4'), device=dev),
+                'inventory_items_quantity': torch.as_tensor(_DevArray(p[3].value, (N, K), '<i4'), device=dev)}
+
+    def device_outputs(self):
+        import torch
+        p = [C.c_void_p() for _ in range(3)]
+        _cabi.check(_cabi.lib().ngw_out_device_ptrs(self._h, *[C.byref(x) for x in p]))
+        N, dev = self.num_envs, 'cuda:%d' % self.device
+        return {'reward': torch.as_tensor(_DevArray(p[0].value, (N,), '<i4'), device=dev),
+                'done': torch.as_tensor(_DevArray(p[1].value, (N,), '|u1'), device=dev),
+                'info': torch.as_tensor(_DevArray(p[2].value, (N,), '<i4'), device=dev)}
+
+    # ------------------------------------------------------------------ state (checkpoint / oracle injection)
+    def get_state(self, first=0, count=None):
+        count = self.num_envs - first if count is None else count
+        S2, K = self.map_size ** 2, self.n_items
+        st = {'map': np.zeros((count, S2), np.int8), 'loc': np.zeros((count, 2), np.int32),
+              'facing': np.zeros(count, np.int32), 'inv': np.zeros((count, K), np.int32),
+              'selected': np.zeros(count, np.int32), 'step_count': np.zeros(count, np.int32),
+              'episode': np.zeros(count, np.uint32)}
+        _cabi.check(_cabi.lib().ngw_get_state(self._h, first, count, _cabi._ptr(st['map'], np.int8), _cabi._ptr(st['loc'], np.int32),
+                                              _cabi._ptr(st['facing'], np.int32), _cabi._ptr(st['inv'], np.int32),
+                                              _cabi._ptr(st['selected'], np.int32), _cabi._ptr(st['step_count'], np.int32),
+                                              _cabi._ptr(st['episode'], np.uint32)))
+        return st
+
+    def set_state(self, first=0, map=None, loc=None, facing=None, inv=None, selected=None, step_count=None, episode=None):
+        arrs = [(map, np.int8), (loc, np.int32), (facing, np.int32), (inv, np.int32), (selected, np.int32),
+                (step_count, np.int32), (episode, np.uint32)]
+        conv = [None if a is None else np.ascontiguousarray(a, dt) for a, dt in arrs]
+        counts = {len(a) for a in conv if a is not None}
+        assert len(counts) == 1, "all state arrays must cover the same number of envs"
+        count = counts.pop()
+        if conv[0] is not None:
+            conv[0] = conv[0].reshape(count, -1)
+        _cabi.check(_cabi.lib().ngw_set_state(self._h, first, count, *[_cabi._ptr(a, dt) for a, (_, dt) in zip(conv, arrs)]))
+
+    # ------------------------------------------------------------------ timing (bench roofline leg)
+    def set_timing(self, enable):
+        _cabi.check(_cabi.lib().ngw_set_timing(self._h, int(bool(enable))))
+
+    def kernel_time(self):
+        ms, n = C.c_double(0), C.c_int64(0)
+        _cabi.check(_cabi.lib().ngw_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -359,5 +359,11 @@ uint32_t ngwo_rollout_batch(const ngw_spec* sp, int64_t n, int32_t n_steps, int6
     return flags;
 }
 
+#ifdef _OPENMP
+#include <omp.h>
+int ngwo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+int ngwo_set_threads(int n) { (void)n; return 1; }
+#endif
 int ngwo_spec_size(void) { return (int)sizeof(ngw_spec); }
 int ngwo_mt_size(void) { return (int)sizeof(ngwo_mt); }

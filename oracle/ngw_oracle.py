@@ -51,8 +51,15 @@ def lib():
         L.ngwo_rollout_batch.argtypes = [vp, C.c_int64, C.c_int32, C.c_int64, C.c_uint64] + st + \
             [u32p, i32p, u8p, u32p, C.c_int, C.c_int, C.c_uint64, C.c_int64]
         L.ngwo_rollout_batch.restype = C.c_uint32
+        L.ngwo_set_threads.argtypes = [C.c_int]
+        L.ngwo_set_threads.restype = C.c_int
         _lib = L
     return _lib
+
+
+def set_threads(n):
+    """OpenMP threads used by the batched drivers; returns the count in effect."""
+    return lib().ngwo_set_threads(int(n))
 
 
 class MT19937:

@@ -198,3 +198,47 @@ def replay_solved(cfg, backend_cls, **kw):
             if t == lens[k] - 1:
                 assert g['so%d_done' % k][t] == 1
     return sum(lens)
+
+
+class HipBackend:
+    """n envs on the MI355X through the C-ABI (VecNovelGridworld); same interface as OracleBackend."""
+
+    def __init__(self, spec, n, **kw):
+        from gym_novel_gridworlds_amd import VecNovelGridworld
+        self.spec = spec
+        self.v = VecNovelGridworld(spec=spec, num_envs=n, **kw)
+        self.n = n
+
+    def load(self, i, map_, loc, facing, inv=None, sel=0, step_count=0):
+        K = self.v.n_items
+        self.v.set_state(i, map=np.asarray(map_, np.int8)[None], loc=np.asarray(loc, np.int32)[None],
+                         facing=np.array([facing], np.int32),
+                         inv=np.zeros((1, K), np.int32) if inv is None else np.asarray(inv, np.int32)[None],
+                         selected=np.array([sel], np.int32), step_count=np.array([step_count], np.int32))
+
+    def load_all(self, map_, loc, facing, inv, sel):
+        self.v.set_state(0, map=map_, loc=loc, facing=facing, inv=inv, selected=sel,
+                         step_count=np.zeros(self.n, np.int32))
+
+    def add_inventory(self, i, item, q):
+        st = self.v.get_state(i, 1)
+        st['inv'][0, item] += q
+        self.v.set_state(i, inv=st['inv'])
+
+    def step(self, actions):
+        import ctypes as C
+        from gym_novel_gridworlds_amd import _cabi
+        a = np.ascontiguousarray(actions, np.int32)
+        L = _cabi.lib()
+        rc = L.ngw_step(self.v._h, _cabi._ptr(a, np.int32))
+        if rc == _cabi.E_INVALID_ACTION:
+            return dict(flags=1)
+        _cabi.check(rc)
+        reward, done, info = self.v.get_step_out(copy=True)
+        return dict(flags=self.v.error_flags(), reward=reward, done=done.astype(np.uint8), result=info['result'].astype(np.uint8),
+                    cost_code=info['step_cost_code'], msg_code=info['message_code'], msg_arg=info['message_arg'])
+
+    def state(self):
+        st = self.v.get_state()
+        return dict(map=st['map'], loc=st['loc'], facing=st['facing'], inv=st['inv'], sel=st['selected'],
+                    step_count=st['step_count'], episode=st['episode'])

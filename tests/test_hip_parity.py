@@ -1,0 +1,221 @@
+"""Parity of the HIP path (through the C-ABI) against the golden vectors and the CPU oracle.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+import ngw_testlib as T
+from gym_novel_gridworlds_amd import VecNovelGridworld
+from gym_novel_gridworlds_amd.spec import make_spec
+from oracle.ngw_oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+ALL = list(T.CFGS)
+STATE_KEYS = ('map', 'loc', 'facing', 'inv', 'selected', 'step_count', 'episode')
+
+
+def oracle_state(o):
+    st = o.st
+    return dict(map=st.map, loc=st.loc, facing=st.facing, inv=st.inv, selected=st.selected, step_count=st.step_count,
+                episode=st.episode)
+
+
+def assert_state_equal(v, o, where):
+    hs, os_ = v.get_state(), oracle_state(o)
+    for k in STATE_KEYS:
+        bad = np.nonzero((hs[k] != os_[k]).reshape(len(hs[k]), -1).any(1))[0]
+        assert bad.size == 0, "%s: %s differs for %d envs, first env %d" % (where, k, bad.size, bad[0])
+
+
+# ------------------------------------------------------------------ golden vectors from the reference
+@pytest.mark.parametrize('cfg', ALL)
+def test_traces_match_reference(cfg):
+    assert T.replay_traces(cfg, T.HipBackend) > 0
+
+
+@pytest.mark.parametrize('cfg', ALL)
+def test_single_steps_match_reference(cfg):
+    assert T.replay_single_steps(cfg, T.HipBackend) > 0
+
+
+@pytest.mark.parametrize('cfg', [c for c in ALL if T.spec_json()['cfgs'][c]['n_solved']])
+def test_solved_episodes_match_reference(cfg):
+    assert T.replay_solved(cfg, T.HipBackend) > 0
+
+
+# ------------------------------------------------------------------ oracle on the same seeded inputs
+@pytest.mark.parametrize('cfg,n', [('pogo10', 5000), ('bow20', 1500), ('axe10', 4096), ('add32', 300), ('pogo13', 777),
+                                   ('bow10', 1000), ('axe12bi', 1000), ('add12m', 640), ('add11e', 500), ('bowaxe16', 900)])
+def test_reset_matches_oracle(cfg, n):
+    """reset(): template + per-env Philox item scatter (+ AddItem pass), three episodes, ragged N, masked reset."""
+    spec = T.build_spec(cfg)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=99, env_index_base=12345)
+    o = Oracle(spec.compile(), n, seed=99, env_index_base=12345)
+    for ep in range(2):
+        v.reset()
+        assert o.reset() == 0
+        assert_state_equal(v, o, '%s reset %d' % (cfg, ep))
+    mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+    v.reset(mask)
+    o.reset(mask)
+    assert_state_equal(v, o, cfg + ' masked reset')
+    obs = v.get_observation()
+    assert (obs['map'].reshape(n, -1) == o.st.map).all() and (obs['agent_location'] == o.st.loc).all()
+    assert (obs['agent_facing_id'] == o.st.facing).all() and (obs['inventory_items_quantity'] == o.st.inv).all()
+
+
+@pytest.mark.parametrize('cfg,n,steps,horizon', [('pogo10', 4096, 260, 50), ('bow20', 1024, 150, 40), ('axe10', 4096, 260, 50),
+                                                 ('add32', 256, 60, 25), ('axe12bi', 1000, 120, 30), ('bow10', 999, 150, 0)])
+def test_autoreset_steps_match_oracle(cfg, n, steps, horizon):
+    """Random actions with same-step autoreset (done or horizon): outputs every step, full state at checkpoints."""
+    spec = T.build_spec(cfg)
+    A = len(spec.actions_id)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=7, autoreset=True, horizon=horizon)
+    o = Oracle(spec.compile(), n, seed=7, autoreset=True, horizon=horizon)
+    v.reset()
+    o.reset()
+    rs = np.random.RandomState(3)
+    goal_in = spec.recipes[spec.goal_item_to_craft]['input']
+    for t in range(steps):
+        if t % 20 == 7:      # hand every 5th env the goal recipe's inputs so that some episodes end with done
+            st = v.get_state()
+            for name, q in goal_in.items():
+                st['inv'][::5, spec.items_id[name]] += q
+                o.st.inv[::5, spec.items_id[name]] += q
+            v.set_state(0, inv=st['inv'])
+        a = rs.randint(0, A, size=n).astype(np.int32)
+        _, reward, done, info = v.step(a)
+        assert o.step(a) == 0
+        where = '%s step %d' % (cfg, t)
+        assert (reward == o.reward).all(), where
+        assert (done == o.done.astype(bool)).all(), where
+        assert (info['result'] == o.result.astype(bool)).all() and (info['step_cost_code'] == o.cost_code).all(), where
+        assert (info['message_code'] == o.msg_code).all() and (info['message_arg'] == o.msg_arg).all(), where
+        if t % 25 == 24 or t == steps - 1:
+            assert_state_equal(v, o, where)
+    assert o.st.episode.max() >= 2
+
+
+@pytest.mark.parametrize('cfg,n,steps', [('pogo10', 8192, 330), ('axe10', 4096, 250), ('bow20', 1024, 120), ('add32', 128, 70)])
+def test_fused_rollout_matches_oracle(cfg, n, steps):
+    """ngw_rollout: T steps in one launch with in-kernel uniform actions == oracle stepping the same action stream."""
+    spec = T.build_spec(cfg)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=5, autoreset=True, horizon=100, env_index_base=1 << 33)
+    o = Oracle(spec.compile(), n, seed=5, autoreset=True, horizon=100, env_index_base=1 << 33)
+    v.reset()
+    o.reset()
+    t0 = 0
+    for chunk in (1, 2, steps - 3):
+        v.rollout(chunk, action_seed=1234, t0=t0)
+        assert o.rollout(chunk, 1234, t0) == 0
+        t0 += chunk
+        assert_state_equal(v, o, '%s rollout to t=%d' % (cfg, t0))
+        reward, done, info = v.get_step_out()
+        assert (reward == o.reward).all() and (done == o.done.astype(bool)).all()
+        assert (info['message_code'] == o.msg_code).all() and (info['step_cost_code'] == o.cost_code).all()
+    assert v.error_flags() == 0
+
+
+# ------------------------------------------------------------------ BASELINE sizes: size-independent properties
+def test_full_size_properties_pogostick_65536():
+    """BASELINE config 2 at full size: determinism, shard independence, structural invariants, oracle on a sample."""
+    n = 65536
+    spec = T.build_spec('pogo10')
+    S, K = spec.map_size, len(spec.items_id)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=0, autoreset=True, horizon=100)
+    v.reset()
+    v.rollout(250, action_seed=1234)
+    st = v.get_state()
+    m = st['map'].reshape(n, S, S)
+    wall = spec.items_id['wall']
+    assert (m[:, 0, :] == wall).all() and (m[:, -1, :] == wall).all() and (m[:, :, 0] == wall).all() and (m[:, :, -1] == wall).all()
+    assert (m[:, 1:-1, 1:-1] != wall).all() and (m >= 0).all() and (m < K).all()
+    r, c = st['loc'][:, 0], st['loc'][:, 1]
+    assert (m[np.arange(n), r, c] == 0).all()                      # the agent always stands on air
+    assert (st['inv'] >= 0).all() and (st['step_count'] == 250 % 100).all() and (st['episode'] == 3).all()
+    # conservation: tree_log on the map + in the inventory + consumed by Craft_plank never exceeds the 5 placed
+    log = spec.items_id['tree_log']
+    assert ((m == log).sum((1, 2)) + st['inv'][:, log] <= 5).all()
+    # determinism + shard independence: two half-size handles keyed by global env index reproduce the halves
+    for base in (0, n // 2):
+        h = VecNovelGridworld(spec=spec, num_envs=n // 2, seed=0, autoreset=True, horizon=100, env_index_base=base)
+        h.reset()
+        h.rollout(250, action_seed=1234)
+        hs = h.get_state()
+        for k in STATE_KEYS:
+            assert (hs[k] == st[k][base:base + n // 2]).all(), k
+        h.close()
+    # the oracle on a strided sample of envs (each env is independent, keyed by its global index)
+    for e in (0, 1, 63, 64, 4097, 65535):
+        o = Oracle(spec.compile(), 1, seed=0, autoreset=True, horizon=100, env_index_base=e)
+        o.reset()
+        o.rollout(250, 1234, 0)
+        os_ = oracle_state(o)
+        for k in STATE_KEYS:
+            assert (os_[k][0] == st[k][e]).all(), (k, e)
+
+
+def test_full_size_bow_65536_and_device_views():
+    """BASELINE config 3 at full size + zero-copy device observation == host observation."""
+    import torch
+    n = 65536
+    spec = T.build_spec('bow20')
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=11, autoreset=True, horizon=100)
+    v.reset()
+    acts = torch.randint(0, len(spec.actions_id), (30, n), dtype=torch.int32, device='cuda')
+    torch.cuda.synchronize()
+    for t in range(30):
+        v.step_device(acts[t].data_ptr())
+    v.sync()
+    obs = v.get_observation(copy=True)
+    dev = v.device_observation()
+    assert (dev['map'].cpu().numpy() == obs['map']).all()
+    assert (dev['agent_location'].cpu().numpy() == obs['agent_location']).all()
+    assert (dev['agent_facing_id'].cpu().numpy() == obs['agent_facing_id']).all()
+    assert (dev['inventory_items_quantity'].cpu().numpy() == obs['inventory_items_quantity']).all()
+    o = Oracle(spec.compile(), 256, seed=11, autoreset=True, horizon=100)
+    o.reset()
+    a = acts[:, :256].cpu().numpy()
+    for t in range(30):
+        o.step(a[t])
+    assert (o.st.map.reshape(256, 20, 20) == obs['map'][:256]).all() and (o.st.inv == obs['inventory_items_quantity'][:256]).all()
+
+
+# ------------------------------------------------------------------ error behaviour
+def test_invalid_action_raises_like_reference():
+    ref = T.spec_json()['cfgs']['pogo10']
+    v = VecNovelGridworld(num_envs=3, seed=1)
+    v.reset()
+    before = v.get_state()
+    for a, exc, text in ref['invalid_action_errors']:
+        with pytest.raises(ValueError, match=text):
+            v.step(np.array([0, a, 1], np.int32))
+    after = v.get_state()
+    for k in STATE_KEYS:
+        assert (before[k] == after[k]).all()
+
+
+def test_invalid_device_action_sets_flag_and_leaves_env_untouched():
+    import torch
+    v = VecNovelGridworld(num_envs=130, seed=1)
+    v.reset()
+    before = v.get_state()
+    a = torch.ones(130, dtype=torch.int32, device='cuda')
+    a[77] = 17
+    torch.cuda.synchronize()
+    v.step_device(a.data_ptr())
+    assert v.error_flags() == 1
+    after = v.get_state()
+    assert (after['facing'][77] == before['facing'][77]) and after['step_count'][77] == 0
+    assert (np.delete(after['step_count'], 77) == 1).all()
+
+
+def test_placement_exhaustion_raises_like_reference():
+    with pytest.raises(AssertionError, match="Cannot place items, increase map size!"):
+        VecNovelGridworld(num_envs=64, map_size=6).reset()
+    v = VecNovelGridworld(num_envs=200, map_size=8, seed=3)      # 16 candidates: some envs fail, some do not
+    o = Oracle(make_spec(T.POGO, 8).compile(), 200, seed=3)
+    flags = o.reset()
+    try:
+        v.reset()
+        assert flags == 0
+    except AssertionError:
+        assert flags == 2
