@@ -75,6 +75,8 @@ def main():
     ap.add_argument('--workload', default='C2', choices=sorted(WORKLOADS))
     ap.add_argument('--mode', default='step', choices=['step', 'rollout'])
     ap.add_argument('--envs', type=int, default=0, help='envs per GPU (default: the workload\'s)')
+    ap.add_argument('--launch', default='graph', choices=['graph', 'eager'],
+                    help='step mode: replay the K step launches from one hipGraph (default) or launch them one by one')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -105,21 +107,34 @@ def main():
     v.reset()
     steps, warmup = args.steps, args.warmup
 
-    acts = None
+    GRAPH_MAX = 2048                      # kernel nodes per graph; longer runs replay it (its action rows repeat)
+    use_graph = args.mode == 'step' and args.launch == 'graph' and steps >= 2
     if args.mode == 'step':
         # i.i.d. uniform int32 actions over len(actions_id), seed 1234 (+rank), resident in HBM before the timed region
         g = torch.Generator(device='cuda')
         g.manual_seed(ACTION_SEED + rank)
-        ring = min(steps + warmup, 1024)
-        acts = torch.randint(0, A, (ring, n), dtype=torch.int32, device='cuda', generator=g)
-        ptrs = [acts[i].data_ptr() for i in range(ring)]
+        rows = warmup + (min(steps, GRAPH_MAX) if use_graph else min(steps, 1024))
+        acts = torch.randint(0, A, (rows, n), dtype=torch.int32, device='cuda', generator=g)
+        ptrs = [acts[i].data_ptr() for i in range(rows)]
+        torch.cuda.synchronize()
+    g_steps = 0
+    if use_graph:
+        g_steps = min(steps, GRAPH_MAX) & ~1
+        v.graph_build(ptrs[warmup], n, g_steps)
 
-    def run(k, t_base):
-        if args.mode == 'step':
-            for i in range(k):
-                v.step_device(ptrs[(t_base + i) % len(ptrs)])
+    def run_eager(k, row0):
+        for i in range(k):
+            v.step_device(ptrs[warmup + (row0 + i) % (len(ptrs) - warmup)] if row0 >= 0 else ptrs[i])
+
+    def run_timed():
+        """exactly `steps` batched steps"""
+        if args.mode == 'rollout':
+            v.rollout(steps, ACTION_SEED, warmup)
+        elif use_graph:
+            v.graph_launch(steps // g_steps)
+            run_eager(steps % g_steps, 0)
         else:
-            v.rollout(k, ACTION_SEED, t_base)
+            run_eager(steps, 0)
 
     def fence():
         v.sync()
@@ -128,10 +143,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run(warmup, 0)
+    if args.mode == 'rollout':
+        v.rollout(warmup, ACTION_SEED, 0)
+    else:
+        run_eager(warmup, -1)
     fence()
+    v.timing_begin()                      # HIP event pair on the kernel's own stream, around the timed launches
     t0 = time.perf_counter()
-    run(steps, warmup)
+    run_timed()
+    dev_ms = v.timing_end()
     fence()
     dt = time.perf_counter() - t0
     assert v.error_flags() == 0
@@ -140,27 +160,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # roofline leg: per-launch HIP-event timing on the kernel's stream (second pass, same inputs)
-    v.set_timing(True)
-    if args.mode == 'step':
-        done_k = 0
-        while done_k < steps:
-            k = min(2048, steps - done_k)
-            run(k, warmup + steps + done_k)
-            v.sync()
-            done_k += k
-    else:
-        run(steps, warmup + steps)
-    k_ms, k_n = v.kernel_time()
-    v.set_timing(False)
-    steps_per_launch = 1 if args.mode == 'step' else steps
-    launch_ms = k_ms / max(k_n, 1)
+    # roofline: algorithmic bytes per launch / average launch duration (device time of the timed region / launches)
+    launches = 1 if args.mode == 'rollout' else steps
+    steps_per_launch = steps if args.mode == 'rollout' else 1
+    launch_ms = dev_ms / launches
     B = algorithmic_bytes(S, K)
     achieved = B * n * steps_per_launch / (launch_ms * 1e-3) / 1e9
     roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel': 'ngw_kernel',
-                'kernel_ms_avg': round(launch_ms, 6), 'launches_timed': int(k_n),
-                'algorithmic_bytes_per_env_step': B, 'env_steps_per_launch': n * steps_per_launch}
+                'kernel_ms_avg': round(launch_ms, 6), 'launches_timed': launches,
+                'algorithmic_bytes_per_env_step': B, 'env_steps_per_launch': n * steps_per_launch,
+                'timing': 'HIP event pair on the kernel stream around the timed launches (includes inter-launch gaps)'}
     pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(pmc):
         rec = json.load(open(pmc)).get('%s_%s' % (args.workload, args.mode))
@@ -176,7 +186,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8/int32', 'data': 'synthetic',
             'config': {'workload': desc, 'name': args.workload, 'envs_per_gpu': n, 'global_envs': n * world,
                        'map_size': S, 'n_items': K, 'n_actions': A, 'horizon': HORIZON, 'autoreset': 'same-step',
-                       'mode': 'one launch per batched step, actions in HBM' if args.mode == 'step'
+                       'mode': ('one launch per batched step (%s), actions in HBM' % ('hipGraph replay' if use_graph else 'eager')) if args.mode == 'step'
                                else 'fused rollout: all steps in one launch, actions generated in-kernel',
                        'parallelism': 'envs sharded x%d, no collective' % world},
             'roofline': roofline,

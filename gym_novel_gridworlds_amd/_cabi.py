@@ -18,7 +18,8 @@ E_INVALID_ARG, E_HIP, E_INVALID_ACTION, E_PLACEMENT, E_NO_DEVICE = -1, -2, -3, -
 SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_count', 'ngw_create', 'ngw_destroy',
            'ngw_set_autoreset', 'ngw_set_stream', 'ngw_reset', 'ngw_step', 'ngw_step_device', 'ngw_rollout',
            'ngw_get_obs', 'ngw_get_step_out', 'ngw_get_state', 'ngw_set_state', 'ngw_obs_device_ptrs',
-           'ngw_out_device_ptrs', 'ngw_sync', 'ngw_error_flags', 'ngw_kernel_time', 'ngw_set_timing']
+           'ngw_out_device_ptrs', 'ngw_sync', 'ngw_error_flags', 'ngw_timing_begin', 'ngw_timing_end',
+           'ngw_graph_build', 'ngw_graph_launch']
 
 _lib = None
 
@@ -72,8 +73,10 @@ def lib():
     L.ngw_out_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.ngw_sync.argtypes = [vp]
     L.ngw_error_flags.argtypes = [vp, C.POINTER(C.c_uint32)]
-    L.ngw_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
-    L.ngw_set_timing.argtypes = [vp, C.c_int]
+    L.ngw_timing_begin.argtypes = [vp]
+    L.ngw_timing_end.argtypes = [vp, C.POINTER(C.c_double)]
+    L.ngw_graph_build.argtypes = [vp, vp, i64, i32]
+    L.ngw_graph_launch.argtypes = [vp, i32]
     if L.ngw_spec_size() != C.sizeof(NgwSpec):
         raise NgwError("ngw_spec layout mismatch: library %d bytes, binding %d bytes" % (L.ngw_spec_size(), C.sizeof(NgwSpec)))
     _lib = L

@@ -32,8 +32,6 @@ int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(NGW_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));     \
     } while (0)
 
-constexpr int kTimingRing = 8192;
-
 }  // namespace
 
 struct ngw_handle {
@@ -48,15 +46,15 @@ struct ngw_handle {
     NgwBufs b{};
     NgwLaunch proto{};           // layout fields filled once
     size_t lds_bytes = 0;
+    int map_mode = 0;
+    NgwDevSpec* dspec = nullptr;      // LUT blob in HBM
     int32_t* actions_dev = nullptr;   // staging for host actions
     uint8_t* mask_dev = nullptr;
     std::vector<void*> allocs;
-    // timing
-    bool timing = false;
-    std::vector<hipEvent_t> ev;   // pairs
-    int ev_used = 0;
-    double t_total_ms = 0.0;
-    int64_t t_n = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing pair
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_steps = 0;
 };
 
 namespace {
@@ -118,29 +116,17 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     a.action_seed = action_seed;
     a.t0 = t0;
     const unsigned grid = (unsigned)(h->n_pad / NGW_EPB);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->timing && h->ev_used + 2 <= (int)h->ev.size()) {
-        e0 = h->ev[h->ev_used++];
-        e1 = h->ev[h->ev_used++];
-        HIP_TRY(hipEventRecord(e0, h->stream));
-    }
-    HIP_TRY(ngw_launch(&h->spec, &a, grid, h->lds_bytes, h->stream));
-    if (e1) HIP_TRY(hipEventRecord(e1, h->stream));
+    HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, grid, h->lds_bytes, h->stream));
     h->cur = (h->cur + n_steps) & 1;
     return NGW_OK;
 }
 
-int drain_timing(ngw_handle* h) {
-    if (h->ev_used == 0) return NGW_OK;
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    for (int i = 0; i + 1 < h->ev_used; i += 2) {
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
-        h->t_total_ms += ms;
-        h->t_n += 1;
-    }
-    h->ev_used = 0;
-    return NGW_OK;
+void drop_graph(ngw_handle* h) {
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    h->graph_exec = nullptr;
+    h->graph = nullptr;
+    h->graph_steps = 0;
 }
 
 }  // namespace
@@ -198,26 +184,38 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     if (!rc) rc = dev_alloc(h, &h->actions_dev, np);
     if (!rc) rc = dev_alloc(h, &h->mask_dev, np);
     if (!rc && spec->additem_item) rc = dev_alloc(h, &h->b.perm, np * S2);
+    if (!rc) rc = dev_alloc(h, &h->dspec, 1);
     if (rc) return bail(rc);
+    {
+        NgwDevSpec hs;
+        memset(&hs, 0, sizeof(hs));
+        hs.sp = *spec;
+        for (int i = 0; i < 32; i++) hs.addq[i] = (double)(spec->additem_pct_lo + i) / 100.0;
+        if (hipMemcpyAsync(h->dspec, &hs, sizeof(hs), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess)
+            return bail(fail(NGW_E_HIP, "spec upload failed"));
+    }
 
     // launch layout
     NgwLaunch& p = h->proto;
     p.n = h->n; p.n_pad = h->n_pad; p.env_base = h->env_base; p.seed = seed;
-    p.S = S; p.S2 = S2; p.K = K;
+    p.S = S; p.S2 = S2; p.K = K; p.KP = K | 1;
+    p.magicK = (uint32_t)((0x100000000ull + (uint32_t)K - 1) / (uint32_t)K);
     const int S2r = (S2 + 3) / 4;                       // dwords per map, rounded up
     const int MSdw = (S2r & 1) ? S2r : S2r + 1;         // odd dword stride -> conflict-free per-lane cell reads
     p.MS = ((S2 & 3) == 0 && (S2r & 1)) ? S2 : MSdw * 4;
+    h->map_mode = (p.MS == S2) ? NGW_MAP_STRAIGHT : (((S2 & 3) == 0) ? NGW_MAP_DWORD : NGW_MAP_BYTE);
     const uint32_t div = ((S2 & 3) == 0) ? (uint32_t)(S2 / 4) : (uint32_t)S2;
     p.magic = (uint32_t)((0x100000000ull + div - 1) / div);
     p.CW = ((S - 4) * (S - 4) + 31) / 32;
     uint32_t off = (uint32_t)(NGW_EPB * p.MS / 4);
     off = (off + 3u) & ~3u;
-    p.off_inv = off; off += (uint32_t)(K * NGW_EPB);
+    p.off_inv = off; off += (uint32_t)(p.KP * NGW_EPB);
     p.off_cand = off; off += (uint32_t)(p.CW * NGW_EPB);
-    p.off_spec = off; off += (uint32_t)(sizeof(ngw_spec) / 4);
+    off = (off + 1u) & ~1u;                             // the blob holds doubles
+    p.off_spec = off; off += (uint32_t)(sizeof(NgwDevSpec) / 4);
     h->lds_bytes = (size_t)off * 4;
     if (h->lds_bytes > 160 * 1024) return bail(fail(NGW_E_INVALID_ARG, "map_size %d needs %zu B of LDS per wavefront (> 160 KiB)", S, h->lds_bytes));
-    for (int i = 0; i < 32; i++) p.addq[i] = (double)(spec->additem_pct_lo + i) / 100.0;
     if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(NGW_E_HIP, "stream sync failed after allocation"));
     *out = h;
     return NGW_OK;
@@ -228,7 +226,9 @@ int ngw_destroy(ngw_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) (void)hipFree(p);
-    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    drop_graph(h);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return NGW_OK;
@@ -246,6 +246,7 @@ int ngw_set_stream(ngw_handle* h, void* hip_stream) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    drop_graph(h);
     if (h->own_stream) { HIP_TRY(hipStreamDestroy(h->stream)); h->own_stream = false; }
     if (hip_stream) {
         h->stream = static_cast<hipStream_t>(hip_stream);
@@ -291,6 +292,15 @@ int ngw_rollout(ngw_handle* h, int32_t n_steps, uint64_t action_seed, int64_t t0
     if (n_steps < 1) return fail(NGW_E_INVALID_ARG, "n_steps must be >= 1");
     HIP_TRY(hipSetDevice(h->device));
     return launch(h, NGW_MODE_ROLLOUT, n_steps, nullptr, nullptr, action_seed, t0);
+}
+
+/* Diagnostic launches (profiling only, not part of include/ngw.h): mode 8 = empty kernel, 9 = stage in/out only. */
+int ngw_debug_launch(ngw_handle* h, int mode, int32_t n_launches) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    for (int i = 0; i < n_launches; i++)
+        if (int rc = launch(h, mode, 1, h->actions_dev, nullptr, 0, 0)) return rc;
+    return NGW_OK;
 }
 
 int ngw_sync(ngw_handle* h) {
@@ -436,28 +446,51 @@ int ngw_error_flags(ngw_handle* h, uint32_t* flags) {
     return NGW_OK;
 }
 
-int ngw_set_timing(ngw_handle* h, int enable) {
+int ngw_timing_begin(ngw_handle* h) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     HIP_TRY(hipSetDevice(h->device));
-    if (enable && h->ev.empty()) {
-        h->ev.resize(kTimingRing);
-        for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
-    }
-    if (int rc = drain_timing(h)) return rc;
-    h->timing = enable != 0;
-    h->t_total_ms = 0.0;
-    h->t_n = 0;
+    if (!h->ev0) { HIP_TRY(hipEventCreate(&h->ev0)); HIP_TRY(hipEventCreate(&h->ev1)); }
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
     return NGW_OK;
 }
 
-int ngw_kernel_time(ngw_handle* h, double* total_ms, int64_t* n) {
-    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+int ngw_timing_end(ngw_handle* h, double* elapsed_ms) {
+    if (!h || !elapsed_ms) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    if (!h->ev0) return fail(NGW_E_INVALID_ARG, "ngw_timing_end without ngw_timing_begin");
     HIP_TRY(hipSetDevice(h->device));
-    if (int rc = drain_timing(h)) return rc;
-    if (total_ms) *total_ms = h->t_total_ms;
-    if (n) *n = h->t_n;
-    h->t_total_ms = 0.0;
-    h->t_n = 0;
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *elapsed_ms = ms;
+    return NGW_OK;
+}
+
+int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps) {
+    if (!h || !actions_dev) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    if (n_steps < 2 || (n_steps & 1)) return fail(NGW_E_INVALID_ARG, "n_steps must be even (the observation buffers ping-pong)");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    drop_graph(h);
+    const int cur0 = h->cur;
+    HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = NGW_OK;
+    for (int i = 0; i < n_steps && !rc; i++) rc = launch(h, NGW_MODE_STEP, 1, actions_dev + (int64_t)i * step_stride, nullptr, 0, 0);
+    hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
+    h->cur = cur0;                                   // capturing enqueued nothing
+    if (rc) { drop_graph(h); return rc; }
+    if (e != hipSuccess) { drop_graph(h); return fail(NGW_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e)); }
+    e = hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { drop_graph(h); return fail(NGW_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+    h->graph_steps = n_steps;
+    return NGW_OK;
+}
+
+int ngw_graph_launch(ngw_handle* h, int32_t reps) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (!h->graph_exec) return fail(NGW_E_INVALID_ARG, "no graph: call ngw_graph_build first");
+    HIP_TRY(hipSetDevice(h->device));
+    for (int i = 0; i < reps; i++) HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));   // even step count: `cur` is unchanged
     return NGW_OK;
 }
 

@@ -7,7 +7,10 @@
 
 #define NGW_EPB 64            /* envs per workgroup = one CDNA wavefront, one lane per env */
 
-enum { NGW_MODE_STEP = 0, NGW_MODE_RESET = 1, NGW_MODE_ROLLOUT = 2 };
+enum { NGW_MODE_STEP = 0, NGW_MODE_RESET = 1, NGW_MODE_ROLLOUT = 2,
+       NGW_MODE_DBG_NOP = 8 /* exit at once: launch floor */, NGW_MODE_DBG_COPY = 9 /* stage in/out, no step logic */ };
+/* how a wave's map chunk is laid out in LDS: same image as HBM / odd-dword-padded rows / byte-granular (odd S) */
+enum { NGW_MAP_STRAIGHT = 0, NGW_MAP_DWORD = 1, NGW_MAP_BYTE = 2 };
 
 /* Device buffers of one handle.  map/loc/facing/inv are the batched observation AND the state (ping-pong pair);
  * selected / step_count / episode are updated in place (each env is owned by exactly one lane). */
@@ -33,15 +36,21 @@ struct NgwLaunch {
     const int32_t* actions;      /* device, NGW_MODE_STEP */
     const uint8_t* reset_mask;   /* device or nullptr, NGW_MODE_RESET */
     int32_t cur, mode, n_steps, autoreset, horizon;
-    int32_t S, S2, MS, K, CW;    /* MS = LDS bytes per env map (MS/4 odd), CW = candidate mask words */
+    int32_t S, S2, MS, K, KP, CW; /* MS = LDS bytes per env map (MS/4 odd), KP = K|1 LDS inventory stride, CW = candidate words */
     uint32_t magic;              /* ceil(2^32 / (S2/4)) (or / S2 for odd S): exact division of chunk offsets */
+    uint32_t magicK;             /* ceil(2^32 / K): exact division of inventory chunk offsets (< 64*K) */
     uint32_t off_inv, off_cand, off_spec;   /* LDS dword offsets */
+};
+
+/* LUT blob kept in HBM (one per handle) and copied to LDS by every wavefront. */
+struct NgwDevSpec {
+    ngw_spec sp;
     double addq[32];             /* AddItem: pct / 100.0 for pct in [pct_lo, pct_hi) as the host's IEEE double */
 };
 
 #ifdef __cplusplus
 extern "C"
 #endif
-hipError_t ngw_launch(const ngw_spec* sp, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream);
+hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, unsigned grid, size_t lds_bytes, hipStream_t stream);
 
 #endif

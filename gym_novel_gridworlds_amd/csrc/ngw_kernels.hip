@@ -9,6 +9,7 @@
 //      coalesced 16-B stores, plus reward / done / packed info.
 // The observation buffers ARE the state, so a step moves 2*S*S + 8*K + ~60 bytes per env and nothing else
 // (SURVEY.md §8(d) prices 2*S*S + 12*K + 45).  Integer/byte work only: no MFMA.
+// Every global load of a phase is issued before its first consumer so a phase costs ONE memory round trip.
 //
 // Semantics follow the reference line by line (citations at each branch):
 //   gym_novel_gridworlds/envs/pogostick_v1_env.py  reset :86-181, step :230-367, craft :413-474, grab :538-554
@@ -20,7 +21,7 @@
 #include "../../include/ngw.h"
 #include "ngw_device.h"
 
-static_assert(sizeof(ngw_spec) % 4 == 0, "ngw_spec is copied to LDS by dwords");
+static_assert(sizeof(NgwDevSpec) % 4 == 0, "the spec blob is copied to LDS by dwords");
 
 namespace {
 
@@ -85,14 +86,14 @@ __device__ __forceinline__ int nth_set_bit(uint32_t x, int n) {
 
 // ---------------------------------------------------------------- per-lane reset on the LDS map
 // pogostick_v1_env.py:86-157 + add_item_to_map :159-181 (+ AddItem.reset, AxeEasy.reset).  `mp` = this lane's map
-// in LDS, `inv` = this lane's inventory column (stride EPB dwords), `cand` = candidate bitmask column (stride EPB).
-__device__ __forceinline__ uint32_t reset_lane(const ngw_spec& sp, const NgwLaunch& a, int8_t* mp, int32_t* inv,
-                                               uint32_t* cand, uint64_t env_global, int64_t env_local, uint32_t episode,
-                                               int& r_out, int& c_out, int& f_out) {
+// in LDS, `inv` = this lane's inventory row, `cand` = candidate bitmask column (stride EPB).
+__device__ __forceinline__ uint32_t reset_lane(const ngw_spec& sp, const double* addq, const NgwLaunch& a, int8_t* mp, int32_t* inv,
+                                            uint32_t* cand, uint64_t env_global, int64_t env_local, uint32_t episode,
+                                            int& r_out, int& c_out, int& f_out) {
     const int S = a.S, K = a.K, W = S - 4, ncand = W * W;
     Philox px;
     philox_init(px, a.seed, env_global, episode);
-    for (int k = 0; k < K; k++) inv[k * EPB] = 0;                                  // :119
+    for (int k = 0; k < K; k++) inv[k] = 0;                                        // :119
     for (int r = 0; r < S; r++)                                                    // :129-130 wall ring around air
         for (int c = 0; c < S; c++)
             mp[r * S + c] = (r == 0 || c == 0 || r == S - 1 || c == S - 1) ? (int8_t)sp.wall_item : (int8_t)0;
@@ -139,92 +140,172 @@ __device__ __forceinline__ uint32_t reset_lane(const ngw_spec& sp, const NgwLaun
             perm[(int64_t)i * ps] = y; perm[(int64_t)j * ps] = x;
         }
         const int pct = (int)bounded(px, (uint32_t)(sp.additem_pct_hi - sp.additem_pct_lo - 1));   // randint(lo, hi)
-        const int cnt = (int)ceil((double)n_air * a.addq[pct]);                    // int(np.ceil(len * (pct / 100)))
+        const int cnt = (int)ceil((double)n_air * addq[pct]);                      // int(np.ceil(len * (pct / 100)))
         for (int i = 0; i < cnt; i++) {
             int cell = perm[(int64_t)i * ps];
             if (cell != agent) mp[cell] = (int8_t)sp.additem_item;                 // :1027
         }
     }
-    if (sp.inv_start_item && !flags) inv[sp.inv_start_item * EPB] = sp.inv_start_qty;   // AxeEasy.reset :33
+    if (sp.inv_start_item && !flags) inv[sp.inv_start_item] = sp.inv_start_qty;         // AxeEasy.reset :33
     return flags;
 }
 
 // ---------------------------------------------------------------- map staging HBM <-> LDS (coalesced 16-B pieces)
-// The wave's 64 maps are one contiguous 64*S2-byte chunk in HBM.  In LDS each env's map starts at e*MS bytes with
-// MS/4 odd so that 64 lanes reading "their" cell hit distinct banks.
-template <bool LOAD>
-__device__ __forceinline__ void stage_maps(const NgwLaunch& a, uint32_t* lds_map, int8_t* gchunk, int tid) {
-    const int npieces = 4 * a.S2;                                                  // EPB * S2 / 16
-    uint4* g4 = reinterpret_cast<uint4*>(gchunk);
-    if (a.MS == a.S2) {                                                            // LDS image == HBM image
-        uint4* l4 = reinterpret_cast<uint4*>(lds_map);
-        for (int p = tid; p < npieces; p += EPB) {
-            if (LOAD) l4[p] = g4[p]; else g4[p] = l4[p];
-        }
-    } else if ((a.S2 & 3) == 0) {                                                  // dword granularity, padded stride
-        const int S2dw = a.S2 >> 2, MSdw = a.MS >> 2;
-        for (int p = tid; p < npieces; p += EPB) {
-            uint32_t d = (uint32_t)p * 4u;                                         // dword offset inside the chunk
-            uint32_t e = __umulhi(d, a.magic);                                     // d / S2dw
-            uint32_t o = d - e * (uint32_t)S2dw;
-            uint32_t v[4];
-            if (LOAD) { uint4 t = g4[p]; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+// The wave's 64 maps are one contiguous 64*S2-byte chunk in HBM = 4*S2 pieces of 16 B; lane l owns pieces
+// l, l+64, ...  A round moves PB pieces per lane: ALL its global loads are issued before the first LDS write (and
+// all LDS reads before the first global store), so a round costs one memory round trip, not PB.
+// In LDS each env's map starts at e*MS bytes with MS/4 odd, so 64 lanes reading "their" cell hit distinct banks.
+constexpr int PB = 8;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                       // native vector: stays in VGPRs
+
+// Loads are UNCONDITIONAL on a clamped index (a duplicate in-bounds load is harmless and keeps the values in plain
+// registers); only stores and LDS writes are predicated.
+__device__ __forceinline__ void pieces_load(u32x4 (&buf)[PB], const u32x4* g4, int base, int npieces, int tid) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (o >= (uint32_t)S2dw) { o = 0; e++; }
-                uint32_t* dst = lds_map + e * (uint32_t)MSdw + o;
-                if (LOAD) *dst = v[q]; else v[q] = *dst;
-                o++;
+    for (int j = 0; j < PB; j++) buf[j] = g4[min(base + tid + EPB * j, npieces - 1)];
+}
+
+__device__ __forceinline__ void pieces_store(const u32x4 (&buf)[PB], u32x4* g4, int base, int npieces, int tid) {
+#pragma unroll
+    for (int j = 0; j < PB; j++) {
+        const int p = base + tid + EPB * j;
+        if (p < npieces) g4[p] = buf[j];
+    }
+}
+
+// LDS <-> register pieces.  TO_LDS: buf -> lds, else lds -> buf.
+template <bool TO_LDS, int MAPMODE>
+__device__ __forceinline__ void pieces_lds(u32x4 (&buf)[PB], const NgwLaunch& a, uint32_t* lds_map, int base, int npieces, int tid) {
+    if (MAPMODE == NGW_MAP_STRAIGHT) {                                             // LDS image == HBM image
+        u32x4* l4 = reinterpret_cast<u32x4*>(lds_map);
+#pragma unroll
+        for (int j = 0; j < PB; j++) {
+            const int p = base + tid + EPB * j;
+            if (TO_LDS) { if (p < npieces) l4[p] = buf[j]; } else buf[j] = l4[min(p, npieces - 1)];
+        }
+    } else if (MAPMODE == NGW_MAP_DWORD) {                                         // dword granularity, padded stride
+        const uint32_t S2dw = (uint32_t)a.S2 >> 2, MSdw = (uint32_t)a.MS >> 2;
+#pragma unroll
+        for (int j = 0; j < PB; j++) {
+            const int p0 = base + tid + EPB * j;
+            const int p = TO_LDS ? p0 : min(p0, npieces - 1);
+            if (!TO_LDS || p0 < npieces) {
+                const uint32_t d = (uint32_t)p * 4u;                               // dword offset inside the chunk
+                uint32_t e = __umulhi(d, a.magic);                                 // d / S2dw (exact, see ngw_abi.cpp)
+                uint32_t o = d - e * S2dw;
+                uint32_t v[4] = {buf[j].x, buf[j].y, buf[j].z, buf[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (o >= S2dw) { o = 0; e++; }
+                    uint32_t* cell = lds_map + e * MSdw + o;
+                    if (TO_LDS) *cell = v[q]; else v[q] = *cell;
+                    o++;
+                }
+                if (!TO_LDS) buf[j] = u32x4{v[0], v[1], v[2], v[3]};
             }
-            if (!LOAD) g4[p] = make_uint4(v[0], v[1], v[2], v[3]);
         }
     } else {                                                                       // odd S: byte granularity
-        int8_t* lb = reinterpret_cast<int8_t*>(lds_map);
-        for (int p = tid; p < npieces; p += EPB) {
-            uint32_t g = (uint32_t)p * 16u;
-            uint32_t e = __umulhi(g, a.magic);                                     // g / S2
-            uint32_t o = g - e * (uint32_t)a.S2;
-            union { uint4 v; int8_t b[16]; } u;
-            if (LOAD) u.v = g4[p];
+        uint8_t* lb = reinterpret_cast<uint8_t*>(lds_map);
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                if (o >= (uint32_t)a.S2) { o = 0; e++; }
-                int8_t* dst = lb + e * (uint32_t)a.MS + o;
-                if (LOAD) *dst = u.b[q]; else u.b[q] = *dst;
-                o++;
+        for (int j = 0; j < PB; j++) {
+            const int p0 = base + tid + EPB * j;
+            const int p = TO_LDS ? p0 : min(p0, npieces - 1);
+            if (!TO_LDS || p0 < npieces) {
+                const uint32_t g = (uint32_t)p * 16u;
+                uint32_t e = __umulhi(g, a.magic);                                 // g / S2
+                uint32_t o = g - e * (uint32_t)a.S2;
+                uint32_t v[4] = {buf[j].x, buf[j].y, buf[j].z, buf[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t w = TO_LDS ? v[q] : 0u;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        if (o >= (uint32_t)a.S2) { o = 0; e++; }
+                        uint8_t* cell = lb + e * (uint32_t)a.MS + o;
+                        if (TO_LDS) *cell = (uint8_t)(w >> (8 * b)); else w |= (uint32_t)*cell << (8 * b);
+                        o++;
+                    }
+                    v[q] = w;
+                }
+                if (!TO_LDS) buf[j] = u32x4{v[0], v[1], v[2], v[3]};
             }
-            if (!LOAD) g4[p] = u.v;
+        }
+    }
+}
+
+// Inventory rows: the wave's 64 rows are one contiguous 64*K-dword chunk [e][K] = 16*K quads of 16 B; lane l owns
+// quads l, l+64, ...  LDS layout [e][KP] with KP = K|1 (odd stride -> per-lane item reads are conflict-free).
+constexpr int IQ = (NGW_MAX_ITEMS + 3) / 4;                                        // quads per lane, K <= 24
+
+template <bool TO_LDS>
+__device__ __forceinline__ void inv_lds(u32x4 (&q)[IQ], const NgwLaunch& a, int32_t* lds_inv, int tid) {
+    const int nq = 16 * a.K;
+    if (a.KP == a.K) {                                                             // K odd: LDS image == HBM image
+        u32x4* l4 = reinterpret_cast<u32x4*>(lds_inv);
+#pragma unroll
+        for (int j = 0; j < IQ; j++) {
+            const int p = tid + EPB * j;
+            if (TO_LDS) { if (p < nq) l4[p] = q[j]; } else q[j] = l4[min(p, nq - 1)];
+        }
+    } else {                                                                       // K even: one pad dword per env
+#pragma unroll
+        for (int j = 0; j < IQ; j++) {
+            const int p0 = tid + EPB * j;
+            const int p = TO_LDS ? p0 : min(p0, nq - 1);
+            if (!TO_LDS || p0 < nq) {
+                const uint32_t d = (uint32_t)p * 4u;
+                uint32_t e = __umulhi(d, a.magicK);                                // d / K
+                uint32_t o = d - e * (uint32_t)a.K;
+                uint32_t v[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (o >= (uint32_t)a.K) { o = 0; e++; }
+                    int32_t* cell = lds_inv + e * (uint32_t)a.KP + o;
+                    if (TO_LDS) *cell = (int32_t)v[i]; else v[i] = (uint32_t)*cell;
+                    o++;
+                }
+                if (!TO_LDS) q[j] = u32x4{v[0], v[1], v[2], v[3]};
+            }
         }
     }
 }
 
 // ---------------------------------------------------------------- the kernel
-__global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const ngw_spec sp_arg, const NgwLaunch a) {
+template <int MAPMODE>
+__global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restrict__ dspec, const NgwLaunch a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if (a.mode == NGW_MODE_DBG_NOP) return;
     const int tid = threadIdx.x;
     const int64_t env0 = (int64_t)blockIdx.x * EPB;
     const int64_t e = env0 + tid;                                                  // local env index of this lane
     const bool live = e < a.n;
     const int S = a.S, K = a.K;
+    const int npieces = 4 * a.S2;                                                  // EPB * S2 / 16
 
-    // LDS carve-up (dword offsets): maps | inventory [K][64] | candidate masks [CW][64] | LUT copy of the spec
+    // LDS carve-up (dword offsets): maps | inventory [64][KP] | candidate masks [CW][64] | LUT copy of the spec
     uint32_t* lds_map = lds;
     int32_t* lds_inv = reinterpret_cast<int32_t*>(lds + a.off_inv);
     uint32_t* lds_cand = lds + a.off_cand;
-    ngw_spec& sp = *reinterpret_cast<ngw_spec*>(lds + a.off_spec);
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&sp_arg);
-        uint32_t* dst = lds + a.off_spec;
-        for (int i = tid; i < (int)(sizeof(ngw_spec) / 4); i += EPB) dst[i] = src[i];
-    }
+    const NgwDevSpec& ds = *reinterpret_cast<const NgwDevSpec*>(lds + a.off_spec);
+    const ngw_spec& sp = ds.sp;
     int8_t* mp = reinterpret_cast<int8_t*>(lds_map) + tid * a.MS;                 // this lane's map
-    int32_t* inv = lds_inv + tid;                                                  // this lane's inventory column
+    int32_t* inv = lds_inv + tid * a.KP;                                           // this lane's inventory row
     uint32_t* cand = lds_cand + tid;
 
     int cur = a.cur;
-    // ---- load state (observation buffers `cur` + in-place aux arrays)
-    stage_maps<true>(a, lds_map, a.b.map[cur] + env0 * a.S2, tid);
-    int r = 1, c = 1, f = 0, sel = 0, steps = 0;
+    // ---- issue EVERY global load of the prologue before touching LDS: LUT blob, first map round, scalars, inventory
+    constexpr int NSPEC = (int)(sizeof(NgwDevSpec) / 4);
+    static_assert(NSPEC <= 4 * EPB, "spec blob is loaded with 4 dwords per lane");
+    uint32_t sv[4];
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(dspec);
+#pragma unroll
+        for (int j = 0; j < 4; j++) sv[j] = src[min(tid + EPB * j, NSPEC - 1)];
+    }
+    u32x4 buf[PB];
+    const u32x4* gin = reinterpret_cast<const u32x4*>(a.b.map[cur] + env0 * a.S2);
+    pieces_load(buf, gin, 0, npieces, tid);
+    int r = 1, c = 1, f = 0, sel = 0, steps = 0, action = 0;
     uint32_t episode = 0;
     if (live) {
         const int2 rc = reinterpret_cast<const int2*>(a.b.loc[cur])[e];
@@ -233,34 +314,51 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const ngw_spec sp_arg, con
         sel = a.b.selected[e];
         steps = a.b.step_count[e];
         episode = a.b.episode[e];
-        const int32_t* gi = a.b.inv[cur] + e * K;
-        for (int k = 0; k < K; k++) inv[k * EPB] = gi[k];
+        if (a.mode == NGW_MODE_STEP) action = a.actions[e];
+        else if (a.mode == NGW_MODE_RESET) action = a.reset_mask ? (int)a.reset_mask[e] : 1;
     }
+    u32x4 iq[IQ];
+    {
+        const u32x4* gi = reinterpret_cast<const u32x4*>(a.b.inv[cur] + env0 * K);
+#pragma unroll
+        for (int j = 0; j < IQ; j++) iq[j] = gi[min(tid + EPB * j, 16 * K - 1)];
+    }
+    // ---- land them in LDS
+    {
+        uint32_t* dst = lds + a.off_spec;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int i = tid + EPB * j; if (i < NSPEC) dst[i] = sv[j]; }
+    }
+    pieces_lds<true, MAPMODE>(buf, a, lds_map, 0, npieces, tid);
+    for (int base = EPB * PB; base < npieces; base += EPB * PB) {                  // big maps: further rounds
+        pieces_load(buf, gin, base, npieces, tid);
+        pieces_lds<true, MAPMODE>(buf, a, lds_map, base, npieces, tid);
+    }
+    inv_lds<true>(iq, a, lds_inv, tid);
     __syncthreads();
 
     uint32_t flags = 0;
     int reward = 0, ended = 0;
     uint32_t info = 0;
+    uint32_t aw0 = 0, aw1 = 0, aw2 = 0, aw3 = 0;                                   // rollout: 4 actions per Philox block
 
     for (int t = 0; t < a.n_steps; t++) {
-        if (live) {
+        if (live && a.mode != NGW_MODE_DBG_COPY) {
+            bool do_reset = false;
             if (a.mode == NGW_MODE_RESET) {
-                if (a.reset_mask == nullptr || a.reset_mask[e]) {
-                    episode++;
-                    flags |= reset_lane(sp, a, mp, inv, cand, (uint64_t)(a.env_base + e), e, episode, r, c, f);
-                    sel = 0; steps = 0;
-                }
+                do_reset = action != 0;
             } else {
-                int action;
                 if (a.mode == NGW_MODE_ROLLOUT) {
-                    // a = (w * A) >> 32, w = philox(key = action_seed ^ tag; ctr = (t, env))[0]
+                    // action(t, env) = (w * A) >> 32 with w = word (t & 3) of philox(key = action_seed ^ tag; ctr = (t >> 2, env))
                     const uint64_t tt = (uint64_t)(a.t0 + t), eg = (uint64_t)(a.env_base + e);
-                    uint32_t o0, o1, o2, o3;
-                    philox_block((uint32_t)tt, (uint32_t)(tt >> 32), (uint32_t)eg, (uint32_t)(eg >> 32),
-                                 (uint32_t)a.action_seed, (uint32_t)(a.action_seed >> 32) ^ 0xA511E9B3u, o0, o1, o2, o3);
-                    action = (int)__umulhi(o0, (uint32_t)sp.n_actions);
-                } else {
-                    action = a.actions[e];
+                    if (t == 0 || (tt & 3) == 0) {
+                        const uint64_t tb = tt >> 2;
+                        philox_block((uint32_t)tb, (uint32_t)(tb >> 32), (uint32_t)eg, (uint32_t)(eg >> 32),
+                                     (uint32_t)a.action_seed, (uint32_t)(a.action_seed >> 32) ^ 0xA511E9B3u, aw0, aw1, aw2, aw3);
+                    }
+                    const uint32_t q = (uint32_t)tt & 3u;
+                    const uint32_t w = q == 0 ? aw0 : (q == 1 ? aw1 : (q == 2 ? aw2 : aw3));
+                    action = (int)__umulhi(w, (uint32_t)sp.n_actions);
                 }
                 if (action < 0 || action >= sp.n_actions) {                        // reference: ValueError before any change (:236)
                     flags |= NGW_F_INVALID_ACTION;
@@ -286,19 +384,19 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const ngw_spec sp_arg, con
                         cost = sp.cost_break;
                         if (sp.breakable[front]) {
                             mp[fcell] = 0;
-                            if (sp.axe_item && inv[sp.axe_item * EPB] >= 1 && sel == sp.axe_item) {
-                                inv[front * EPB] += sp.axe_qty; rew = sp.axe_reward; cost = sp.axe_cost;
+                            if (sp.axe_item && inv[sp.axe_item] >= 1 && sel == sp.axe_item) {
+                                inv[front] += sp.axe_qty; rew = sp.axe_reward; cost = sp.axe_cost;
                             } else {
-                                inv[front * EPB] += 1;
+                                inv[front] += 1;
                                 if (!sp.axe_item) rew = sp.break_reward[front];
                             }
                         } else { result = 0; msg = NGW_MSG_CANNOT_BREAK; arg = front; }
                         break;
                     case NGW_ACT_PLACE:                                            // :295-314
-                        if (inv[sp.place_item * EPB] >= 1) {
+                        if (inv[sp.place_item] >= 1) {
                             if (front == 0) {
                                 mp[fcell] = (int8_t)sp.place_item;
-                                inv[sp.place_item * EPB] -= 1;
+                                inv[sp.place_item] -= 1;
                                 msg = NGW_MSG_PLACED; arg = sp.place_item;
                                 // is_block_in_front_next_to(tree_log) :391-411, bounds-checked 4-neighbourhood
                                 const int nr = sp.place_near;
@@ -316,7 +414,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const ngw_spec sp_arg, con
                             bool near = !nr || (fr > 0 && mp[fcell - S] == nr) || (fr < S - 1 && mp[fcell + S] == nr) ||
                                         (fc > 0 && mp[fcell - 1] == nr) || (fc < S - 1 && mp[fcell + 1] == nr);
                             if (near) {
-                                inv[sp.ext_out * EPB] += sp.ext_qty;
+                                inv[sp.ext_out] += sp.ext_qty;
                                 if (sp.ext_consume) mp[fcell] = 0;
                                 rew = sp.ext_reward; cost = sp.ext_cost_ok;
                             } else { result = 0; msg = NGW_MSG_EXTRACT_NOT_NEAR; }
@@ -327,7 +425,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const ngw_spec sp_arg, con
                         int missing = 0;
                         for (int j = 0; j < nin; j++) {                            // :422-427, dict order
                             const int item = sp.recipe_in_item[rx][j];
-                            if (!(inv[item * EPB] >= (int)sp.recipe_in[rx][item])) missing |= 1 << j;
+                            if (!(inv[item] >= (int)sp.recipe_in[rx][item])) missing |= 1 << j;
                         }
                         if (missing) {                                             // :430-440
                             result = 0; msg = NGW_MSG_MISSING_ITEMS; arg = (rx << 8) | missing; cost = sp.cost_missing[rx];
@@ -337,16 +435,16 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const ngw_spec sp_arg, con
                             rew = sp.craft_reward;
                             for (int j = 0; j < nin; j++) {
                                 const int item = sp.recipe_in_item[rx][j];
-                                inv[item * EPB] -= (int)sp.recipe_in[rx][item];
+                                inv[item] -= (int)sp.recipe_in[rx][item];
                             }
-                            inv[sp.recipe_out_item[rx] * EPB] += sp.recipe_out_qty[rx];
+                            inv[sp.recipe_out_item[rx]] += sp.recipe_out_qty[rx];
                             cost = sp.cost_ok[rx]; msg = NGW_MSG_CRAFTED; arg = sp.recipe_out_item[rx];
                         }
                         break;
                     }
                     case NGW_ACT_SELECT:                                           // :338-347
                         cost = sp.cost_select;
-                        if (inv[aarg * EPB] >= 1) sel = aarg; else { result = 0; msg = NGW_MSG_NOT_IN_INVENTORY; }
+                        if (inv[aarg] >= 1) sel = aarg; else { result = 0; msg = NGW_MSG_NOT_IN_INVENTORY; }
                         break;
                     default: break;
                     }
@@ -354,32 +452,43 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const ngw_spec sp_arg, con
                         for (int rr = r - 1; rr <= r + 1; rr++)
                             for (int cc = c - 1; cc <= c + 1; cc++) {
                                 const int id = mp[rr * S + cc];
-                                if (id != 0 && sp.entity[id]) { mp[rr * S + cc] = 0; inv[id * EPB] += 1; }
+                                if (id != 0 && sp.entity[id]) { mp[rr * S + cc] = 0; inv[id] += 1; }
                             }
                     }
                     int done = 0;                                                  // :354-357
-                    if (inv[sp.goal_item * EPB] >= 1) { rew = sp.reward_done; done = 1; }
+                    if (inv[sp.goal_item] >= 1) { rew = sp.reward_done; done = 1; }
                     steps += 1;                                                    // :362
                     reward = rew; ended = done;
                     info = (uint32_t)result | ((uint32_t)done << 1) | ((uint32_t)cost << 2) | ((uint32_t)msg << 8) |
                            ((uint32_t)arg << 16);
                     if (a.autoreset && (done || (a.horizon > 0 && steps >= a.horizon))) {   // same-step autoreset
-                        episode++;
-                        flags |= reset_lane(sp, a, mp, inv, cand, (uint64_t)(a.env_base + e), e, episode, r, c, f);
-                        sel = 0; steps = 0; ended = 1;
+                        do_reset = true; ended = 1;
                     }
                 }
             }
+            if (do_reset) {                                                        // single call site: the body is large
+                episode++;
+                flags |= reset_lane(sp, ds.addq, a, mp, inv, cand, (uint64_t)(a.env_base + e), e, episode, r, c, f);
+                sel = 0; steps = 0;
+            }
         }
         __syncthreads();
-        // ---- write the new state == the observation into the other buffer
+        // ---- write the new state == the observation into the other buffer: all LDS reads, then all stores
         const int nxt = cur ^ 1;
-        stage_maps<false>(a, lds_map, a.b.map[nxt] + env0 * a.S2, tid);
+        u32x4* gout = reinterpret_cast<u32x4*>(a.b.map[nxt] + env0 * a.S2);
+        for (int base = 0; base < npieces; base += EPB * PB) {
+            pieces_lds<false, MAPMODE>(buf, a, lds_map, base, npieces, tid);
+            pieces_store(buf, gout, base, npieces, tid);
+        }
+        {
+            u32x4* go = reinterpret_cast<u32x4*>(a.b.inv[nxt] + env0 * K);
+            inv_lds<false>(iq, a, lds_inv, tid);
+#pragma unroll
+            for (int j = 0; j < IQ; j++) { const int p = tid + EPB * j; if (p < 16 * K) go[p] = iq[j]; }
+        }
         if (live) {
             reinterpret_cast<int2*>(a.b.loc[nxt])[e] = make_int2(r, c);
             a.b.facing[nxt][e] = f;
-            int32_t* go = a.b.inv[nxt] + e * K;
-            for (int k = 0; k < K; k++) go[k] = inv[k * EPB];
             if (a.mode != NGW_MODE_RESET) {
                 a.b.reward[e] = reward;
                 a.b.done[e] = (uint8_t)ended;
@@ -399,17 +508,28 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const ngw_spec sp_arg, con
 
 }  // namespace
 
-extern "C" hipError_t ngw_launch(const ngw_spec* sp, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
+template <int MAPMODE>
+static hipError_t launch_mode(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     // CDNA4 has 160 KiB of LDS per CU; anything above the 64 KiB default needs an explicit opt-in per device.
     static size_t lds_opt_in[64] = {0};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (lds_bytes > 64 * 1024 && dev < 64 && lds_bytes > lds_opt_in[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ngw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ngw_kernel<MAPMODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes);
         if (e != hipSuccess) return e;
         lds_opt_in[dev] = lds_bytes;
     }
-    hipLaunchKernelGGL(ngw_kernel, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, *sp, *a);
+    hipLaunchKernelGGL(ngw_kernel<MAPMODE>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, dspec, *a);
     return hipGetLastError();
+}
+
+extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, unsigned grid, size_t lds_bytes,
+                                 hipStream_t stream) {
+    switch (map_mode) {
+    case NGW_MAP_STRAIGHT: return launch_mode<NGW_MAP_STRAIGHT>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MAP_DWORD: return launch_mode<NGW_MAP_DWORD>(dspec, a, grid, lds_bytes, stream);
+    default: return launch_mode<NGW_MAP_BYTE>(dspec, a, grid, lds_bytes, stream);
+    }
 }

@@ -201,11 +201,19 @@ class VecNovelGridworld:
             conv[0] = conv[0].reshape(count, -1)
         _cabi.check(_cabi.lib().ngw_set_state(self._h, first, count, *[_cabi._ptr(a, dt) for a, (_, dt) in zip(conv, arrs)]))
 
-    # ------------------------------------------------------------------ timing (bench roofline leg)
-    def set_timing(self, enable):
-        _cabi.check(_cabi.lib().ngw_set_timing(self._h, int(bool(enable))))
+    # ------------------------------------------------------------------ timing (bench roofline leg) / hipGraph stepping
+    def timing_begin(self):
+        _cabi.check(_cabi.lib().ngw_timing_begin(self._h))
 
-    def kernel_time(self):
-        ms, n = C.c_double(0), C.c_int64(0)
-        _cabi.check(_cabi.lib().ngw_kernel_time(self._h, C.byref(ms), C.byref(n)))
-        return ms.value, n.value
+    def timing_end(self):
+        """Device milliseconds between timing_begin() and now on the handle's stream (HIP event pair)."""
+        ms = C.c_double(0)
+        _cabi.check(_cabi.lib().ngw_timing_end(self._h, C.byref(ms)))
+        return ms.value
+
+    def graph_build(self, actions_ptr, step_stride, n_steps):
+        """Capture n_steps (even) step_device launches reading actions_ptr + i * step_stride into one hipGraph."""
+        _cabi.check(_cabi.lib().ngw_graph_build(self._h, C.c_void_p(int(actions_ptr)), int(step_stride), int(n_steps)))
+
+    def graph_launch(self, reps=1):
+        _cabi.check(_cabi.lib().ngw_graph_launch(self._h, int(reps)))

@@ -170,10 +170,16 @@ int ngw_out_device_ptrs(ngw_handle* h, void** reward, void** done, void** info);
 int ngw_sync(ngw_handle* h);
 /* Reads and clears the sticky device error flags (NGW_F_*). */
 int ngw_error_flags(ngw_handle* h, uint32_t* flags);
-/* Average device time of the last `ngw_step*`/`ngw_rollout` launches since the previous call, measured with
- * HIP events on the handle's stream (bench.py roofline leg).  Returns launches counted in *n. */
-int ngw_kernel_time(ngw_handle* h, double* total_ms, int64_t* n);
-int ngw_set_timing(ngw_handle* h, int enable);
+/* Device time of everything enqueued on the handle's stream between the two calls, measured with a HIP event pair
+ * recorded on that stream (bench.py roofline leg: elapsed / launches = average launch duration incl. gaps). */
+int ngw_timing_begin(ngw_handle* h);
+int ngw_timing_end(ngw_handle* h, double* elapsed_ms);
+
+/* hipGraph stepping for launch-bound loops: captures n_steps (even) consecutive ngw_step_device launches whose
+ * actions are read from actions_dev + i * step_stride (int32 elements) into one executable graph, then replays it.
+ * Semantically identical to calling ngw_step_device n_steps * reps times with those action rows. */
+int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps);
+int ngw_graph_launch(ngw_handle* h, int32_t reps);
 
 #ifdef __cplusplus
 }

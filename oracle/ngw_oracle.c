@@ -80,12 +80,14 @@ static uint32_t philox_next(ngwo_philox* p) {
     return p->buf[4 - p->have--];
 }
 
-/* uniform action of the fused rollout: a = (w * A) >> 32 with w = philox(key = seed ^ tag; ctr = (t_lo, t_hi, env_lo, env_hi))[0] */
+/* uniform action of the fused rollout: a(t, env) = (w * A) >> 32 with w = word (t & 3) of
+ * philox(key = seed ^ tag; ctr = (t >> 2 lo, t >> 2 hi, env_lo, env_hi)) - one Philox block serves four steps */
 uint32_t ngwo_rollout_action(uint64_t action_seed, uint64_t env, uint64_t t, uint32_t n_actions) {
     uint32_t key[2] = {(uint32_t)action_seed, (uint32_t)(action_seed >> 32) ^ 0xA511E9B3u};
-    uint32_t ctr[4] = {(uint32_t)t, (uint32_t)(t >> 32), (uint32_t)env, (uint32_t)(env >> 32)}, out[4];
+    uint64_t tb = t >> 2;
+    uint32_t ctr[4] = {(uint32_t)tb, (uint32_t)(tb >> 32), (uint32_t)env, (uint32_t)(env >> 32)}, out[4];
     philox4x32_10(ctr, key, out);
-    return (uint32_t)(((uint64_t)out[0] * n_actions) >> 32);
+    return (uint32_t)(((uint64_t)out[t & 3] * n_actions) >> 32);
 }
 
 /* ------------------------------------------------------------------ word source + numpy bounded draw */

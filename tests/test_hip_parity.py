@@ -219,3 +219,27 @@ def test_placement_exhaustion_raises_like_reference():
         assert flags == 0
     except AssertionError:
         assert flags == 2
+
+
+def test_graph_stepping_equals_eager_stepping():
+    """ngw_graph_build/launch replays exactly the step launches it captured (two replays == 2 x 6 eager steps)."""
+    import torch
+    spec = T.build_spec('axe10')
+    n, A = 3000, len(spec.actions_id)
+    acts = torch.randint(0, A, (6, n), dtype=torch.int32, device='cuda')
+    torch.cuda.synchronize()
+    a = VecNovelGridworld(spec=spec, num_envs=n, seed=21, autoreset=True, horizon=5)
+    b = VecNovelGridworld(spec=spec, num_envs=n, seed=21, autoreset=True, horizon=5)
+    a.reset()
+    b.reset()
+    a.graph_build(acts.data_ptr(), n, 6)
+    a.graph_launch(2)
+    for rep in range(2):
+        for t in range(6):
+            b.step_device(acts[t].data_ptr())
+    sa, sb = a.get_state(), b.get_state()
+    for k in STATE_KEYS:
+        assert (sa[k] == sb[k]).all(), k
+    ra, rb = a.get_step_out(copy=True), b.get_step_out(copy=True)
+    assert (ra[0] == rb[0]).all() and (ra[1] == rb[1]).all()
+    assert a.error_flags() == 0
