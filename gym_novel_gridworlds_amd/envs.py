@@ -1,0 +1,282 @@
+"""Single-environment adapters with the reference's `gym.Env` surface, backed by the batched HIP path (N = 1).
+
+`PogostickV1Env` / `BowV1Env` mirror gym_novel_gridworlds/envs/pogostick_v1_env.py and bow_v1_env.py as seen by
+callers: constructor `__init__(env=None)` :26, `reset(map_size=None, items_id=None, items_quantity=None)` :86,
+`step(action_id)` :230 -> `(obs, reward, done, info)` with info `{'result', 'step_cost', 'message'}` :359, the Dict
+observation of `get_observation()` :214-228 whose values alias the env's attributes, the public attribute surface
+ and the exceptions (ValueError for an unknown action id :236, AssertionError when items cannot be
+placed :167).  Between calls the HOST attributes are the truth - exactly like the reference, callers may mutate
+`env.map`, `env.inventory_items_quantity`, `env.agent_location`, ... directly (tests/keyboard_interface.py:93-100);
+every step pushes them to the device, runs ONE launch of the step kernel and pulls the result back.
+
+This is BASELINE.json config 1 ("plumbing"): it exists so the path drops in under `gym.make`; throughput comes
+from `VecNovelGridworld`.
+"""
+import copy
+
+import numpy as np
+
+from . import spaces
+from .spec import DIRECTION_ID, DIRECTION_STR, STEP_COSTS, EnvSpec
+from .vec_env import PLACEMENT_MESSAGE, VecNovelGridworld
+
+try:
+    import gym as _gym
+    _EnvBase = _gym.Env
+except Exception:                                           # noqa: BLE001 - gym is optional
+    _EnvBase = object
+
+_DR, _DC = (-1, 1, 0, 0), (0, 0, -1, 1)
+
+
+class _NovelGridworldEnv(_EnvBase):
+    ENV_ID = None
+
+    def __init__(self, env=None):
+        self._spec = EnvSpec(self.ENV_ID, 10)
+        self._vec = None
+        self._vec_key = None
+        self._seed = None
+        self._episode_base = 0
+        sp = self._spec
+        self.env_id = sp.env_id
+        self.env = env                                       # env to restore in reset (pogostick_v1_env.py:29, :89-109)
+        self.map_size = sp.map_size
+        self.map = np.zeros((self.map_size, self.map_size), dtype=int)
+        self.agent_location = (1, 1)
+        self.direction_id = dict(DIRECTION_ID)
+        self.agent_facing_str = 'NORTH'
+        self.agent_facing_id = self.direction_id[self.agent_facing_str]
+        self.block_in_front_str = 'air'
+        self.block_in_front_id = 0
+        self.block_in_front_location = (0, 0)
+        # the spec object's tables ARE the env's tables (novelty injection edits them in place, like the reference)
+        self.items = sp.items
+        self.items_id = sp.items_id
+        self.unbreakable_items = sp.unbreakable_items
+        self.goal_item_to_craft = sp.goal_item_to_craft
+        self.items_quantity = sp.items_quantity
+        self.inventory_items_quantity = {item: 0 for item in self.items}
+        self.selected_item = ''
+        self.entities = sp.entities
+        self.available_locations = []
+        self.not_available_locations = []
+        self.actions_id = sp.actions_id
+        self.manipulation_actions_id = sp.manipulation_actions_id
+        self.recipes = sp.recipes
+        self.craft_actions_id = sp.craft_actions_id
+        self.select_actions_id = sp.select_actions_id
+        self.action_space = spaces.Discrete(len(self.actions_id))
+        self.last_action = 'Forward'
+        self.step_count = 0
+        self.last_step_cost = 0
+        self.max_items = sp.max_items
+        self.observation_space = spaces.Dict({'map': spaces.Box(low=0, high=self.max_items,
+                                                                shape=(self.map_size, self.map_size, 1))})
+        self.last_reward = 0
+        self.reward_intermediate = sp.reward_intermediate
+        self.reward_done = sp.reward_done
+        self.last_done = False
+
+    # ------------------------------------------------------------------ backend
+    def _make_backend(self, spec, seed):
+        """One-env device handle.  Overridden in CPU tests with an oracle-backed stand-in."""
+        return VecNovelGridworld(spec=spec, num_envs=1, seed=seed)
+
+    def seed(self, seed=None):
+        """The reference ignores seed() (global np.random); here it keys the device's per-episode Philox streams."""
+        self._seed = None if seed is None else int(seed)
+        self._close_backend()
+        return [seed]
+
+    def _backend(self):
+        sp = self._spec
+        # callers may REBIND the public tables (env.items_quantity = {...}); the spec follows the env's attributes
+        sp.items, sp.items_id, sp.items_quantity, sp.entities = self.items, self.items_id, self.items_quantity, self.entities
+        sp.actions_id, sp.recipes, sp.unbreakable_items = self.actions_id, self.recipes, self.unbreakable_items
+        sp.goal_item_to_craft = self.goal_item_to_craft
+        sp.map_size = int(self.map_size)
+        sp.reward_intermediate, sp.reward_done = self.reward_intermediate, self.reward_done
+        key = (sp.map_size, tuple(sp.items_id.items()), tuple(sp.actions_id.items()), tuple(sp.items_quantity.items()),
+               tuple(sorted(sp.entities)), repr(sp.axe), repr(sp.additem), repr(sp.start_inventory), sp.reward_done,
+               sp.reward_intermediate)
+        if self._vec is None or key != self._vec_key:
+            self._close_backend()
+            if self._seed is None:                          # reproducible under np.random.seed(), like the reference
+                self._seed = int(np.random.randint(0, 2 ** 31 - 1))
+            self._vec = self._make_backend(sp, self._seed)
+            self._vec_key = key
+            if self._episode_base:
+                self._vec.set_state(0, episode=np.array([self._episode_base], np.uint32))
+        return self._vec
+
+    def _close_backend(self):
+        if self._vec is not None:
+            self._episode_base = int(self._vec.get_state(0, 1)['episode'][0])
+            self._vec.close()
+            self._vec = None
+
+    def _push(self, vec):
+        """host attributes -> device state"""
+        ids, S, K = self.items_id, self.map_size, len(self.items_id)
+        inv = np.zeros((1, K), np.int32)
+        for name, q in self.inventory_items_quantity.items():
+            inv[0, ids[name]] = q                            # KeyError for an unknown item name, like the reference
+        m = np.ascontiguousarray(np.asarray(self.map).reshape(1, S * S), np.int8)
+        vec.set_state(0, map=m, loc=np.array([self.agent_location], np.int32),
+                      facing=np.array([self.agent_facing_id], np.int32), inv=inv,
+                      selected=np.array([ids[self.selected_item] if self.selected_item else 0], np.int32),
+                      step_count=np.array([self.step_count], np.int32))
+
+    def _pull(self, vec):
+        """device state -> host attributes (the map array object is kept: observations alias it)"""
+        st = vec.get_state(0, 1)
+        S = self.map_size
+        if self.map.shape != (S, S):
+            self.map = np.zeros((S, S), dtype=int)
+        self.map[...] = st['map'][0].reshape(S, S)
+        self.agent_location = (int(st['loc'][0, 0]), int(st['loc'][0, 1]))
+        self.set_agent_facing(DIRECTION_STR[int(st['facing'][0])])
+        names = self._spec.item_names
+        for i, name in enumerate(names):
+            self.inventory_items_quantity[name] = int(st['inv'][0, i])
+        sel = int(st['selected'][0])
+        self.selected_item = names[sel] if sel else ''
+        self.step_count = int(st['step_count'][0])
+
+    # ------------------------------------------------------------------ reference API
+    def reset(self, map_size=None, items_id=None, items_quantity=None):
+        if self.env is not None:                             # restore branch, pogostick_v1_env.py:89-109
+            print("RESTORING " + self.env_id + " ...")
+            src = self.env
+            self.map_size = copy.deepcopy(src.map_size)
+            self.map = copy.deepcopy(src.map)
+            self.items_id.clear(); self.items_id.update(copy.deepcopy(src.items_id))
+            self.items_quantity.clear(); self.items_quantity.update(copy.deepcopy(src.items_quantity))
+            self.inventory_items_quantity = copy.deepcopy(src.inventory_items_quantity)
+            self.available_locations = copy.deepcopy(src.available_locations)
+            self.not_available_locations = copy.deepcopy(src.not_available_locations)
+            self.last_action = copy.deepcopy(src.last_action)
+            self.step_count = copy.deepcopy(src.step_count)
+            self.last_reward = copy.deepcopy(src.last_reward)
+            self.last_done = False
+            self.agent_location = copy.deepcopy(src.agent_location)
+            self.set_agent_facing(copy.deepcopy(src.agent_facing_str))
+            obs = self.get_observation()
+            self.update_block_in_front()
+            return obs
+        if map_size is not None:
+            self.map_size = map_size
+        if items_id is not None:
+            self.items_id.clear(); self.items_id.update(items_id)
+        if items_quantity is not None:
+            self.items_quantity.clear(); self.items_quantity.update(items_quantity)
+        self.inventory_items_quantity = {item: 0 for item in self.items}
+        self.selected_item = ''
+        self.available_locations = []
+        self.not_available_locations = []
+        self.last_action = 'Forward'
+        self.step_count = 0
+        self.last_step_cost = 0
+        self.last_reward = 0
+        self.last_done = False
+        vec = self._backend()
+        vec.reset()                                          # AssertionError(PLACEMENT_MESSAGE) when items do not fit
+        self._pull(vec)
+        obs = self.get_observation()
+        self.update_block_in_front()
+        return obs
+
+    def step(self, action_id):
+        # ValueError("<id> is not in list") for an unknown action id, before anything changes (:236)
+        self.last_action = list(self.actions_id.keys())[list(self.actions_id.values()).index(action_id)]
+        vec = self._backend()
+        self._push(vec)
+        _, reward, done, info = vec.step(np.array([action_id], np.int32))
+        self._pull(vec)
+        obs = self.get_observation()
+        self.update_block_in_front()
+        reward, done = int(reward[0]), bool(info_done(done))
+        step_cost = STEP_COSTS[int(info['step_cost_code'][0])]
+        message = self._spec.format_message(int(action_id), int(info['message_code'][0]), int(info['message_arg'][0]))
+        out_info = {'result': bool(info['result'][0]), 'step_cost': step_cost, 'message': message}
+        self.last_step_cost = step_cost
+        self.last_reward = reward
+        self.last_done = done
+        return obs, reward, done, out_info
+
+    def get_observation(self):
+        assert not self.max_items < len(self.items), "Cannot have more than " + str(self.max_items) + " items"
+        return {'map': self.map, 'agent_location': self.agent_location, 'agent_facing_id': self.agent_facing_id,
+                'inventory_items_quantity': self.inventory_items_quantity}
+
+    def set_agent_location(self, r, c):
+        self.agent_location = (r, c)
+
+    def set_agent_facing(self, direction_str):
+        self.agent_facing_str = direction_str
+        self.agent_facing_id = self.direction_id[self.agent_facing_str]
+
+    def set_lasts(self, lasts):
+        self.last_action = lasts['last_action']
+        self.step_count = lasts['step_count']
+        self.last_step_cost = lasts['last_step_cost']
+        self.last_reward = lasts['last_reward']
+        self.last_done = lasts['last_done']
+
+    def set_items_id(self, items):
+        from .spec import set_items_id
+        return set_items_id(items)
+
+    def update_block_in_front(self):                         # pogostick_v1_env.py:369-389
+        r, c = self.agent_location
+        f = self.agent_facing_id
+        self.block_in_front_location = (r + _DR[f], c + _DC[f])
+        self.block_in_front_id = int(self.map[self.block_in_front_location[0]][self.block_in_front_location[1]])
+        if self.block_in_front_id == 0:
+            self.block_in_front_str = 'air'
+        else:
+            self.block_in_front_str = list(self.items_id.keys())[list(self.items_id.values()).index(self.block_in_front_id)]
+
+    def is_block_in_front_next_to(self, item):               # :391-411
+        self.update_block_in_front()
+        r, c = self.block_in_front_location
+        for d in range(4):
+            rr, cc = r + _DR[d], c + _DC[d]
+            if 0 <= rr <= self.map_size - 1 and 0 <= cc <= self.map_size - 1 and self.map[rr][cc] == self.items_id[item]:
+                return True
+        return False
+
+    def add_new_items(self, new_items_quantity):             # :495-501
+        for item in new_items_quantity:
+            self._spec.add_new_item(item)
+            self.items_quantity.update({item: new_items_quantity[item]})
+        self.reset()
+
+    def render(self, mode='human', title=None):
+        raise NotImplementedError("rendering is outside the batched hot path (SURVEY.md §2 row 12)")
+
+    def close(self):
+        self._close_backend()
+
+
+def info_done(done):
+    return bool(np.asarray(done).reshape(-1)[0])
+
+
+class PogostickV1Env(_NovelGridworldEnv):
+    """Goal: craft 1 pogo_stick (pogostick_v1_env.py:17-24)."""
+    ENV_ID = 'NovelGridworld-Pogostick-v1'
+
+
+class BowV1Env(_NovelGridworldEnv):
+    """Goal: craft 1 bow (bow_v1_env.py:17-24)."""
+    ENV_ID = 'NovelGridworld-Bow-v1'
+
+
+ENTRY_POINTS = {'NovelGridworld-Pogostick-v1': PogostickV1Env, 'NovelGridworld-Bow-v1': BowV1Env}
+
+
+def make(env_id, **kwargs):
+    """`gym.make(id)` equivalent that works without gym (entry points as in gym_novel_gridworlds/__init__.py:47-60)."""
+    return ENTRY_POINTS[env_id](**kwargs)

@@ -1,0 +1,77 @@
+"""`inject_novelty` with the reference's call shape (gym_novel_gridworlds/novelty_wrappers.py:1586-1674).
+
+    env = inject_novelty(env, novelty_name, difficulty='hard', novelty_arg1='', novelty_arg2='')
+
+Accepts a single-env adapter (envs.py) - returns a wrapper that forwards reads to the wrapped env exactly like
+`gym.core.Wrapper` (copies action_space / observation_space at construction, `__getattr__` for reads only) - or a
+`VecNovelGridworld`, for which it returns a NEW batched env built from the edited spec."""
+from .novelty import apply_novelty
+from .vec_env import VecNovelGridworld
+
+
+class NoveltyWrapper(object):
+    """Reads fall through to the wrapped env; writes stay on the wrapper (gym 0.18 `Wrapper` semantics)."""
+
+    def __init__(self, env):
+        self.env = env
+        self.action_space = env.action_space                 # copied, NOT grown by axe/additem
+        self.observation_space = env.observation_space
+        self.reward_range = getattr(env, 'reward_range', (-float('inf'), float('inf')))
+        self.metadata = getattr(env, 'metadata', {})
+
+    def __getattr__(self, name):
+        if name.startswith('_'):
+            raise AttributeError("attempted to get missing private attribute '{}'".format(name))
+        return getattr(self.env, name)
+
+    @property
+    def unwrapped(self):
+        return getattr(self.env, 'unwrapped', self.env)
+
+    def step(self, action_id):
+        return self.env.step(action_id)
+
+    def reset(self, **kwargs):
+        return self.env.reset(**kwargs)
+
+    def render(self, mode='human', **kwargs):
+        return self.env.render(mode, **kwargs)
+
+    def close(self):
+        return self.env.close()
+
+    def seed(self, seed=None):
+        return self.env.seed(seed)
+
+
+class AxeEasy(NoveltyWrapper):
+    pass
+
+
+class AxeMedium(NoveltyWrapper):
+    pass
+
+
+class AddItem(NoveltyWrapper):
+    def reset(self):                                          # novelty_wrappers.py:1013 takes no kwargs
+        return self.env.reset()
+
+
+def inject_novelty(env, novelty_name, difficulty='hard', novelty_arg1='', novelty_arg2=''):
+    if isinstance(env, VecNovelGridworld):
+        import copy
+        spec = copy.deepcopy(env.spec)
+        apply_novelty(spec, novelty_name, difficulty, novelty_arg1, novelty_arg2)
+        return VecNovelGridworld(spec=spec, num_envs=env.num_envs, device=env.device, seed=env.seed,
+                                 autoreset=env.autoreset, horizon=env.horizon)
+    base = getattr(env, 'unwrapped', env)
+    base = getattr(base, 'env', base) if isinstance(base, NoveltyWrapper) else base
+    spec = base._spec
+    apply_novelty(spec, novelty_name, difficulty, novelty_arg1, novelty_arg2)     # validates like the reference
+    if novelty_name == 'axe':
+        if difficulty == 'medium':
+            base.reset()            # AxeMedium.__init__ -> add_new_items -> reset(): the axe appears on the map (:129)
+            return AxeMedium(env)
+        base.inventory_items_quantity.update({novelty_arg1 + '_axe': 1})          # AxeEasy.__init__ :22
+        return AxeEasy(env)
+    return AddItem(env)

@@ -243,3 +243,45 @@ def test_graph_stepping_equals_eager_stepping():
     ra, rb = a.get_step_out(copy=True), b.get_step_out(copy=True)
     assert (ra[0] == rb[0]).all() and (ra[1] == rb[1]).all()
     assert a.error_flags() == 0
+
+
+@pytest.mark.parametrize('cfg', ['pogo10', 'bow20', 'axe10', 'add12m'])
+def test_single_env_adapter_on_hip_backend(cfg):
+    """BASELINE config 1 plumbing: the reference-shaped single-env API on the real device backend."""
+    assert T.replay_adapter(cfg, 'hip', max_steps=250, n_single=150) > 300
+
+
+def test_single_env_random_action_loop_shape():
+    """tests/random_action.py:51-64 loop shape on the adapter: 50 steps, map_size change + reset every 10."""
+    import gym_novel_gridworlds_amd as G
+    np.random.seed(0)
+    env = G.make('NovelGridworld-Pogostick-v1')
+    obs = env.reset()
+    for i in range(50):
+        a = env.action_space.sample()
+        obs, reward, done, info = env.step(a)
+        assert set(obs) == {'map', 'agent_location', 'agent_facing_id', 'inventory_items_quantity'}
+        assert obs['map'].shape == (env.map_size, env.map_size) and set(info) == {'result', 'step_cost', 'message'}
+        if (i + 1) % 10 == 0:
+            env.map_size = int(np.random.randint(low=10, high=20, size=1)[0])
+            obs = env.reset()
+            wall = env.items_id['wall']
+            assert (obs['map'][0] == wall).all() and (obs['map'] == env.items_id['tree_log']).sum() == 5
+    env.close()
+
+
+def test_packed_observation_gather_roundtrip_single_rank():
+    """dist.ShardedVecNovelGridworld on one GPU: packed observation (the RCCL gather payload) unpacks to the batch."""
+    from gym_novel_gridworlds_amd.dist import ShardedVecNovelGridworld
+    spec = T.build_spec('axe10')
+    env = ShardedVecNovelGridworld(global_num_envs=2048, spec=spec, seed=9, autoreset=True, horizon=20)
+    env.reset()
+    env.rollout(33, action_seed=7)
+    got = env.gather_observation()
+    st = env.local.get_state()
+    reward, done, info = env.local.get_step_out(copy=True)
+    assert (got['map'].cpu().numpy().reshape(2048, -1) == st['map']).all()
+    assert (got['agent_location'].cpu().numpy() == st['loc']).all() and (got['agent_facing_id'].cpu().numpy() == st['facing']).all()
+    assert (got['inventory_items_quantity'].cpu().numpy() == st['inv']).all()
+    assert (got['reward'].cpu().numpy() == reward).all() and (got['done'].cpu().numpy() == done).all()
+    env.close()

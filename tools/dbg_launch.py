@@ -6,6 +6,15 @@ from gym_novel_gridworlds_amd import VecNovelGridworld, _cabi
 import torch
 L = _cabi.lib()
 L.ngw_debug_launch.argtypes = [C.c_void_p, C.c_int, C.c_int32]
+if sys.argv[1:] == ['calib']:
+    # PMC calibration: 20 staging-only launches at 1 Mi envs (state 2 x 148 MB, beyond the 256 MiB Infinity Cache
+    # together with the output buffers); bytes per launch are known: read = write = n_pad * (S*S + 4*K + 12) (+ small)
+    n = 1 << 20
+    v = VecNovelGridworld(num_envs=n)
+    v.reset(); v.sync()
+    L.ngw_debug_launch(v._h, 9, 20); v.sync()
+    print('calib n', n, 'bytes_read_per_launch', n * (100 + 36 + 12 + 1 + 4 + 4 + 4), 'bytes_written_per_launch', n * (100 + 36 + 12 + 1 + 4 + 4))
+    sys.exit(0)
 for n in [int(x) for x in (sys.argv[1:] or ['65536', '262144', '1048576'])]:
     v = VecNovelGridworld(num_envs=n, autoreset=True, horizon=100)
     v.reset()
