@@ -171,12 +171,41 @@ def main():
                 'kernel_ms_avg': round(launch_ms, 6), 'launches_timed': launches,
                 'algorithmic_bytes_per_env_step': B, 'env_steps_per_launch': n * steps_per_launch,
                 'timing': 'HIP event pair on the kernel stream around the timed launches (includes inter-launch gaps)'}
-    pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(pmc):
-        rec = json.load(open(pmc)).get('%s_%s' % (args.workload, args.mode))
-        if rec:
-            roofline['traffic'] = rec['hbm_bytes_per_launch']
-            roofline['traffic_source'] = rec['source']
+    pmc_file = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    pmc = json.load(open(pmc_file)) if os.path.exists(pmc_file) else {}
+
+    def add_traffic(rf, mode, env_steps_per_launch):
+        """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process)."""
+        rec = pmc.get('%s_%s' % (args.workload, mode))
+        if rec and n == 65536 or (rec and args.workload == 'C4' and n == 32768):
+            rf['traffic'] = round(rec['hbm_bytes_per_env_step'] * env_steps_per_launch)
+            rf['traffic_source'] = rec['source']
+
+    add_traffic(roofline, args.mode, n * steps_per_launch)
+
+    # the other mode of the same workload, reported beside the headline (fused T-step rollout: SURVEY.md §8(d))
+    fused = None
+    if args.mode == 'step' and world == 1:
+        v.rollout(warmup, ACTION_SEED, 10 ** 6)
+        fence()
+        v.timing_begin()
+        t1 = time.perf_counter()
+        v.rollout(steps, ACTION_SEED, 10 ** 6 + warmup)
+        f_ms = v.timing_end()
+        fence()
+        f_dt = time.perf_counter() - t1
+        f_ach = B * n * steps / (f_ms * 1e-3) / 1e9
+        obs_bytes = S * S + 4 * K + 12 + 9            # what the fused kernel must write per env-step (state stays on chip)
+        fused = {'value': round(n * steps / f_dt, 1), 'unit': 'env-steps/s', 'ms_per_step': round(f_dt / steps * 1e3, 6),
+                 'what': 'ngw_rollout: all %d steps in ONE launch, uniform actions generated in-kernel, state kept in LDS, '
+                         'observation batch written to HBM every step' % steps,
+                 'roofline': {'bound': 'hbm', 'achieved': round(f_ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                              'frac': round(f_ach / HBM_PEAK_GBS, 4), 'kernel_ms': round(f_ms, 4),
+                              'algorithmic_bytes_per_env_step': B, 'min_hbm_bytes_per_env_step': obs_bytes,
+                              'frac_of_peak_on_min_bytes': round(obs_bytes * n * steps / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              'traffic': None}}
+        add_traffic(fused['roofline'], 'rollout', n * steps)
+        assert v.error_flags() == 0
 
     if rank == 0:
         total = n * world * steps
@@ -191,6 +220,8 @@ def main():
                        'parallelism': 'envs sharded x%d, no collective' % world},
             'roofline': roofline,
         }
+        if fused:
+            line['fused_rollout'] = fused
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(spec)
             line['cpu_baseline'] = {'value': round(cb['allcores']['value'], 1), 'unit': 'env-steps/s',

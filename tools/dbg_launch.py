@@ -13,7 +13,7 @@ if sys.argv[1:] == ['calib']:
     v = VecNovelGridworld(num_envs=n)
     v.reset(); v.sync()
     L.ngw_debug_launch(v._h, 9, 20); v.sync()
-    print('calib n', n, 'bytes_read_per_launch', n * (100 + 36 + 12 + 1 + 4 + 4 + 4), 'bytes_written_per_launch', n * (100 + 36 + 12 + 1 + 4 + 4))
+    print('calib n', n, 'bytes_read_per_launch', n * 157, 'bytes_written_per_launch', n * 166)
     sys.exit(0)
 for n in [int(x) for x in (sys.argv[1:] or ['65536', '262144', '1048576'])]:
     v = VecNovelGridworld(num_envs=n, autoreset=True, horizon=100)
