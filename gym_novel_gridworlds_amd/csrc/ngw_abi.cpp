@@ -87,6 +87,18 @@ int check_spec(const ngw_spec* s) {
     }
     for (int j = 0; j < s->n_start; j++)
         if (!item_ok(s->start_item[j])) return fail(NGW_E_INVALID_ARG, "start item out of range");
+    int brw = s->reward_step;
+    for (int i = 0; i < K; i++)
+        if (s->break_reward[i] != s->reward_step) {
+            if (brw != s->reward_step && brw != s->break_reward[i]) return fail(NGW_E_INVALID_ARG, "break_reward must take one value besides reward_step");
+            brw = s->break_reward[i];
+        }
+    for (int r = 0; r < s->n_recipes; r++)              /* the kernel applies a recipe from prefetched counts: ids must differ */
+        for (int j = 0; j < s->recipe_n_in[r]; j++) {
+            if (s->recipe_in_item[r][j] == s->recipe_out_item[r]) return fail(NGW_E_INVALID_ARG, "recipe %d consumes its own output", r);
+            for (int k = 0; k < j; k++)
+                if (s->recipe_in_item[r][j] == s->recipe_in_item[r][k]) return fail(NGW_E_INVALID_ARG, "recipe %d lists an input twice", r);
+        }
     if (s->additem_item && !(s->additem_pct_lo < s->additem_pct_hi && s->additem_pct_hi - s->additem_pct_lo <= 32 && s->additem_pct_hi <= 100))
         return fail(NGW_E_INVALID_ARG, "additem percent range invalid");
     return NGW_OK;
@@ -191,6 +203,39 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
         memset(&hs, 0, sizeof(hs));
         hs.sp = *spec;
         for (int i = 0; i < 32; i++) hs.addq[i] = (double)(spec->additem_pct_lo + i) / 100.0;
+        NgwStepU& u = hs.u;
+        for (int i = 0; i < K; i++) {
+            if (spec->breakable[i]) u.brk_mask |= 1u << i;
+            if (spec->entity[i]) u.ent_mask |= 1u << i;
+            if (spec->break_reward[i] != spec->reward_step) { u.rew_mask |= 1u << i; u.break_reward = spec->break_reward[i]; }
+        }
+        u.n_actions = spec->n_actions; u.reward_step = spec->reward_step; u.reward_done = spec->reward_done;
+        u.craft_reward = spec->craft_reward;
+        u.cost_forward = spec->cost_forward; u.cost_turn = spec->cost_turn; u.cost_break = spec->cost_break;
+        u.cost_place = spec->cost_place; u.cost_extract = spec->cost_extract; u.cost_select = spec->cost_select;
+        u.table_item = spec->table_item; u.goal_item = spec->goal_item;
+        u.place_item = spec->place_item; u.place_near = spec->place_near; u.n_entities = spec->n_entities;
+        u.ext_src = spec->ext_src; u.ext_near = spec->ext_near; u.ext_out = spec->ext_out; u.ext_qty = spec->ext_qty;
+        u.ext_consume = spec->ext_consume; u.ext_cost_ok = spec->ext_cost_ok;
+        u.axe_item = spec->axe_item; u.axe_cost = spec->axe_cost; u.axe_qty = spec->axe_qty;
+        u.place_reward = spec->place_reward; u.ext_reward = spec->ext_reward; u.axe_reward = spec->axe_reward;
+        for (int a = 0; a < spec->n_actions; a++) {
+            uint32_t* d = hs.act_desc + a * NGW_ACT_DW;
+            const uint32_t kind = spec->act_kind[a], arg = spec->act_arg[a];
+            d[0] = kind | (arg << 8);
+            if (kind == NGW_ACT_CRAFT) {
+                const int r = (int)arg;
+                d[0] |= ((uint32_t)spec->recipe_n_in[r] << 16) | ((uint32_t)(spec->recipe_needs_table[r] ? 1 : 0) << 24);
+                for (int j = 0; j < spec->recipe_n_in[r]; j++) {
+                    const uint32_t item = spec->recipe_in_item[r][j];
+                    d[1] |= item << (8 * j);
+                    d[2] |= (uint32_t)spec->recipe_in[r][item] << (8 * j);
+                }
+                d[3] = spec->recipe_out_item[r] | ((uint32_t)spec->recipe_out_qty[r] << 8) |
+                       ((uint32_t)spec->cost_missing[r] << 16) | ((uint32_t)spec->cost_no_table[r] << 24);
+                d[4] = spec->cost_ok[r];
+            }
+        }
         if (hipMemcpyAsync(h->dspec, &hs, sizeof(hs), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess)
             return bail(fail(NGW_E_HIP, "spec upload failed"));
@@ -212,8 +257,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     off = (off + 3u) & ~3u;
     p.off_inv = off; off += (uint32_t)(p.KP * NGW_EPB);
     p.off_cand = off; off += (uint32_t)(p.CW * NGW_EPB);
-    off = (off + 1u) & ~1u;                             // the blob holds doubles
-    p.off_spec = off; off += (uint32_t)(sizeof(NgwDevSpec) / 4);
+    p.off_act = off; off += (uint32_t)(NGW_MAX_ACTIONS * NGW_ACT_DW);
     h->lds_bytes = (size_t)off * 4;
     if (h->lds_bytes > 160 * 1024) return bail(fail(NGW_E_INVALID_ARG, "map_size %d needs %zu B of LDS per wavefront (> 160 KiB)", S, h->lds_bytes));
     if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(NGW_E_HIP, "stream sync failed after allocation"));

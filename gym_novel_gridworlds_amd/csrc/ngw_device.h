@@ -39,12 +39,31 @@ struct NgwLaunch {
     int32_t S, S2, MS, K, KP, CW; /* MS = LDS bytes per env map (MS/4 odd), KP = K|1 LDS inventory stride, CW = candidate words */
     uint32_t magic;              /* ceil(2^32 / (S2/4)) (or / S2 for odd S): exact division of chunk offsets */
     uint32_t magicK;             /* ceil(2^32 / K): exact division of inventory chunk offsets (< 64*K) */
-    uint32_t off_inv, off_cand, off_spec;   /* LDS dword offsets */
+    uint32_t off_inv, off_cand, off_act;    /* LDS dword offsets */
 };
 
-/* LUT blob kept in HBM (one per handle) and copied to LDS by every wavefront. */
+/* Uniform step parameters: every lane uses the same value, so the kernel reads them with SCALAR loads straight
+ * from the HBM blob (no LDS latency in the step's dependency chain). */
+struct NgwStepU {
+    uint32_t brk_mask, ent_mask, rew_mask;  /* bit i: item i is breakable / an entity / gives break_reward when broken */
+    int32_t n_actions, reward_step, reward_done, craft_reward, break_reward;
+    uint8_t cost_forward, cost_turn, cost_break, cost_place, cost_extract, cost_select, table_item, goal_item;
+    uint8_t place_item, place_near, n_entities, ext_src, ext_near, ext_out, ext_qty, ext_consume;
+    uint8_t ext_cost_ok, axe_item, axe_cost, axe_qty;
+    int8_t place_reward, ext_reward, axe_reward, _pad;
+};
+
+/* Per-action descriptor, NGW_ACT_DW dwords, copied to LDS (the only lane-varying LUT of the step):
+ *   d0 = kind | arg<<8 | n_inputs<<16 | needs_table<<24      d1 = input item ids (4 bytes, dict order)
+ *   d2 = input quantities (4 bytes)                          d3 = out_item | out_qty<<8 | cost_missing<<16 | cost_no_table<<24
+ *   d4 = cost_ok                                             (d1..d4 are zero for non-craft actions) */
+#define NGW_ACT_DW 5
+
+/* Blob kept in HBM (one per handle). */
 struct NgwDevSpec {
-    ngw_spec sp;
+    NgwStepU u;
+    uint32_t act_desc[NGW_MAX_ACTIONS * NGW_ACT_DW];
+    ngw_spec sp;                 /* full spec: the (cold) reset path reads it with scalar loads */
     double addq[32];             /* AddItem: pct / 100.0 for pct in [pct_lo, pct_hi) as the host's IEEE double */
 };
 

@@ -25,6 +25,13 @@ static_assert(sizeof(NgwDevSpec) % 4 == 0, "the spec blob is copied to LDS by dw
 
 namespace {
 
+// Keep a value in a register across the step loop: the empty asm makes it opaque, so the compiler can neither
+// re-load it from the kernarg segment / HBM with s_load inside the loop nor recompute it (worst case it parks it in
+// a VGPR lane, one v_readlane to bring it back - no memory wait).
+#define PIN_S(x) asm volatile("" : "+s"(x))
+#define PIN_V(x) asm volatile("" : "+v"(x))
+#define GLOBAL_AS __attribute__((address_space(1)))
+
 constexpr int EPB = NGW_EPB;   // envs per block = wavefront width
 
 // ---------------------------------------------------------------- Philox4x32-10 (counter-based, per env & episode)
@@ -87,9 +94,21 @@ __device__ __forceinline__ int nth_set_bit(uint32_t x, int n) {
 // ---------------------------------------------------------------- per-lane reset on the LDS map
 // pogostick_v1_env.py:86-157 + add_item_to_map :159-181 (+ AddItem.reset, AxeEasy.reset).  `mp` = this lane's map
 // in LDS, `inv` = this lane's inventory row, `cand` = candidate bitmask column (stride EPB).
-__device__ __forceinline__ uint32_t reset_lane(const ngw_spec& sp, const double* addq, const NgwLaunch& a, int8_t* mp, int32_t* inv,
-                                            uint32_t* cand, uint64_t env_global, int64_t env_local, uint32_t episode,
-                                            int& r_out, int& c_out, int& f_out) {
+// Out of line ON PURPOSE: this is the cold path (1 % of env-steps at H = 100); inlined, its register needs spill the
+// scalars of the hot step loop.  Returns flags | r<<8 | c<<16 | facing<<24.
+struct ResetArgs {
+    const NgwDevSpec* dspec;
+    uint16_t* perm;
+    int64_t n_pad;
+    uint64_t seed;
+    int S, S2, K, CW;
+};
+
+__device__ __noinline__ uint32_t reset_lane(const ResetArgs a, int8_t* mp, int32_t* inv, uint32_t* cand, uint64_t env_global,
+                                            int64_t env_local, uint32_t episode) {
+    const ngw_spec& sp = a.dspec->sp;
+    const double* addq = a.dspec->addq;
+    int r_out, c_out, f_out;
     const int S = a.S, K = a.K, W = S - 4, ncand = W * W;
     Philox px;
     philox_init(px, a.seed, env_global, episode);
@@ -129,7 +148,7 @@ __device__ __forceinline__ uint32_t reset_lane(const ngw_spec& sp, const double*
         if (flags) break;
     }
     if (sp.additem_item && !flags) {                                               // AddItem.reset novelty_wrappers.py:1017-1028
-        uint16_t* perm = a.b.perm + env_local;                                     // [S2][n_pad] scratch column
+        uint16_t* perm = a.perm + env_local;                                       // [S2][n_pad] scratch column
         const int64_t ps = a.n_pad;
         int n_air = 0;
         for (int i = 0; i < a.S2; i++)
@@ -147,7 +166,7 @@ __device__ __forceinline__ uint32_t reset_lane(const ngw_spec& sp, const double*
         }
     }
     if (sp.inv_start_item && !flags) inv[sp.inv_start_item] = sp.inv_start_qty;         // AxeEasy.reset :33
-    return flags;
+    return flags | ((uint32_t)r_out << 8) | ((uint32_t)c_out << 16) | ((uint32_t)f_out << 24);
 }
 
 // ---------------------------------------------------------------- map staging HBM <-> LDS (coalesced 16-B pieces)
@@ -157,20 +176,17 @@ __device__ __forceinline__ uint32_t reset_lane(const ngw_spec& sp, const double*
 // In LDS each env's map starts at e*MS bytes with MS/4 odd, so 64 lanes reading "their" cell hit distinct banks.
 constexpr int PB = 8;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                       // native vector: stays in VGPRs
+typedef GLOBAL_AS u32x4 g_u32x4;
+typedef GLOBAL_AS int2 g_int2;
+typedef GLOBAL_AS int32_t g_i32;
+typedef GLOBAL_AS uint32_t g_u32;
+typedef GLOBAL_AS uint8_t g_u8;
 
 // Loads are UNCONDITIONAL on a clamped index (a duplicate in-bounds load is harmless and keeps the values in plain
 // registers); only stores and LDS writes are predicated.
 __device__ __forceinline__ void pieces_load(u32x4 (&buf)[PB], const u32x4* g4, int base, int npieces, int tid) {
 #pragma unroll
     for (int j = 0; j < PB; j++) buf[j] = g4[min(base + tid + EPB * j, npieces - 1)];
-}
-
-__device__ __forceinline__ void pieces_store(const u32x4 (&buf)[PB], u32x4* g4, int base, int npieces, int tid) {
-#pragma unroll
-    for (int j = 0; j < PB; j++) {
-        const int p = base + tid + EPB * j;
-        if (p < npieces) g4[p] = buf[j];
-    }
 }
 
 // LDS <-> register pieces.  TO_LDS: buf -> lds, else lds -> buf.
@@ -240,16 +256,19 @@ constexpr int IQ = (NGW_MAX_ITEMS + 3) / 4;                                     
 template <bool TO_LDS>
 __device__ __forceinline__ void inv_lds(u32x4 (&q)[IQ], const NgwLaunch& a, int32_t* lds_inv, int tid) {
     const int nq = 16 * a.K;
+    const int rounds = (nq + EPB - 1) / EPB;                                       // uniform: quads per lane actually used
     if (a.KP == a.K) {                                                             // K odd: LDS image == HBM image
         u32x4* l4 = reinterpret_cast<u32x4*>(lds_inv);
 #pragma unroll
         for (int j = 0; j < IQ; j++) {
+            if (j >= rounds) break;
             const int p = tid + EPB * j;
             if (TO_LDS) { if (p < nq) l4[p] = q[j]; } else q[j] = l4[min(p, nq - 1)];
         }
     } else {                                                                       // K even: one pad dword per env
 #pragma unroll
         for (int j = 0; j < IQ; j++) {
+            if (j >= rounds) break;
             const int p0 = tid + EPB * j;
             const int p = TO_LDS ? p0 : min(p0, nq - 1);
             if (!TO_LDS || p0 < nq) {
@@ -271,10 +290,13 @@ __device__ __forceinline__ void inv_lds(u32x4 (&q)[IQ], const NgwLaunch& a, int3
 }
 
 // ---------------------------------------------------------------- the kernel
-template <int MAPMODE>
+// LDS reads of the step are issued in TWO parallel levels (L0: action descriptor, block in front and its four
+// neighbours, the inventory slots whose item id is uniform; L1: the slots whose id comes out of L0) and the per-kind
+// bodies then work on registers only - the dependency chain of a step is two LDS latencies plus ALU, whatever the kind.
+template <int MAPMODE, int MODE>
 __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restrict__ dspec, const NgwLaunch a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    if (a.mode == NGW_MODE_DBG_NOP) return;
+    if (MODE == NGW_MODE_DBG_NOP) return;
     const int tid = threadIdx.x;
     const int64_t env0 = (int64_t)blockIdx.x * EPB;
     const int64_t e = env0 + tid;                                                  // local env index of this lane
@@ -282,26 +304,23 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     const int S = a.S, K = a.K;
     const int npieces = 4 * a.S2;                                                  // EPB * S2 / 16
 
-    // LDS carve-up (dword offsets): maps | inventory [64][KP] | candidate masks [CW][64] | LUT copy of the spec
+    // LDS carve-up (dword offsets): maps | inventory [64][KP] | candidate masks [CW][64] | action descriptors
     uint32_t* lds_map = lds;
     int32_t* lds_inv = reinterpret_cast<int32_t*>(lds + a.off_inv);
     uint32_t* lds_cand = lds + a.off_cand;
-    const NgwDevSpec& ds = *reinterpret_cast<const NgwDevSpec*>(lds + a.off_spec);
-    const ngw_spec& sp = ds.sp;
+    const uint32_t* lds_act = lds + a.off_act;
+    const NgwStepU U = dspec->u;                                                   // uniform: ONE scalar load, kept in SGPRs
     int8_t* mp = reinterpret_cast<int8_t*>(lds_map) + tid * a.MS;                 // this lane's map
     int32_t* inv = lds_inv + tid * a.KP;                                           // this lane's inventory row
     uint32_t* cand = lds_cand + tid;
 
     int cur = a.cur;
-    // ---- issue EVERY global load of the prologue before touching LDS: LUT blob, first map round, scalars, inventory
-    constexpr int NSPEC = (int)(sizeof(NgwDevSpec) / 4);
-    static_assert(NSPEC <= 4 * EPB, "spec blob is loaded with 4 dwords per lane");
+    // ---- issue EVERY global load of the prologue before touching LDS: action table, first map round, scalars, inventory
+    constexpr int NACT = NGW_MAX_ACTIONS * NGW_ACT_DW;
+    static_assert(NACT <= 4 * EPB, "the action table is loaded with 4 dwords per lane");
     uint32_t sv[4];
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(dspec);
 #pragma unroll
-        for (int j = 0; j < 4; j++) sv[j] = src[min(tid + EPB * j, NSPEC - 1)];
-    }
+    for (int j = 0; j < 4; j++) sv[j] = dspec->act_desc[min(tid + EPB * j, NACT - 1)];
     u32x4 buf[PB];
     const u32x4* gin = reinterpret_cast<const u32x4*>(a.b.map[cur] + env0 * a.S2);
     pieces_load(buf, gin, 0, npieces, tid);
@@ -314,20 +333,20 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
         sel = a.b.selected[e];
         steps = a.b.step_count[e];
         episode = a.b.episode[e];
-        if (a.mode == NGW_MODE_STEP) action = a.actions[e];
-        else if (a.mode == NGW_MODE_RESET) action = a.reset_mask ? (int)a.reset_mask[e] : 1;
+        if (MODE == NGW_MODE_STEP) action = a.actions[e];
+        else if (MODE == NGW_MODE_RESET) action = a.reset_mask ? (int)a.reset_mask[e] : 1;
     }
     u32x4 iq[IQ];
     {
         const u32x4* gi = reinterpret_cast<const u32x4*>(a.b.inv[cur] + env0 * K);
 #pragma unroll
-        for (int j = 0; j < IQ; j++) iq[j] = gi[min(tid + EPB * j, 16 * K - 1)];
+        for (int j = 0; j < IQ; j++) iq[j] = (j * EPB < 16 * K) ? gi[min(tid + EPB * j, 16 * K - 1)] : u32x4{0u, 0u, 0u, 0u};
     }
     // ---- land them in LDS
     {
-        uint32_t* dst = lds + a.off_spec;
+        uint32_t* dst = lds + a.off_act;
 #pragma unroll
-        for (int j = 0; j < 4; j++) { const int i = tid + EPB * j; if (i < NSPEC) dst[i] = sv[j]; }
+        for (int j = 0; j < 4; j++) { const int i = tid + EPB * j; if (i < NACT) dst[i] = sv[j]; }
     }
     pieces_lds<true, MAPMODE>(buf, a, lds_map, 0, npieces, tid);
     for (int base = EPB * PB; base < npieces; base += EPB * PB) {                  // big maps: further rounds
@@ -342,157 +361,205 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     uint32_t info = 0;
     uint32_t aw0 = 0, aw1 = 0, aw2 = 0, aw3 = 0;                                   // rollout: 4 actions per Philox block
 
-    for (int t = 0; t < a.n_steps; t++) {
-        if (live && a.mode != NGW_MODE_DBG_COPY) {
+    // ---- everything the step loop needs, fetched once and pinned in registers
+    // per-lane output addresses for both ping-pong parities (VGPR pairs; 1 wave per SIMD leaves plenty)
+    g_u32x4* gmap[2] = {(g_u32x4*)(reinterpret_cast<u32x4*>(a.b.map[0] + env0 * a.S2) + tid),
+                        (g_u32x4*)(reinterpret_cast<u32x4*>(a.b.map[1] + env0 * a.S2) + tid)};
+    g_u32x4* ginv[2] = {(g_u32x4*)(reinterpret_cast<u32x4*>(a.b.inv[0] + env0 * K) + tid),
+                        (g_u32x4*)(reinterpret_cast<u32x4*>(a.b.inv[1] + env0 * K) + tid)};
+    g_int2* gloc[2] = {(g_int2*)(reinterpret_cast<int2*>(a.b.loc[0]) + e), (g_int2*)(reinterpret_cast<int2*>(a.b.loc[1]) + e)};
+    g_i32* gfac[2] = {(g_i32*)(a.b.facing[0] + e), (g_i32*)(a.b.facing[1] + e)};
+    g_i32* grew = (g_i32*)(a.b.reward + e);
+    g_u8* gdone = (g_u8*)(a.b.done + e);
+    g_u32* ginfo = (g_u32*)(a.b.info + e);
+    PIN_V(gmap[0]); PIN_V(gmap[1]); PIN_V(ginv[0]); PIN_V(ginv[1]); PIN_V(gloc[0]); PIN_V(gloc[1]);
+    PIN_V(gfac[0]); PIN_V(gfac[1]); PIN_V(grew); PIN_V(gdone); PIN_V(ginfo);
+    constexpr int mode = MODE;
+    int n_steps = (MODE == NGW_MODE_ROLLOUT) ? a.n_steps : 1, autoreset = a.autoreset, horizon = a.horizon;
+    PIN_S(n_steps); PIN_S(autoreset); PIN_S(horizon);
+    const uint64_t env_global = (uint64_t)(a.env_base + e);
+    uint32_t key0 = (uint32_t)a.action_seed, key1 = (uint32_t)(a.action_seed >> 32) ^ 0xA511E9B3u;
+    uint64_t tt = (uint64_t)a.t0;
+    PIN_S(key0); PIN_S(key1);
+    // uniform step parameters, unpacked into scalars
+    uint32_t brk_mask = U.brk_mask, ent_mask = U.ent_mask, rew_mask = U.rew_mask;
+    int n_actions = U.n_actions, reward_step = U.reward_step, reward_done = U.reward_done, craft_reward = U.craft_reward;
+    int break_reward = U.break_reward;
+    int cost_forward = U.cost_forward, cost_turn = U.cost_turn, cost_break = U.cost_break, cost_place = U.cost_place;
+    int cost_extract = U.cost_extract, cost_select = U.cost_select, table_item = U.table_item, goal_item = U.goal_item;
+    int place_item = U.place_item, place_near = U.place_near, n_entities = U.n_entities, ext_src = U.ext_src;
+    int ext_near = U.ext_near, ext_out = U.ext_out, ext_qty = U.ext_qty, ext_consume = U.ext_consume;
+    int ext_cost_ok = U.ext_cost_ok, axe_item = U.axe_item, axe_cost = U.axe_cost, axe_qty = U.axe_qty;
+    int place_reward = U.place_reward, ext_reward = U.ext_reward, axe_reward = U.axe_reward;
+    PIN_S(brk_mask); PIN_S(ent_mask); PIN_S(rew_mask); PIN_S(n_actions); PIN_S(reward_step); PIN_S(reward_done);
+    PIN_S(craft_reward); PIN_S(break_reward); PIN_S(cost_forward); PIN_S(cost_turn); PIN_S(cost_break); PIN_S(cost_place);
+    PIN_S(cost_extract); PIN_S(cost_select); PIN_S(table_item); PIN_S(goal_item); PIN_S(place_item); PIN_S(place_near);
+    PIN_S(n_entities); PIN_S(ext_src); PIN_S(ext_near); PIN_S(ext_out); PIN_S(ext_qty); PIN_S(ext_consume);
+    PIN_S(ext_cost_ok); PIN_S(axe_item); PIN_S(axe_cost); PIN_S(axe_qty); PIN_S(place_reward); PIN_S(ext_reward); PIN_S(axe_reward);
+
+    for (int t = 0; t < n_steps; t++, tt++) {
+        if (live && mode != NGW_MODE_DBG_COPY) {
             bool do_reset = false;
-            if (a.mode == NGW_MODE_RESET) {
+            if (mode == NGW_MODE_RESET) {
                 do_reset = action != 0;
             } else {
-                if (a.mode == NGW_MODE_ROLLOUT) {
+                if (mode == NGW_MODE_ROLLOUT) {
                     // action(t, env) = (w * A) >> 32 with w = word (t & 3) of philox(key = action_seed ^ tag; ctr = (t >> 2, env))
-                    const uint64_t tt = (uint64_t)(a.t0 + t), eg = (uint64_t)(a.env_base + e);
                     if (t == 0 || (tt & 3) == 0) {
                         const uint64_t tb = tt >> 2;
-                        philox_block((uint32_t)tb, (uint32_t)(tb >> 32), (uint32_t)eg, (uint32_t)(eg >> 32),
-                                     (uint32_t)a.action_seed, (uint32_t)(a.action_seed >> 32) ^ 0xA511E9B3u, aw0, aw1, aw2, aw3);
+                        philox_block((uint32_t)tb, (uint32_t)(tb >> 32), (uint32_t)env_global, (uint32_t)(env_global >> 32),
+                                     key0, key1, aw0, aw1, aw2, aw3);
                     }
                     const uint32_t q = (uint32_t)tt & 3u;
                     const uint32_t w = q == 0 ? aw0 : (q == 1 ? aw1 : (q == 2 ? aw2 : aw3));
-                    action = (int)__umulhi(w, (uint32_t)sp.n_actions);
+                    action = (int)__umulhi(w, (uint32_t)n_actions);
                 }
-                if (action < 0 || action >= sp.n_actions) {                        // reference: ValueError before any change (:236)
+                if (action < 0 || action >= n_actions) {                         // reference: ValueError before any change (:236)
                     flags |= NGW_F_INVALID_ACTION;
                     reward = 0; ended = 0; info = 0;
                 } else {
-                    int rew = sp.reward_step, result = 1, cost = 0, msg = NGW_MSG_NONE, arg = 0;   // :239-242
-                    const int kind = sp.act_kind[action], aarg = sp.act_arg[action];
+                    // ---------------- L0: independent LDS reads
+                    const uint32_t* ad = lds_act + action * NGW_ACT_DW;
+                    const uint32_t d0 = ad[0], d1 = ad[1], d2 = ad[2], d3 = ad[3], d4 = ad[4];
                     const int dr = (f == 0) ? -1 : (f == 1 ? 1 : 0), dc = (f == 2) ? -1 : (f == 3 ? 1 : 0);
                     const int fr = r + dr, fc = c + dc, fcell = fr * S + fc;
                     const int front = mp[fcell];                                   // block in front (:369-389)
+                    // 4-neighbourhood of the front cell, only in-bounds cells count (is_block_in_front_next_to :391-411)
+                    const bool okN = fr > 0, okS = fr < S - 1, okW = fc > 0, okE = fc < S - 1;
+                    const int nbN = mp[okN ? fcell - S : fcell], nbS = mp[okS ? fcell + S : fcell];
+                    const int nbW = mp[okW ? fcell - 1 : fcell], nbE = mp[okE ? fcell + 1 : fcell];
+                                        const int inv_place = inv[place_item], inv_ext = inv[ext_out], inv_axe = inv[axe_item];
+                    // ---------------- L1: reads whose address came out of L0
+                    const int kind = d0 & 255, aarg = (d0 >> 8) & 255, nin = (d0 >> 16) & 255;
+                    const int in0 = d1 & 255, in1 = (d1 >> 8) & 255, in2 = (d1 >> 16) & 255, in3 = d1 >> 24;
+                    const int out_item = d3 & 255;
+                    const int inv_front = inv[front];
+                    const int inv_arg = inv[min(aarg, K - 1)];
+                    const int iv0 = inv[in0], iv1 = inv[in1], iv2 = inv[in2], iv3 = inv[in3], inv_out = inv[out_item];
+                    // ---------------- register-only bodies
+                    int rew = reward_step, result = 1, cost = 0, msg = NGW_MSG_NONE, arg = 0;   // :239-242
                     switch (kind) {
                     case NGW_ACT_FORWARD:                                          // :244-257
                         if (front == 0) { r = fr; c = fc; } else { result = 0; msg = NGW_MSG_BLOCK_IN_PATH; }
-                        cost = sp.cost_forward;
+                        cost = cost_forward;
                         break;
                     case NGW_ACT_LEFT:                                             // :258-268  N->W S->E W->S E->N
-                        f = (0x0132 >> (f * 4)) & 3; cost = sp.cost_turn;
+                        f = (0x0132 >> (f * 4)) & 3; cost = cost_turn;
                         break;
                     case NGW_ACT_RIGHT:                                            // :269-279  N->E S->W W->N E->S
-                        f = (0x1023 >> (f * 4)) & 3; cost = sp.cost_turn;
+                        f = (0x1023 >> (f * 4)) & 3; cost = cost_turn;
                         break;
                     case NGW_ACT_BREAK:                                            // :280-294, axe: novelty_wrappers.py:144-183
-                        cost = sp.cost_break;
-                        if (sp.breakable[front]) {
+                        cost = cost_break;
+                        if ((brk_mask >> front) & 1u) {
                             mp[fcell] = 0;
-                            if (sp.axe_item && inv[sp.axe_item] >= 1 && sel == sp.axe_item) {
-                                inv[front] += sp.axe_qty; rew = sp.axe_reward; cost = sp.axe_cost;
+                            if (axe_item && inv_axe >= 1 && sel == axe_item) {
+                                inv[front] = inv_front + axe_qty; rew = axe_reward; cost = axe_cost;
                             } else {
-                                inv[front] += 1;
-                                if (!sp.axe_item) rew = sp.break_reward[front];
+                                inv[front] = inv_front + 1;
+                                if (!axe_item && ((rew_mask >> front) & 1u)) rew = break_reward;
                             }
                         } else { result = 0; msg = NGW_MSG_CANNOT_BREAK; arg = front; }
                         break;
                     case NGW_ACT_PLACE:                                            // :295-314
-                        if (inv[sp.place_item] >= 1) {
+                        if (inv_place >= 1) {
                             if (front == 0) {
-                                mp[fcell] = (int8_t)sp.place_item;
-                                inv[sp.place_item] -= 1;
-                                msg = NGW_MSG_PLACED; arg = sp.place_item;
-                                // is_block_in_front_next_to(tree_log) :391-411, bounds-checked 4-neighbourhood
-                                const int nr = sp.place_near;
-                                bool near = (fr > 0 && mp[fcell - S] == nr) || (fr < S - 1 && mp[fcell + S] == nr) ||
-                                            (fc > 0 && mp[fcell - 1] == nr) || (fc < S - 1 && mp[fcell + 1] == nr);
-                                if (near) rew = sp.place_reward;
+                                mp[fcell] = (int8_t)place_item;
+                                inv[place_item] = inv_place - 1;
+                                msg = NGW_MSG_PLACED; arg = place_item;
+                                const int nr = place_near;
+                                if ((okN && nbN == nr) || (okS && nbS == nr) || (okW && nbW == nr) || (okE && nbE == nr))
+                                    rew = place_reward;
                             } else { result = 0; msg = NGW_MSG_ALREADY_EXISTS; arg = front; }
                         } else { result = 0; msg = NGW_MSG_NOT_IN_INVENTORY; }
-                        cost = sp.cost_place;
+                        cost = cost_place;
                         break;
                     case NGW_ACT_EXTRACT:                                          // :315-331 / bow_v1_env.py:293-304
-                        cost = sp.cost_extract;
-                        if (front == sp.ext_src) {
-                            const int nr = sp.ext_near;
-                            bool near = !nr || (fr > 0 && mp[fcell - S] == nr) || (fr < S - 1 && mp[fcell + S] == nr) ||
-                                        (fc > 0 && mp[fcell - 1] == nr) || (fc < S - 1 && mp[fcell + 1] == nr);
-                            if (near) {
-                                inv[sp.ext_out] += sp.ext_qty;
-                                if (sp.ext_consume) mp[fcell] = 0;
-                                rew = sp.ext_reward; cost = sp.ext_cost_ok;
+                        cost = cost_extract;
+                        if (front == ext_src) {
+                            const int nr = ext_near;
+                            if (!nr || (okN && nbN == nr) || (okS && nbS == nr) || (okW && nbW == nr) || (okE && nbE == nr)) {
+                                inv[ext_out] = inv_ext + ext_qty;
+                                if (ext_consume) mp[fcell] = 0;
+                                rew = ext_reward; cost = ext_cost_ok;
                             } else { result = 0; msg = NGW_MSG_EXTRACT_NOT_NEAR; }
                         } else { result = 0; msg = NGW_MSG_EXTRACT_NO_SRC; }
                         break;
                     case NGW_ACT_CRAFT: {                                          // craft :413-474
-                        const int rx = aarg, nin = sp.recipe_n_in[rx];
-                        int missing = 0;
-                        for (int j = 0; j < nin; j++) {                            // :422-427, dict order
-                            const int item = sp.recipe_in_item[rx][j];
-                            if (!(inv[item] >= (int)sp.recipe_in[rx][item])) missing |= 1 << j;
-                        }
+                        const int nd0 = d2 & 255, nd1 = (d2 >> 8) & 255, nd2 = (d2 >> 16) & 255, nd3 = d2 >> 24;
+                        const int missing = ((nin > 0 && iv0 < nd0) ? 1 : 0) | ((nin > 1 && iv1 < nd1) ? 2 : 0) |
+                                            ((nin > 2 && iv2 < nd2) ? 4 : 0) | ((nin > 3 && iv3 < nd3) ? 8 : 0);   // :422-427
                         if (missing) {                                             // :430-440
-                            result = 0; msg = NGW_MSG_MISSING_ITEMS; arg = (rx << 8) | missing; cost = sp.cost_missing[rx];
-                        } else if (sp.recipe_needs_table[rx] && front != sp.table_item) {   // :444-453
-                            result = 0; msg = NGW_MSG_NEED_TABLE; cost = sp.cost_no_table[rx];
-                        } else {                                                   // :455-474
-                            rew = sp.craft_reward;
-                            for (int j = 0; j < nin; j++) {
-                                const int item = sp.recipe_in_item[rx][j];
-                                inv[item] -= (int)sp.recipe_in[rx][item];
-                            }
-                            inv[sp.recipe_out_item[rx]] += sp.recipe_out_qty[rx];
-                            cost = sp.cost_ok[rx]; msg = NGW_MSG_CRAFTED; arg = sp.recipe_out_item[rx];
+                            result = 0; msg = NGW_MSG_MISSING_ITEMS; arg = (aarg << 8) | missing; cost = (d3 >> 16) & 255;
+                        } else if (((d0 >> 24) & 1u) && front != table_item) {   // :444-453
+                            result = 0; msg = NGW_MSG_NEED_TABLE; cost = d3 >> 24;
+                        } else {                                                   // :455-474 (ids of a recipe are distinct)
+                            rew = craft_reward;
+                            if (nin > 0) inv[in0] = iv0 - nd0;
+                            if (nin > 1) inv[in1] = iv1 - nd1;
+                            if (nin > 2) inv[in2] = iv2 - nd2;
+                            if (nin > 3) inv[in3] = iv3 - nd3;
+                            inv[out_item] = inv_out + (int)((d3 >> 8) & 255);
+                            cost = (int)d4; msg = NGW_MSG_CRAFTED; arg = out_item;
                         }
                         break;
                     }
                     case NGW_ACT_SELECT:                                           // :338-347
-                        cost = sp.cost_select;
-                        if (inv[aarg] >= 1) sel = aarg; else { result = 0; msg = NGW_MSG_NOT_IN_INVENTORY; }
+                        cost = cost_select;
+                        if (inv_arg >= 1) sel = aarg; else { result = 0; msg = NGW_MSG_NOT_IN_INVENTORY; }
                         break;
                     default: break;
                     }
-                    if (sp.n_entities) {                                           // grab_entities :538-554 (3x3 incl. own cell)
+                    if (n_entities) {                                            // grab_entities :538-554 (3x3 incl. own cell)
                         for (int rr = r - 1; rr <= r + 1; rr++)
                             for (int cc = c - 1; cc <= c + 1; cc++) {
                                 const int id = mp[rr * S + cc];
-                                if (id != 0 && sp.entity[id]) { mp[rr * S + cc] = 0; inv[id] += 1; }
+                                if (id != 0 && ((ent_mask >> id) & 1u)) { mp[rr * S + cc] = 0; inv[id] += 1; }
                             }
                     }
-                    int done = 0;                                                  // :354-357
-                    if (inv[sp.goal_item] >= 1) { rew = sp.reward_done; done = 1; }
+                    int done = 0;                                                  // :354-357 (LDS ops of a wave are in order)
+                    if (inv[goal_item] >= 1) { rew = reward_done; done = 1; }
                     steps += 1;                                                    // :362
                     reward = rew; ended = done;
                     info = (uint32_t)result | ((uint32_t)done << 1) | ((uint32_t)cost << 2) | ((uint32_t)msg << 8) |
                            ((uint32_t)arg << 16);
-                    if (a.autoreset && (done || (a.horizon > 0 && steps >= a.horizon))) {   // same-step autoreset
+                    if (autoreset && (done || (horizon > 0 && steps >= horizon))) {   // same-step autoreset
                         do_reset = true; ended = 1;
                     }
                 }
             }
-            if (do_reset) {                                                        // single call site: the body is large
+            if (do_reset) {                                                        // cold path, out of line
                 episode++;
-                flags |= reset_lane(sp, ds.addq, a, mp, inv, cand, (uint64_t)(a.env_base + e), e, episode, r, c, f);
+                const ResetArgs ra = {dspec, a.b.perm, a.n_pad, a.seed, S, a.S2, K, a.CW};
+                const uint32_t rr = reset_lane(ra, mp, inv, cand, env_global, e, episode);
+                flags |= rr & 0xFFu;
+                r = (int)((rr >> 8) & 0xFFu); c = (int)((rr >> 16) & 0xFFu); f = (int)(rr >> 24);
                 sel = 0; steps = 0;
             }
         }
         __syncthreads();
         // ---- write the new state == the observation into the other buffer: all LDS reads, then all stores
         const int nxt = cur ^ 1;
-        u32x4* gout = reinterpret_cast<u32x4*>(a.b.map[nxt] + env0 * a.S2);
+        g_u32x4* gout = nxt ? gmap[1] : gmap[0];                                   // already offset by this lane's piece 0
         for (int base = 0; base < npieces; base += EPB * PB) {
             pieces_lds<false, MAPMODE>(buf, a, lds_map, base, npieces, tid);
-            pieces_store(buf, gout, base, npieces, tid);
+#pragma unroll
+            for (int j = 0; j < PB; j++)
+                if (base + tid + EPB * j < npieces) gout[base + EPB * j] = buf[j];
         }
         {
-            u32x4* go = reinterpret_cast<u32x4*>(a.b.inv[nxt] + env0 * K);
+            g_u32x4* go = nxt ? ginv[1] : ginv[0];
             inv_lds<false>(iq, a, lds_inv, tid);
 #pragma unroll
-            for (int j = 0; j < IQ; j++) { const int p = tid + EPB * j; if (p < 16 * K) go[p] = iq[j]; }
+            for (int j = 0; j < IQ; j++) { if (j * EPB < 16 * K && tid + EPB * j < 16 * K) go[EPB * j] = iq[j]; }
         }
         if (live) {
-            reinterpret_cast<int2*>(a.b.loc[nxt])[e] = make_int2(r, c);
-            a.b.facing[nxt][e] = f;
-            if (a.mode != NGW_MODE_RESET) {
-                a.b.reward[e] = reward;
-                a.b.done[e] = (uint8_t)ended;
-                a.b.info[e] = info;
+            { g_int2* gl = nxt ? gloc[1] : gloc[0]; gl->x = r; gl->y = c; }
+            *(nxt ? gfac[1] : gfac[0]) = f;
+            if (mode != NGW_MODE_RESET) {
+                *grew = reward;
+                *gdone = (uint8_t)ended;
+                *ginfo = info;
             }
         }
         cur = nxt;
@@ -508,21 +575,32 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
 
 }  // namespace
 
-template <int MAPMODE>
-static hipError_t launch_mode(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
+template <int MAPMODE, int MODE>
+static hipError_t launch_one(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     // CDNA4 has 160 KiB of LDS per CU; anything above the 64 KiB default needs an explicit opt-in per device.
     static size_t lds_opt_in[64] = {0};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (lds_bytes > 64 * 1024 && dev < 64 && lds_bytes > lds_opt_in[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ngw_kernel<MAPMODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ngw_kernel<MAPMODE, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes);
         if (e != hipSuccess) return e;
         lds_opt_in[dev] = lds_bytes;
     }
-    hipLaunchKernelGGL(ngw_kernel<MAPMODE>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, dspec, *a);
+    hipLaunchKernelGGL((ngw_kernel<MAPMODE, MODE>), dim3(grid), dim3(NGW_EPB), lds_bytes, stream, dspec, *a);
     return hipGetLastError();
+}
+
+template <int MAPMODE>
+static hipError_t launch_mode(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
+    switch (a->mode) {
+    case NGW_MODE_STEP: return launch_one<MAPMODE, NGW_MODE_STEP>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MODE_RESET: return launch_one<MAPMODE, NGW_MODE_RESET>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MODE_ROLLOUT: return launch_one<MAPMODE, NGW_MODE_ROLLOUT>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MODE_DBG_COPY: return launch_one<MAPMODE, NGW_MODE_DBG_COPY>(dspec, a, grid, lds_bytes, stream);
+    default: return launch_one<MAPMODE, NGW_MODE_DBG_NOP>(dspec, a, grid, lds_bytes, stream);
+    }
 }
 
 extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, unsigned grid, size_t lds_bytes,

@@ -16,7 +16,7 @@ messages as (code, arg) pairs formatted here by `format_message`.
 import copy
 import ctypes as C
 
-MAX_ITEMS, MAX_ACTIONS, MAX_RECIPES, MAX_RECIPE_INPUTS, MAX_START = 24, 48, 8, 8, 8
+MAX_ITEMS, MAX_ACTIONS, MAX_RECIPES, MAX_RECIPE_INPUTS, MAX_START = 24, 48, 8, 4, 8
 MAX_MAP_SIZE = 64
 ABI_VERSION = 1
 

@@ -28,7 +28,7 @@ extern "C" {
 #define NGW_MAX_ITEMS 24        /* reference asserts len(items) <= max_items = 20 (pogostick_v1_env.py:75,220) */
 #define NGW_MAX_ACTIONS 48
 #define NGW_MAX_RECIPES 8
-#define NGW_MAX_RECIPE_INPUTS 8
+#define NGW_MAX_RECIPE_INPUTS 4  /* the reference's recipes have <= 3 inputs (pogostick_v1_env.py:56-59) */
 #define NGW_MAX_START_ITEMS 8
 #define NGW_MAX_MAP_SIZE 64     /* S; the LDS-resident kernel supports S*S <= 4096 */
 
@@ -52,7 +52,7 @@ enum { NGW_ACT_FORWARD = 0, NGW_ACT_LEFT = 1, NGW_ACT_RIGHT = 2, NGW_ACT_BREAK =
 enum { NGW_MSG_NONE = 0, NGW_MSG_BLOCK_IN_PATH = 1, NGW_MSG_CANNOT_BREAK = 2 /* arg = item */,
        NGW_MSG_PLACED = 3 /* arg = item */, NGW_MSG_ALREADY_EXISTS = 4 /* arg = front item */,
        NGW_MSG_NOT_IN_INVENTORY = 5, NGW_MSG_EXTRACT_NO_SRC = 6, NGW_MSG_EXTRACT_NOT_NEAR = 7,
-       NGW_MSG_MISSING_ITEMS = 8 /* arg = recipe<<8 | mask over recipe inputs in dict order */,
+       NGW_MSG_MISSING_ITEMS = 8 /* arg = recipe<<8 | mask over the recipe's inputs in dict order */,
        NGW_MSG_NEED_TABLE = 9, NGW_MSG_CRAFTED = 10 /* arg = crafted item */ };
 
 /* packed per-env info word produced by the step kernel:
