@@ -40,7 +40,6 @@ struct ngw_handle {
     int device = 0;
     uint64_t seed = 0;
     int autoreset = 0, horizon = 0;
-    int cur = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     NgwBufs b{};
@@ -118,7 +117,6 @@ int dev_alloc(ngw_handle* h, T** p, size_t count) {
 int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, const uint8_t* mask_dev, uint64_t action_seed, int64_t t0) {
     NgwLaunch a = h->proto;
     a.b = h->b;
-    a.cur = h->cur;
     a.mode = mode;
     a.n_steps = n_steps;
     a.actions = actions_dev;
@@ -129,7 +127,6 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     a.t0 = t0;
     const unsigned grid = (unsigned)(h->n_pad / NGW_EPB);
     HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, grid, h->lds_bytes, h->stream));
-    h->cur = (h->cur + n_steps) & 1;
     return NGW_OK;
 }
 
@@ -180,12 +177,10 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     const int S = spec->map_size, S2 = S * S, K = spec->n_items;
     const size_t np = (size_t)h->n_pad;
     int rc = NGW_OK;
-    for (int i = 0; i < 2 && !rc; i++) {
-        if (!rc) rc = dev_alloc(h, &h->b.map[i], np * S2);
-        if (!rc) rc = dev_alloc(h, &h->b.loc[i], np * 2);
-        if (!rc) rc = dev_alloc(h, &h->b.facing[i], np);
-        if (!rc) rc = dev_alloc(h, &h->b.inv[i], np * K);
-    }
+    if (!rc) rc = dev_alloc(h, &h->b.map, np * S2);
+    if (!rc) rc = dev_alloc(h, &h->b.loc, np * 2);
+    if (!rc) rc = dev_alloc(h, &h->b.facing, np);
+    if (!rc) rc = dev_alloc(h, &h->b.inv, np * K);
     if (!rc) rc = dev_alloc(h, &h->b.selected, np);
     if (!rc) rc = dev_alloc(h, &h->b.step_count, np);
     if (!rc) rc = dev_alloc(h, &h->b.episode, np);
@@ -363,11 +358,10 @@ int ngw_get_obs(ngw_handle* h, int8_t* map, int32_t* loc, int32_t* facing, int32
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     HIP_TRY(hipSetDevice(h->device));
     const size_t n = (size_t)h->n, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
-    const int c = h->cur;
-    D2H(map, h->b.map[c], n * S2);
-    D2H(loc, h->b.loc[c], n * 2 * sizeof(int32_t));
-    D2H(facing, h->b.facing[c], n * sizeof(int32_t));
-    D2H(inv, h->b.inv[c], n * K * sizeof(int32_t));
+    D2H(map, h->b.map, n * S2);
+    D2H(loc, h->b.loc, n * 2 * sizeof(int32_t));
+    D2H(facing, h->b.facing, n * sizeof(int32_t));
+    D2H(inv, h->b.inv, n * K * sizeof(int32_t));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return NGW_OK;
 }
@@ -402,11 +396,10 @@ int ngw_get_state(ngw_handle* h, int64_t first, int64_t count, int8_t* map, int3
     if (first < 0 || count < 0 || first + count > h->n) return fail(NGW_E_INVALID_ARG, "env range [%lld, +%lld) out of bounds", (long long)first, (long long)count);
     HIP_TRY(hipSetDevice(h->device));
     const size_t n = (size_t)count, f = (size_t)first, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
-    const int c = h->cur;
-    D2H(map, h->b.map[c] + f * S2, n * S2);
-    D2H(loc, h->b.loc[c] + f * 2, n * 2 * sizeof(int32_t));
-    D2H(facing, h->b.facing[c] + f, n * sizeof(int32_t));
-    D2H(inv, h->b.inv[c] + f * K, n * K * sizeof(int32_t));
+    D2H(map, h->b.map + f * S2, n * S2);
+    D2H(loc, h->b.loc + f * 2, n * 2 * sizeof(int32_t));
+    D2H(facing, h->b.facing + f, n * sizeof(int32_t));
+    D2H(inv, h->b.inv + f * K, n * K * sizeof(int32_t));
     D2H(step_count, h->b.step_count + f, n * sizeof(int32_t));
     D2H(episode, h->b.episode + f, n * sizeof(uint32_t));
     std::vector<uint8_t> sel;
@@ -451,11 +444,10 @@ int ngw_set_state(ngw_handle* h, int64_t first, int64_t count, const int8_t* map
         }
     }
     HIP_TRY(hipSetDevice(h->device));
-    const int c = h->cur;
-    H2D(h->b.map[c] + f * S2, map, n * S2);
-    H2D(h->b.loc[c] + f * 2, loc, n * 2 * sizeof(int32_t));
-    H2D(h->b.facing[c] + f, facing, n * sizeof(int32_t));
-    H2D(h->b.inv[c] + f * K, inv, n * K * sizeof(int32_t));
+    H2D(h->b.map + f * S2, map, n * S2);
+    H2D(h->b.loc + f * 2, loc, n * 2 * sizeof(int32_t));
+    H2D(h->b.facing + f, facing, n * sizeof(int32_t));
+    H2D(h->b.inv + f * K, inv, n * K * sizeof(int32_t));
     H2D(h->b.step_count + f, step_count, n * sizeof(int32_t));
     H2D(h->b.episode + f, episode, n * sizeof(uint32_t));
     if (selected) HIP_TRY(hipMemcpyAsync(h->b.selected + f, sel.data(), n, hipMemcpyHostToDevice, h->stream));
@@ -465,11 +457,10 @@ int ngw_set_state(ngw_handle* h, int64_t first, int64_t count, const int8_t* map
 
 int ngw_obs_device_ptrs(ngw_handle* h, void** map, void** loc, void** facing, void** inv) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
-    const int c = h->cur;
-    if (map) *map = h->b.map[c];
-    if (loc) *loc = h->b.loc[c];
-    if (facing) *facing = h->b.facing[c];
-    if (inv) *inv = h->b.inv[c];
+    if (map) *map = h->b.map;
+    if (loc) *loc = h->b.loc;
+    if (facing) *facing = h->b.facing;
+    if (inv) *inv = h->b.inv;
     return NGW_OK;
 }
 
@@ -512,16 +503,14 @@ int ngw_timing_end(ngw_handle* h, double* elapsed_ms) {
 
 int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps) {
     if (!h || !actions_dev) return fail(NGW_E_INVALID_ARG, "NULL argument");
-    if (n_steps < 2 || (n_steps & 1)) return fail(NGW_E_INVALID_ARG, "n_steps must be even (the observation buffers ping-pong)");
+    if (n_steps < 1) return fail(NGW_E_INVALID_ARG, "n_steps must be >= 1");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     drop_graph(h);
-    const int cur0 = h->cur;
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     int rc = NGW_OK;
     for (int i = 0; i < n_steps && !rc; i++) rc = launch(h, NGW_MODE_STEP, 1, actions_dev + (int64_t)i * step_stride, nullptr, 0, 0);
     hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
-    h->cur = cur0;                                   // capturing enqueued nothing
     if (rc) { drop_graph(h); return rc; }
     if (e != hipSuccess) { drop_graph(h); return fail(NGW_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e)); }
     e = hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0);
@@ -534,7 +523,7 @@ int ngw_graph_launch(ngw_handle* h, int32_t reps) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     if (!h->graph_exec) return fail(NGW_E_INVALID_ARG, "no graph: call ngw_graph_build first");
     HIP_TRY(hipSetDevice(h->device));
-    for (int i = 0; i < reps; i++) HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));   // even step count: `cur` is unchanged
+    for (int i = 0; i < reps; i++) HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
     return NGW_OK;
 }
 

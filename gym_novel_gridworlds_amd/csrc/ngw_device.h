@@ -12,13 +12,15 @@ enum { NGW_MODE_STEP = 0, NGW_MODE_RESET = 1, NGW_MODE_ROLLOUT = 2,
 /* how a wave's map chunk is laid out in LDS: same image as HBM / odd-dword-padded rows / byte-granular (odd S) */
 enum { NGW_MAP_STRAIGHT = 0, NGW_MAP_DWORD = 1, NGW_MAP_BYTE = 2 };
 
-/* Device buffers of one handle.  map/loc/facing/inv are the batched observation AND the state (ping-pong pair);
- * selected / step_count / episode are updated in place (each env is owned by exactly one lane). */
+/* Device buffers of one handle.  map/loc/facing/inv are the batched observation AND the state, updated IN PLACE:
+ * a step writes through only the bytes it changes (a map cell, a few inventory slots, the agent pose); a reset
+ * rewrites the wave's whole chunk with coalesced stores.  Each env is owned by exactly one lane, so there is no
+ * intra-launch hazard; launches are ordered by the stream. */
 struct NgwBufs {
-    int8_t* map[2];       /* [n_pad][S*S]  */
-    int32_t* loc[2];      /* [n_pad][2]    */
-    int32_t* facing[2];   /* [n_pad]       */
-    int32_t* inv[2];      /* [n_pad][K]    */
+    int8_t* map;          /* [n_pad][S*S]  */
+    int32_t* loc;         /* [n_pad][2]    */
+    int32_t* facing;      /* [n_pad]       */
+    int32_t* inv;         /* [n_pad][K]    */
     uint8_t* selected;    /* [n_pad] item id, 0 = ''  */
     int32_t* step_count;  /* [n_pad] */
     uint32_t* episode;    /* [n_pad] reset counter, keys the Philox stream */
@@ -35,7 +37,7 @@ struct NgwLaunch {
     uint64_t seed, action_seed;
     const int32_t* actions;      /* device, NGW_MODE_STEP */
     const uint8_t* reset_mask;   /* device or nullptr, NGW_MODE_RESET */
-    int32_t cur, mode, n_steps, autoreset, horizon;
+    int32_t mode, n_steps, autoreset, horizon;
     int32_t S, S2, MS, K, KP, CW; /* MS = LDS bytes per env map (MS/4 odd), KP = K|1 LDS inventory stride, CW = candidate words */
     uint32_t magic;              /* ceil(2^32 / (S2/4)) (or / S2 for odd S): exact division of chunk offsets */
     uint32_t magicK;             /* ceil(2^32 / K): exact division of inventory chunk offsets (< 64*K) */

@@ -4,11 +4,12 @@
 //   1. stages its 64 tile maps (64*S*S contiguous bytes) HBM -> LDS with coalesced 16-B loads, and the
 //      per-env scalars / inventory rows into registers / LDS,
 //   2. runs the table-driven step (and, for envs whose episode ended, the reset) per lane on LDS,
-//   3. writes the NEW state = the batched observation (map i8 [N,S,S], agent_location i32 [N,2],
-//      agent_facing_id i32 [N], inventory i32 [N,K]) to the OTHER buffer of a ping-pong pair with
-//      coalesced 16-B stores, plus reward / done / packed info.
-// The observation buffers ARE the state, so a step moves 2*S*S + 8*K + ~60 bytes per env and nothing else
-// (SURVEY.md §8(d) prices 2*S*S + 12*K + 45).  Integer/byte work only: no MFMA.
+//   3. writes THROUGH to HBM only what the step changed - the broken / placed map cell, the touched inventory
+//      slots, the agent pose - plus reward / done / packed info; a reset rewrites the wave's whole chunk with
+//      coalesced 16-B stores.
+// The observation buffers (map i8 [N,S,S], agent_location i32 [N,2], agent_facing_id i32 [N], inventory i32 [N,K])
+// ARE the state and are updated in place, so a step reads S*S + 4*K + ~30 bytes per env and writes ~30
+// (SURVEY.md §8(d) prices 2*S*S + 12*K + 45 for a read-pack-write design).  Integer/byte work only: no MFMA.
 // Every global load of a phase is issued before its first consumer so a phase costs ONE memory round trip.
 //
 // Semantics follow the reference line by line (citations at each branch):
@@ -314,7 +315,6 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     int32_t* inv = lds_inv + tid * a.KP;                                           // this lane's inventory row
     uint32_t* cand = lds_cand + tid;
 
-    int cur = a.cur;
     // ---- issue EVERY global load of the prologue before touching LDS: action table, first map round, scalars, inventory
     constexpr int NACT = NGW_MAX_ACTIONS * NGW_ACT_DW;
     static_assert(NACT <= 4 * EPB, "the action table is loaded with 4 dwords per lane");
@@ -322,14 +322,14 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
 #pragma unroll
     for (int j = 0; j < 4; j++) sv[j] = dspec->act_desc[min(tid + EPB * j, NACT - 1)];
     u32x4 buf[PB];
-    const u32x4* gin = reinterpret_cast<const u32x4*>(a.b.map[cur] + env0 * a.S2);
+    const u32x4* gin = reinterpret_cast<const u32x4*>(a.b.map + env0 * a.S2);
     pieces_load(buf, gin, 0, npieces, tid);
     int r = 1, c = 1, f = 0, sel = 0, steps = 0, action = 0;
     uint32_t episode = 0;
     if (live) {
-        const int2 rc = reinterpret_cast<const int2*>(a.b.loc[cur])[e];
+        const int2 rc = reinterpret_cast<const int2*>(a.b.loc)[e];
         r = rc.x; c = rc.y;
-        f = a.b.facing[cur][e];
+        f = a.b.facing[e];
         sel = a.b.selected[e];
         steps = a.b.step_count[e];
         episode = a.b.episode[e];
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     }
     u32x4 iq[IQ];
     {
-        const u32x4* gi = reinterpret_cast<const u32x4*>(a.b.inv[cur] + env0 * K);
+        const u32x4* gi = reinterpret_cast<const u32x4*>(a.b.inv + env0 * K);
 #pragma unroll
         for (int j = 0; j < IQ; j++) iq[j] = (j * EPB < 16 * K) ? gi[min(tid + EPB * j, 16 * K - 1)] : u32x4{0u, 0u, 0u, 0u};
     }
@@ -363,17 +363,16 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
 
     // ---- everything the step loop needs, fetched once and pinned in registers
     // per-lane output addresses for both ping-pong parities (VGPR pairs; 1 wave per SIMD leaves plenty)
-    g_u32x4* gmap[2] = {(g_u32x4*)(reinterpret_cast<u32x4*>(a.b.map[0] + env0 * a.S2) + tid),
-                        (g_u32x4*)(reinterpret_cast<u32x4*>(a.b.map[1] + env0 * a.S2) + tid)};
-    g_u32x4* ginv[2] = {(g_u32x4*)(reinterpret_cast<u32x4*>(a.b.inv[0] + env0 * K) + tid),
-                        (g_u32x4*)(reinterpret_cast<u32x4*>(a.b.inv[1] + env0 * K) + tid)};
-    g_int2* gloc[2] = {(g_int2*)(reinterpret_cast<int2*>(a.b.loc[0]) + e), (g_int2*)(reinterpret_cast<int2*>(a.b.loc[1]) + e)};
-    g_i32* gfac[2] = {(g_i32*)(a.b.facing[0] + e), (g_i32*)(a.b.facing[1] + e)};
+    g_u32x4* gmap = (g_u32x4*)(reinterpret_cast<u32x4*>(a.b.map + env0 * a.S2) + tid);     // coalesced chunk (reset only)
+    g_u32x4* ginv = (g_u32x4*)(reinterpret_cast<u32x4*>(a.b.inv + env0 * K) + tid);
+    GLOBAL_AS int8_t* gm = (GLOBAL_AS int8_t*)(a.b.map + e * a.S2);                      // this env's map / inventory row
+    g_i32* gi = (g_i32*)(a.b.inv + e * K);
+    g_int2* gloc = (g_int2*)(reinterpret_cast<int2*>(a.b.loc) + e);
+    g_i32* gfac = (g_i32*)(a.b.facing + e);
     g_i32* grew = (g_i32*)(a.b.reward + e);
     g_u8* gdone = (g_u8*)(a.b.done + e);
     g_u32* ginfo = (g_u32*)(a.b.info + e);
-    PIN_V(gmap[0]); PIN_V(gmap[1]); PIN_V(ginv[0]); PIN_V(ginv[1]); PIN_V(gloc[0]); PIN_V(gloc[1]);
-    PIN_V(gfac[0]); PIN_V(gfac[1]); PIN_V(grew); PIN_V(gdone); PIN_V(ginfo);
+    PIN_V(gmap); PIN_V(ginv); PIN_V(gm); PIN_V(gi); PIN_V(gloc); PIN_V(gfac); PIN_V(grew); PIN_V(gdone); PIN_V(ginfo);
     constexpr int mode = MODE;
     int n_steps = (MODE == NGW_MODE_ROLLOUT) ? a.n_steps : 1, autoreset = a.autoreset, horizon = a.horizon;
     PIN_S(n_steps); PIN_S(autoreset); PIN_S(horizon);
@@ -398,8 +397,8 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     PIN_S(ext_cost_ok); PIN_S(axe_item); PIN_S(axe_cost); PIN_S(axe_qty); PIN_S(place_reward); PIN_S(ext_reward); PIN_S(axe_reward);
 
     for (int t = 0; t < n_steps; t++, tt++) {
+        bool do_reset = false;
         if (live && mode != NGW_MODE_DBG_COPY) {
-            bool do_reset = false;
             if (mode == NGW_MODE_RESET) {
                 do_reset = action != 0;
             } else {
@@ -452,20 +451,19 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                     case NGW_ACT_BREAK:                                            // :280-294, axe: novelty_wrappers.py:144-183
                         cost = cost_break;
                         if ((brk_mask >> front) & 1u) {
-                            mp[fcell] = 0;
+                            mp[fcell] = 0; gm[fcell] = 0;
+                            int nv = inv_front + 1;
                             if (axe_item && inv_axe >= 1 && sel == axe_item) {
-                                inv[front] = inv_front + axe_qty; rew = axe_reward; cost = axe_cost;
-                            } else {
-                                inv[front] = inv_front + 1;
-                                if (!axe_item && ((rew_mask >> front) & 1u)) rew = break_reward;
-                            }
+                                nv = inv_front + axe_qty; rew = axe_reward; cost = axe_cost;
+                            } else if (!axe_item && ((rew_mask >> front) & 1u)) rew = break_reward;
+                            inv[front] = nv; gi[front] = nv;
                         } else { result = 0; msg = NGW_MSG_CANNOT_BREAK; arg = front; }
                         break;
                     case NGW_ACT_PLACE:                                            // :295-314
                         if (inv_place >= 1) {
                             if (front == 0) {
-                                mp[fcell] = (int8_t)place_item;
-                                inv[place_item] = inv_place - 1;
+                                mp[fcell] = (int8_t)place_item; gm[fcell] = (int8_t)place_item;
+                                inv[place_item] = inv_place - 1; gi[place_item] = inv_place - 1;
                                 msg = NGW_MSG_PLACED; arg = place_item;
                                 const int nr = place_near;
                                 if ((okN && nbN == nr) || (okS && nbS == nr) || (okW && nbW == nr) || (okE && nbE == nr))
@@ -479,8 +477,8 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                         if (front == ext_src) {
                             const int nr = ext_near;
                             if (!nr || (okN && nbN == nr) || (okS && nbS == nr) || (okW && nbW == nr) || (okE && nbE == nr)) {
-                                inv[ext_out] = inv_ext + ext_qty;
-                                if (ext_consume) mp[fcell] = 0;
+                                inv[ext_out] = inv_ext + ext_qty; gi[ext_out] = inv_ext + ext_qty;
+                                if (ext_consume) { mp[fcell] = 0; gm[fcell] = 0; }
                                 rew = ext_reward; cost = ext_cost_ok;
                             } else { result = 0; msg = NGW_MSG_EXTRACT_NOT_NEAR; }
                         } else { result = 0; msg = NGW_MSG_EXTRACT_NO_SRC; }
@@ -495,11 +493,12 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                             result = 0; msg = NGW_MSG_NEED_TABLE; cost = d3 >> 24;
                         } else {                                                   // :455-474 (ids of a recipe are distinct)
                             rew = craft_reward;
-                            if (nin > 0) inv[in0] = iv0 - nd0;
-                            if (nin > 1) inv[in1] = iv1 - nd1;
-                            if (nin > 2) inv[in2] = iv2 - nd2;
-                            if (nin > 3) inv[in3] = iv3 - nd3;
-                            inv[out_item] = inv_out + (int)((d3 >> 8) & 255);
+                            if (nin > 0) { inv[in0] = iv0 - nd0; gi[in0] = iv0 - nd0; }
+                            if (nin > 1) { inv[in1] = iv1 - nd1; gi[in1] = iv1 - nd1; }
+                            if (nin > 2) { inv[in2] = iv2 - nd2; gi[in2] = iv2 - nd2; }
+                            if (nin > 3) { inv[in3] = iv3 - nd3; gi[in3] = iv3 - nd3; }
+                            const int nout = inv_out + (int)((d3 >> 8) & 255);
+                            inv[out_item] = nout; gi[out_item] = nout;
                             cost = (int)d4; msg = NGW_MSG_CRAFTED; arg = out_item;
                         }
                         break;
@@ -514,7 +513,11 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                         for (int rr = r - 1; rr <= r + 1; rr++)
                             for (int cc = c - 1; cc <= c + 1; cc++) {
                                 const int id = mp[rr * S + cc];
-                                if (id != 0 && ((ent_mask >> id) & 1u)) { mp[rr * S + cc] = 0; inv[id] += 1; }
+                                if (id != 0 && ((ent_mask >> id) & 1u)) {
+                                    mp[rr * S + cc] = 0; gm[rr * S + cc] = 0;
+                                    const int nv = inv[id] + 1;
+                                    inv[id] = nv; gi[id] = nv;
+                                }
                             }
                     }
                     int done = 0;                                                  // :354-357 (LDS ops of a wave are in order)
@@ -537,33 +540,30 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                 sel = 0; steps = 0;
             }
         }
-        __syncthreads();
-        // ---- write the new state == the observation into the other buffer: all LDS reads, then all stores
-        const int nxt = cur ^ 1;
-        g_u32x4* gout = nxt ? gmap[1] : gmap[0];                                   // already offset by this lane's piece 0
-        for (int base = 0; base < npieces; base += EPB * PB) {
-            pieces_lds<false, MAPMODE>(buf, a, lds_map, base, npieces, tid);
+        // ---- a reset rewrote whole maps / inventory rows in LDS: store the wave's chunk back with coalesced 16-B pieces
+        //      (wave-uniform decision; lanes that only stepped have already written their few changed bytes through)
+        if (mode == NGW_MODE_DBG_COPY || __any(do_reset)) {
+            __syncthreads();
+            for (int base = 0; base < npieces; base += EPB * PB) {
+                pieces_lds<false, MAPMODE>(buf, a, lds_map, base, npieces, tid);
 #pragma unroll
-            for (int j = 0; j < PB; j++)
-                if (base + tid + EPB * j < npieces) gout[base + EPB * j] = buf[j];
-        }
-        {
-            g_u32x4* go = nxt ? ginv[1] : ginv[0];
+                for (int j = 0; j < PB; j++)
+                    if (base + tid + EPB * j < npieces) gmap[base + EPB * j] = buf[j];
+            }
             inv_lds<false>(iq, a, lds_inv, tid);
 #pragma unroll
-            for (int j = 0; j < IQ; j++) { if (j * EPB < 16 * K && tid + EPB * j < 16 * K) go[EPB * j] = iq[j]; }
+            for (int j = 0; j < IQ; j++) { if (j * EPB < 16 * K && tid + EPB * j < 16 * K) ginv[EPB * j] = iq[j]; }
+            __syncthreads();
         }
         if (live) {
-            { g_int2* gl = nxt ? gloc[1] : gloc[0]; gl->x = r; gl->y = c; }
-            *(nxt ? gfac[1] : gfac[0]) = f;
+            gloc->x = r; gloc->y = c;
+            *gfac = f;
             if (mode != NGW_MODE_RESET) {
                 *grew = reward;
                 *gdone = (uint8_t)ended;
                 *ginfo = info;
             }
         }
-        cur = nxt;
-        __syncthreads();
     }
     if (live) {
         a.b.selected[e] = (uint8_t)sel;

@@ -8,7 +8,7 @@
  *
  * One handle = N independent environments resident on ONE GPU (one process per GPU; shard by
  * creating one handle per rank with `env_index_base = rank * N`).  All state lives in HBM as
- * structure-of-arrays; the observation buffers ARE the state (ping-pong pair), see DESIGN.md.
+ * structure-of-arrays; the observation buffers ARE the state, updated in place, see DESIGN.md.
  *
  * Every function returns 0 on success or a negative NGW_E_* code; ngw_last_error() gives the
  * thread-local message.  A handle is not thread-safe (one host thread per handle), matching the
@@ -145,8 +145,8 @@ int ngw_step(ngw_handle* h, const int32_t* actions_host);
 /* Same with actions already in HBM; an out-of-range id sets NGW_F_INVALID_ACTION and leaves that env untouched. */
 int ngw_step_device(ngw_handle* h, const int32_t* actions_dev);
 /* Fused bench mode: T steps in one launch with on-device uniform actions
- * a = (philox(action_seed; t, env) * A) >> 32; state stays in LDS/registers between steps.  The observation
- * of every step is written to the current observation buffers (last one survives). */
+ * a(t, env) = (word (t & 3) of philox(action_seed; t >> 2, env) * A) >> 32; state stays in LDS/registers between
+ * steps and every step's changes are written through to the observation buffers. */
 int ngw_rollout(ngw_handle* h, int32_t n_steps, uint64_t action_seed, int64_t t0);
 
 /* get_observation(): pogostick_v1_env.py:214-228, batched: map i8 [N,S,S], agent_location i32 [N,2] (r,c),
@@ -164,7 +164,8 @@ int ngw_set_state(ngw_handle* h, int64_t first, int64_t count, const int8_t* map
                   const int32_t* facing, const int32_t* inv, const int32_t* selected,
                   const int32_t* step_count, const uint32_t* episode);
 
-/* Device pointers of the CURRENT observation / output buffers (valid until the next step or reset). */
+/* Device pointers of the observation / output buffers (fixed for the handle's lifetime; contents are the state
+ * after the last enqueued step and are updated in place by the next one). */
 int ngw_obs_device_ptrs(ngw_handle* h, void** map, void** loc, void** facing, void** inv);
 int ngw_out_device_ptrs(ngw_handle* h, void** reward, void** done, void** info);
 int ngw_sync(ngw_handle* h);
@@ -175,7 +176,7 @@ int ngw_error_flags(ngw_handle* h, uint32_t* flags);
 int ngw_timing_begin(ngw_handle* h);
 int ngw_timing_end(ngw_handle* h, double* elapsed_ms);
 
-/* hipGraph stepping for launch-bound loops: captures n_steps (even) consecutive ngw_step_device launches whose
+/* hipGraph stepping for launch-bound loops: captures n_steps consecutive ngw_step_device launches whose
  * actions are read from actions_dev + i * step_stride (int32 elements) into one executable graph, then replays it.
  * Semantically identical to calling ngw_step_device n_steps * reps times with those action rows. */
 int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps);
