@@ -78,6 +78,9 @@ def main():
     ap.add_argument('--launch', default='graph', choices=['graph', 'eager'],
                     help='step mode: replay the K step launches from one hipGraph (default) or launch them one by one')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='gloo + --single-device: rehearse the N > 1 code path on a one-GPU box (every rank on cuda:0)')
+    ap.add_argument('--single-device', action='store_true')
     args = ap.parse_args()
 
     import torch
@@ -90,10 +93,15 @@ def main():
             sys.exit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
         args.gpus = world
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL on ROCm
+        else:
+            dist.init_process_group('gloo')
 
     from gym_novel_gridworlds_amd import VecNovelGridworld, apply_novelty, make_spec
     env_id, S, nov, n_default, desc = WORKLOADS[args.workload]
@@ -156,9 +164,9 @@ def main():
     dt = time.perf_counter() - t0
     assert v.error_flags() == 0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt, dev_ms], dtype=torch.float64, device='cuda' if args.dist_backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dev_ms = float(t[0].item()), float(t[1].item())
 
     # roofline: algorithmic bytes per launch / average launch duration (device time of the timed region / launches)
     launches = 1 if args.mode == 'rollout' else steps

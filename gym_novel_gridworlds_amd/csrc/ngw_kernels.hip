@@ -32,6 +32,7 @@ namespace {
 #define PIN_S(x) asm volatile("" : "+s"(x))
 #define PIN_V(x) asm volatile("" : "+v"(x))
 #define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
 
 constexpr int EPB = NGW_EPB;   // envs per block = wavefront width
 
@@ -105,12 +106,15 @@ struct ResetArgs {
     int S, S2, K, CW;
 };
 
-__device__ __noinline__ uint32_t reset_lane(const ResetArgs a, int8_t* mp, int32_t* inv, uint32_t* cand, uint64_t env_global,
-                                            int64_t env_local, uint32_t episode) {
-    const ngw_spec& sp = a.dspec->sp;
-    const double* addq = a.dspec->addq;
+// (LDS / global pointers carry their address space: across a real call generic pointers would turn every access
+//  into a flat_* instruction)
+__device__ __noinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t* mp, LDS_AS int32_t* inv, LDS_AS uint32_t* cand,
+                                            uint64_t env_global, int64_t env_local, uint32_t episode) {
+    const GLOBAL_AS ngw_spec& sp = *(const GLOBAL_AS ngw_spec*)&a.dspec->sp;
+    const GLOBAL_AS double* addq = (const GLOBAL_AS double*)a.dspec->addq;
     int r_out, c_out, f_out;
     const int S = a.S, K = a.K, W = S - 4, ncand = W * W;
+    const uint32_t magicW = (uint32_t)((0x100000000ull + (uint32_t)W - 1) / (uint32_t)W);   // pos / W == umulhi(pos, magicW), pos < 2^12
     Philox px;
     philox_init(px, a.seed, env_global, episode);
     for (int k = 0; k < K; k++) inv[k] = 0;                                        // :119
@@ -124,8 +128,9 @@ __device__ __noinline__ uint32_t reset_lane(const ResetArgs a, int8_t* mp, int32
     int len = ncand;
     uint32_t flags = 0;
     int apos = (int)bounded(px, (uint32_t)len - 1);                                // :141 (agent stays in the list)
-    const int agent = (2 + apos / W) * S + 2 + apos % W;
-    r_out = agent / S; c_out = agent % S;
+    const int arow = (int)__umulhi((uint32_t)apos, magicW), acol = apos - arow * W;
+    const int agent = (2 + arow) * S + 2 + acol;
+    r_out = 2 + arow; c_out = 2 + acol;
     f_out = (int)bounded(px, 3);                                                   // :145
     for (int j = 0; j < sp.n_start; j++) {                                         // :147-148 insertion order
         const int item = sp.start_item[j], want = sp.start_qty[j];
@@ -139,7 +144,8 @@ __device__ __noinline__ uint32_t reset_lane(const ResetArgs a, int8_t* mp, int32
             cand[w * EPB] &= ~(1u << bit);                                         // list.pop(idx)
             len--;
             const int pos = w * 32 + bit;
-            const int cell = (2 + pos / W) * S + 2 + pos % W;
+            const int prow = (int)__umulhi((uint32_t)pos, magicW);
+            const int cell = (2 + prow) * S + 2 + (pos - prow * W);
             if (cell != agent &&                                                   // :172-174
                 mp[cell] == 0 && mp[cell - S] == 0 && mp[cell + S] == 0 && mp[cell - 1] == 0 && mp[cell + 1] == 0) {
                 mp[cell] = (int8_t)item;                                           // :177-180
@@ -149,7 +155,7 @@ __device__ __noinline__ uint32_t reset_lane(const ResetArgs a, int8_t* mp, int32
         if (flags) break;
     }
     if (sp.additem_item && !flags) {                                               // AddItem.reset novelty_wrappers.py:1017-1028
-        uint16_t* perm = a.perm + env_local;                                       // [S2][n_pad] scratch column
+        GLOBAL_AS uint16_t* perm = (GLOBAL_AS uint16_t*)(a.perm + env_local);          // [S2][n_pad] scratch column
         const int64_t ps = a.n_pad;
         int n_air = 0;
         for (int i = 0; i < a.S2; i++)
@@ -534,7 +540,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
             if (do_reset) {                                                        // cold path, out of line
                 episode++;
                 const ResetArgs ra = {dspec, a.b.perm, a.n_pad, a.seed, S, a.S2, K, a.CW};
-                const uint32_t rr = reset_lane(ra, mp, inv, cand, env_global, e, episode);
+                const uint32_t rr = reset_lane(ra, (LDS_AS int8_t*)mp, (LDS_AS int32_t*)inv, (LDS_AS uint32_t*)cand, env_global, e, episode);
                 flags |= rr & 0xFFu;
                 r = (int)((rr >> 8) & 0xFFu); c = (int)((rr >> 16) & 0xFFu); f = (int)(rr >> 24);
                 sel = 0; steps = 0;

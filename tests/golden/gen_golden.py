@@ -49,6 +49,7 @@ CFGS = {
     'add12m':   (POGO, 12, ('additem', 'medium', 'spring', '')),
     'add11e':   (POGO, 11, ('additem', 'easy', 'arrow', '')),
     'bowaxe16': (BOW, 16, ('axe', 'medium', 'wooden', 'false')),
+    'axeeasy10': (POGO, 10, ('axe', 'easy', 'wooden', '')),         # AxeEasy: the axe starts in the inventory
 }
 DIRS = ['NORTH', 'SOUTH', 'WEST', 'EAST']
 
@@ -163,19 +164,20 @@ def exhaustion_cases():
 def gen_resets(cfg, nseeds, out):
     env = make_env(cfg)
     base = env.unwrapped
-    maps, locs, facs, words = [], [], [], []
+    maps, locs, facs, words, invs = [], [], [], [], []
     for seed in range(nseeds):
         np.random.seed(seed)
         for _ in range(3):
             env.reset()
             m, loc, f, sel, inv = snap(base)
-            assert sel == 0 and not inv.any()
-            maps.append(m), locs.append(loc), facs.append(f)
+            assert sel == 0 and (not inv.any() or cfg == 'axeeasy10')
+            maps.append(m), locs.append(loc), facs.append(f), invs.append(inv)
         words.append(next_word())
     out['rs_map'] = np.array(maps, np.int8).reshape(nseeds, 3, -1)
     out['rs_loc'] = np.array(locs, np.int32).reshape(nseeds, 3, 2)
     out['rs_facing'] = np.array(facs, np.int32).reshape(nseeds, 3)
     out['rs_next_word'] = np.array(words, np.uint32)
+    out['rs_inv'] = np.array(invs, np.int32).reshape(nseeds, 3, -1)
 
 
 # ---------------------------------------------------------------- G3 traces
@@ -195,7 +197,7 @@ def gen_trace(cfg, k, T, out, strings):
     msg = np.zeros(T, np.int32)
     loc, fac, sel, inv = np.zeros((T, 2), np.int32), np.zeros(T, np.int32), np.zeros(T, np.int32), np.zeros((T, K), np.int32)
     md_t, md_i, md_v = [], [], []
-    rl_t, rl_map, rl_loc, rl_fac = [], [], [], []
+    rl_t, rl_map, rl_loc, rl_fac, rl_inv = [], [], [], [], []
     inj_t, inj_item, inj_q = [], [], []
 
     np.random.seed(1000 + k)
@@ -204,8 +206,8 @@ def gen_trace(cfg, k, T, out, strings):
     for t in range(T):
         if need_reset:
             env.reset()
-            m, l, f, _, _ = snap(base)
-            rl_t.append(t), rl_map.append(m), rl_loc.append(l), rl_fac.append(f)
+            m, l, f, _, iv0 = snap(base)
+            rl_t.append(t), rl_map.append(m), rl_loc.append(l), rl_fac.append(f), rl_inv.append(iv0)
             prev_map, need_reset, done_run = m, False, 0
         if t % 37 == 36:
             for name in rs.choice(inj_pool, size=3, replace=False):
@@ -241,6 +243,7 @@ def gen_trace(cfg, k, T, out, strings):
                                                          np.array(md_v, np.int8))
     out[p + 'rl_t'], out[p + 'rl_map'] = np.array(rl_t, np.int32), np.array(rl_map, np.int8)
     out[p + 'rl_loc'], out[p + 'rl_facing'] = np.array(rl_loc, np.int32), np.array(rl_fac, np.int32)
+    out[p + 'rl_inv'] = np.array(rl_inv, np.int32)
     out[p + 'inj_t'], out[p + 'inj_item'], out[p + 'inj_q'] = (np.array(inj_t, np.int32), np.array(inj_item, np.int32),
                                                                np.array(inj_q, np.int32))
     return int(done.sum())
@@ -435,7 +438,7 @@ def gen_solved(cfg, nep, out, strings):
         np.random.seed(500 + seed)
         seed += 1
         env.reset()
-        m0, l0, f0, _, _ = snap(base)
+        m0, l0, f0, _, i0 = snap(base)
         K = len(base.items_id)
         rows = []
         prev = [m0]
@@ -454,7 +457,7 @@ def gen_solved(cfg, nep, out, strings):
             continue
         p = 'so%d_' % got
         got += 1
-        out[p + 'map0'], out[p + 'loc0'], out[p + 'facing0'] = m0, l0, f0
+        out[p + 'map0'], out[p + 'loc0'], out[p + 'facing0'], out[p + 'inv0'] = m0, l0, f0, i0
         out[p + 'action'] = np.array([r[0] for r in rows], np.int32)
         out[p + 'reward'] = np.array([r[1] for r in rows], np.int32)
         out[p + 'done'] = np.array([r[2] for r in rows], np.uint8)
@@ -516,7 +519,7 @@ PLAN = {  # cfg: (reset seeds, traces, steps per trace, single-step cases, solve
     'pogo10': (48, 6, 1600, 6000, 4), 'bow20': (32, 4, 1600, 3000, 3), 'axe10': (48, 6, 1600, 6000, 4),
     'add32': (24, 3, 1200, 500, 0), 'pogo13': (16, 2, 1000, 1500, 2), 'bow10': (16, 2, 1000, 3000, 2),
     'axe12bi': (16, 3, 1200, 4000, 3), 'add12m': (16, 2, 1000, 1500, 0), 'add11e': (16, 1, 600, 500, 0),
-    'bowaxe16': (16, 2, 1000, 2500, 2),
+    'bowaxe16': (16, 2, 1000, 2500, 2), 'axeeasy10': (16, 3, 1200, 3000, 2),
 }
 
 

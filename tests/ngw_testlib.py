@@ -18,6 +18,7 @@ CFGS = {
     'pogo13': (POGO, 13, None), 'bow10': (BOW, 10, None), 'axe12bi': (POGO, 12, ('axe', 'medium', 'iron', 'true')),
     'add12m': (POGO, 12, ('additem', 'medium', 'spring', '')), 'add11e': (POGO, 11, ('additem', 'easy', 'arrow', '')),
     'bowaxe16': (BOW, 16, ('axe', 'medium', 'wooden', 'false')),
+    'axeeasy10': (POGO, 10, ('axe', 'easy', 'wooden', '')),
 }
 HEADLINE = ['pogo10', 'bow20', 'axe10', 'add32']       # BASELINE.json configs 2-5
 
@@ -120,7 +121,8 @@ def replay_traces(cfg, backend_cls, **kw):
             p = 'tr%d_' % k
             if t in ev[k]['rl']:
                 j = ev[k]['rl'][t]
-                be.load(k, g[p + 'rl_map'][j], g[p + 'rl_loc'][j], g[p + 'rl_facing'][j])
+                be.load(k, g[p + 'rl_map'][j], g[p + 'rl_loc'][j], g[p + 'rl_facing'][j],
+                        inv=g[p + 'rl_inv'][j] if p + 'rl_inv' in g else None)
                 exp_map[k] = g[p + 'rl_map'][j]
             for it, q in ev[k]['inj'].get(t, ()):
                 be.add_inventory(k, it, q)
@@ -173,7 +175,8 @@ def replay_solved(cfg, backend_cls, **kw):
     lens = [len(g['so%d_action' % k]) for k in range(nso)]
     exp_map = np.stack([g['so%d_map0' % k] for k in range(nso)])
     for k in range(nso):
-        be.load(k, g['so%d_map0' % k], g['so%d_loc0' % k], g['so%d_facing0' % k])
+        be.load(k, g['so%d_map0' % k], g['so%d_loc0' % k], g['so%d_facing0' % k],
+                inv=g['so%d_inv0' % k] if 'so%d_inv0' % k in g else None)
     md = [{} for _ in range(nso)]
     for k in range(nso):
         for t, i, v in zip(g['so%d_md_t' % k], g['so%d_md_i' % k], g['so%d_md_v' % k]):
@@ -346,7 +349,8 @@ def replay_adapter(cfg, backend, max_steps=400, n_single=300):
     for t in range(min(max_steps, len(g[p + 'action']))):
         if t in rl:
             j = rl[t]
-            adapter_inject(base, spec, g[p + 'rl_map'][j], g[p + 'rl_loc'][j], g[p + 'rl_facing'][j], 0, np.zeros(K, int))
+            adapter_inject(base, spec, g[p + 'rl_map'][j], g[p + 'rl_loc'][j], g[p + 'rl_facing'][j], 0,
+                           g[p + 'rl_inv'][j] if p + 'rl_inv' in g else np.zeros(K, int))
             base.step_count = 0
         for it, q in inj.get(t, ()):
             base.inventory_items_quantity[names[it]] += q

@@ -43,7 +43,8 @@ def test_solved_episodes_match_reference(cfg):
 
 # ------------------------------------------------------------------ oracle on the same seeded inputs
 @pytest.mark.parametrize('cfg,n', [('pogo10', 5000), ('bow20', 1500), ('axe10', 4096), ('add32', 300), ('pogo13', 777),
-                                   ('bow10', 1000), ('axe12bi', 1000), ('add12m', 640), ('add11e', 500), ('bowaxe16', 900)])
+                                   ('bow10', 1000), ('axe12bi', 1000), ('add12m', 640), ('add11e', 500), ('bowaxe16', 900),
+                                   ('axeeasy10', 700)])
 def test_reset_matches_oracle(cfg, n):
     """reset(): template + per-env Philox item scatter (+ AddItem pass), three episodes, ragged N, masked reset."""
     spec = T.build_spec(cfg)

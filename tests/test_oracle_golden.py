@@ -44,7 +44,8 @@ def test_reset_mt19937_matches_reference(cfg):
             assert o.reset_mt(mt) == 0
             assert (o.st.map[0] == g['rs_map'][seed, j]).all(), (cfg, seed, j)
             assert (o.st.loc[0] == g['rs_loc'][seed, j]).all() and o.st.facing[0] == g['rs_facing'][seed, j]
-            assert not o.st.inv.any() and o.st.selected[0] == 0 and o.st.step_count[0] == 0
+            exp_inv = g['rs_inv'][seed, j] if 'rs_inv' in g else 0
+            assert (o.st.inv[0] == exp_inv).all() and o.st.selected[0] == 0 and o.st.step_count[0] == 0
         assert mt.next() == g['rs_next_word'][seed], (cfg, seed)
 
 

@@ -20,8 +20,8 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(src, pattern), recursive=True)
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
+    return f[-1] if f else None
 
 
 def kernel_rows(path):
@@ -47,14 +47,15 @@ for mode in ('step', 'rollout'):
     out.append('')
     if mode == 'step':
         steps = d[1:]                                  # first launch is the reset-all
-        normal = [x for x in steps if x < 2.5 * st.median(steps)]
-        resets = [x for x in steps if x >= 2.5 * st.median(steps)]
+        resets = [steps[i] for i in range(99, len(steps), 100)]      # every env hits the horizon H = 100 together
+        normal = [steps[i] for i in range(len(steps)) if i % 100 != 99]
+        big = sorted(normal)[-3:]
         out.append('Per-dispatch (kernel_trace.csv): reset-all launch %.1f us; %d step launches: median %.2f us, mean %.2f us; '
-                   '%d of them hit the horizon (every env resets in that launch): mean %.1f us; the other %d: mean %.2f us. '
-                   'VGPR %s, SGPR %s, workgroup %s, grid %s.'
-                   % (d[0], len(steps), st.median(steps), st.mean(steps), len(resets), st.mean(resets) if resets else 0,
-                      len(normal), st.mean(normal), rows[1]['VGPR_Count'], rows[1]['SGPR_Count'], rows[1]['Workgroup_Size_X'],
-                      rows[1]['Grid_Size_X']))
+                   '%d of them hit the horizon (every env resets in that launch): %s us; the other %d: mean %.2f us, '
+                   'three slowest %s us. VGPR %s, SGPR %s, workgroup %s, grid %s.'
+                   % (d[0], len(steps), st.median(steps), st.mean(steps), len(resets), ', '.join('%.1f' % x for x in resets),
+                      len(normal), st.mean(normal), ', '.join('%.1f' % x for x in big), rows[1]['VGPR_Count'],
+                      rows[1]['SGPR_Count'], rows[1]['Workgroup_Size_X'], rows[1]['Grid_Size_X']))
     else:
         out.append('Per-dispatch: reset-all %.1f us; warm-up rollout (100 steps) %.1f us; timed rollout (400 steps) %.1f us = %.3f us per batched step.'
                    % (d[0], d[1], d[2], d[2] / 400))

@@ -8,6 +8,7 @@
 set -e
 TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="python3 bench.py --no-cpu-baseline --steps 400 --warmup 100"
