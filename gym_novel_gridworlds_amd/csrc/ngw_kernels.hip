@@ -609,8 +609,15 @@ static hipError_t launch_mode(const NgwDevSpec* dspec, const NgwLaunch* a, unsig
     }
 }
 
+__global__ void ngw_nop_kernel(const NgwDevSpec* dspec, const NgwLaunch a) {}
+
 extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, unsigned grid, size_t lds_bytes,
                                  hipStream_t stream) {
+    if (a->mode >= 10 && a->mode <= 12) {       // diagnostics: empty kernels with other workgroup shapes over the same lanes
+        const unsigned tpb = a->mode == 10 ? 256 : (a->mode == 11 ? 1024 : 128);
+        hipLaunchKernelGGL(ngw_nop_kernel, dim3(grid * NGW_EPB / tpb), dim3(tpb), a->mode == 12 ? lds_bytes * 2 : 0, stream, dspec, *a);
+        return hipGetLastError();
+    }
     switch (map_mode) {
     case NGW_MAP_STRAIGHT: return launch_mode<NGW_MAP_STRAIGHT>(dspec, a, grid, lds_bytes, stream);
     case NGW_MAP_DWORD: return launch_mode<NGW_MAP_DWORD>(dspec, a, grid, lds_bytes, stream);

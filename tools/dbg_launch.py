@@ -20,7 +20,7 @@ for n in [int(x) for x in (sys.argv[1:] or ['65536', '262144', '1048576'])]:
     v.reset()
     acts = torch.randint(0, 17, (64, n), dtype=torch.int32, device='cuda')
     torch.cuda.synchronize()
-    for mode, name in ((8, 'nop'), (9, 'copy'), (0, 'step')):
+    for mode, name in ((8, 'nop'), (10, 'nop 256-thread WGs'), (11, 'nop 1024-thread WGs'), (12, 'nop 128-thread WGs + LDS'), (9, 'copy'), (0, 'step')):
         for rep in range(2):
             v.sync(); t = time.perf_counter()
             K = 500
