@@ -86,6 +86,9 @@ int check_spec(const ngw_spec* s) {
     }
     for (int j = 0; j < s->n_start; j++)
         if (!item_ok(s->start_item[j])) return fail(NGW_E_INVALID_ARG, "start item out of range");
+    int total_place = 0;
+    for (int j = 0; j < s->n_start; j++) total_place += s->start_qty[j];
+    if (total_place > NGW_MAX_PLACE) return fail(NGW_E_INVALID_ARG, "items_quantity places %d items per reset (max %d)", total_place, NGW_MAX_PLACE);
     int brw = s->reward_step;
     for (int i = 0; i < K; i++)
         if (s->break_reward[i] != s->reward_step) {
@@ -190,7 +193,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     if (!rc) rc = dev_alloc(h, &h->b.flags, 1);
     if (!rc) rc = dev_alloc(h, &h->actions_dev, np);
     if (!rc) rc = dev_alloc(h, &h->mask_dev, np);
-    if (!rc && spec->additem_item) rc = dev_alloc(h, &h->b.perm, np * S2);
+    if (!rc && spec->additem_item) rc = dev_alloc(h, &h->b.perm, np * S2);   // HBM fallback for maps too big for the LDS shuffle
     if (!rc) rc = dev_alloc(h, &h->dspec, 1);
     if (rc) return bail(rc);
     {
@@ -214,6 +217,8 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
         u.ext_consume = spec->ext_consume; u.ext_cost_ok = spec->ext_cost_ok;
         u.axe_item = spec->axe_item; u.axe_cost = spec->axe_cost; u.axe_qty = spec->axe_qty;
         u.place_reward = spec->place_reward; u.ext_reward = spec->ext_reward; u.axe_reward = spec->axe_reward;
+        for (int j = 0; j < spec->n_start; j++)
+            for (int q = 0; q < spec->start_qty[j]; q++) hs.place_seq[hs.n_place++] = spec->start_item[j];
         for (int a = 0; a < spec->n_actions; a++) {
             uint32_t* d = hs.act_desc + a * NGW_ACT_DW;
             const uint32_t kind = spec->act_kind[a], arg = spec->act_arg[a];
@@ -252,7 +257,14 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     off = (off + 3u) & ~3u;
     p.off_inv = off; off += (uint32_t)(p.KP * NGW_EPB);
     p.off_cand = off; off += (uint32_t)(p.CW * NGW_EPB);
-    p.off_act = off; off += (uint32_t)(NGW_MAX_ACTIONS * NGW_ACT_DW);
+    p.off_act = off; off += (uint32_t)(NGW_MAX_ACTIONS * NGW_ACT_DW + NGW_MAX_PLACE / 4);
+    p.perm_lds = 0; p.off_perm = off;
+    if (spec->additem_item) {
+        // Shuffle array in LDS only while the wave's LDS stays small (<= 32 KiB, 5 waves/CU).  Measured at S = 32: the
+        // extra 64 KiB halves the resident waves per CU and costs more (step 50 -> 115 us) than the HBM scratch column.
+        const uint32_t perm_dw = (uint32_t)(S2 * 32 * 2 / 4);
+        if ((size_t)(off + perm_dw) * 4 <= 32 * 1024) { p.perm_lds = 1; off += perm_dw; }
+    }
     h->lds_bytes = (size_t)off * 4;
     if (h->lds_bytes > 160 * 1024) return bail(fail(NGW_E_INVALID_ARG, "map_size %d needs %zu B of LDS per wavefront (> 160 KiB)", S, h->lds_bytes));
     if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(NGW_E_HIP, "stream sync failed after allocation"));

@@ -39,6 +39,8 @@ struct NgwLaunch {
     const uint8_t* reset_mask;   /* device or nullptr, NGW_MODE_RESET */
     int32_t mode, n_steps, autoreset, horizon;
     int32_t S, S2, MS, K, KP, CW; /* MS = LDS bytes per env map (MS/4 odd), KP = K|1 LDS inventory stride, CW = candidate words */
+    int32_t perm_lds;            /* AddItem shuffle array: 1 = LDS at off_perm ([S2][32] u16, two half-wave batches), 0 = HBM scratch */
+    uint32_t off_perm;
     uint32_t magic;              /* ceil(2^32 / (S2/4)) (or / S2 for odd S): exact division of chunk offsets */
     uint32_t magicK;             /* ceil(2^32 / K): exact division of inventory chunk offsets (< 64*K) */
     uint32_t off_inv, off_cand, off_act;    /* LDS dword offsets */
@@ -62,9 +64,14 @@ struct NgwStepU {
 #define NGW_ACT_DW 5
 
 /* Blob kept in HBM (one per handle). */
+#define NGW_MAX_PLACE 64            /* items placed by one reset (sum of items_quantity); reference: 6-7 */
 struct NgwDevSpec {
     NgwStepU u;
+    /* --- the two tables below are contiguous: 256 dwords copied to LDS by every wavefront */
     uint32_t act_desc[NGW_MAX_ACTIONS * NGW_ACT_DW];
+    uint8_t place_seq[NGW_MAX_PLACE];   /* item id of the n-th placement of a reset (items_quantity flattened in order) */
+    /* --- */
+    int32_t n_place;
     ngw_spec sp;                 /* full spec: the (cold) reset path reads it with scalar loads */
     double addq[32];             /* AddItem: pct / 100.0 for pct in [pct_lo, pct_hi) as the host's IEEE double */
 };

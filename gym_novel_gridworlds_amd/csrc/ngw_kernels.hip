@@ -17,6 +17,7 @@
 //   gym_novel_gridworlds/envs/bow_v1_env.py        Extract_string :293-304, craft :386-441
 //   gym_novel_gridworlds/novelty_wrappers.py       AxeEasy :9-114, AxeMedium :117-213, AddItem :991-1034
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/ngw.h"
@@ -100,16 +101,37 @@ __device__ __forceinline__ int nth_set_bit(uint32_t x, int n) {
 // scalars of the hot step loop.  Returns flags | r<<8 | c<<16 | facing<<24.
 struct ResetArgs {
     const NgwDevSpec* dspec;
-    uint16_t* perm;
+    uint16_t* perm;                 // HBM scratch [S2][n_pad] (used when the shuffle array does not fit in LDS)
     int64_t n_pad;
     uint64_t seed;
-    int S, S2, K, CW;
+    int S, S2, K, CW, perm_lds;
 };
+
+// AddItem.reset (novelty_wrappers.py:1017-1028) on a shuffle array `perm` with element stride `ps`.
+template <typename P>
+__device__ __forceinline__ void additem_pass(P perm, int64_t ps, Philox& px, LDS_AS int8_t* mp, int S2, int agent, int item,
+                                             int pct_span, const GLOBAL_AS double* addq) {
+    int n_air = 0;
+    for (int i = 0; i < S2; i++)
+        if (mp[i] == 0) { perm[(int64_t)n_air * ps] = (uint16_t)i; n_air++; }       // np.where(map == 0), row-major
+    for (int i = n_air - 1; i >= 1; i--) {                                         // np.random.shuffle: Fisher-Yates from the top
+        const int j = (int)bounded(px, (uint32_t)i);
+        const uint16_t x = perm[(int64_t)i * ps], y = perm[(int64_t)j * ps];
+        perm[(int64_t)i * ps] = y; perm[(int64_t)j * ps] = x;
+    }
+    const int pct = (int)bounded(px, (uint32_t)(pct_span - 1));                    // randint(lo, hi)
+    const int cnt = (int)ceil((double)n_air * addq[pct]);                          // int(np.ceil(len * (pct / 100)))
+    for (int i = 0; i < cnt; i++) {
+        const int cell = perm[(int64_t)i * ps];
+        if (cell != agent) mp[cell] = (int8_t)item;                                // :1027 skips the agent cell
+    }
+}
 
 // (LDS / global pointers carry their address space: across a real call generic pointers would turn every access
 //  into a flat_* instruction)
 __device__ __noinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t* mp, LDS_AS int32_t* inv, LDS_AS uint32_t* cand,
-                                            uint64_t env_global, int64_t env_local, uint32_t episode) {
+                                            const LDS_AS uint8_t* place_seq, LDS_AS uint16_t* perm_lds, uint64_t env_global,
+                                            int64_t env_local, uint32_t episode) {
     const GLOBAL_AS ngw_spec& sp = *(const GLOBAL_AS ngw_spec*)&a.dspec->sp;
     const GLOBAL_AS double* addq = (const GLOBAL_AS double*)a.dspec->addq;
     int r_out, c_out, f_out;
@@ -132,44 +154,37 @@ __device__ __noinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t* mp
     const int agent = (2 + arow) * S + 2 + acol;
     r_out = 2 + arow; c_out = 2 + acol;
     f_out = (int)bounded(px, 3);                                                   // :145
-    for (int j = 0; j < sp.n_start; j++) {                                         // :147-148 insertion order
-        const int item = sp.start_item[j], want = sp.start_qty[j];
-        int count = 0;
-        while (count < want) {                                                     // add_item_to_map
-            if (len < 1) { flags |= NGW_F_PLACEMENT; break; }                     // :167
-            int idx = (int)bounded(px, (uint32_t)len - 1);                         // :169
-            int w = 0, pc;
-            while (idx >= (pc = __popc(cand[w * EPB]))) { idx -= pc; w++; }         // idx-th remaining, row-major
-            const int bit = nth_set_bit(cand[w * EPB], idx);
-            cand[w * EPB] &= ~(1u << bit);                                         // list.pop(idx)
-            len--;
-            const int pos = w * 32 + bit;
-            const int prow = (int)__umulhi((uint32_t)pos, magicW);
-            const int cell = (2 + prow) * S + 2 + (pos - prow * W);
-            if (cell != agent &&                                                   // :172-174
-                mp[cell] == 0 && mp[cell - S] == 0 && mp[cell + S] == 0 && mp[cell - 1] == 0 && mp[cell + 1] == 0) {
-                mp[cell] = (int8_t)item;                                           // :177-180
-                count++;
-            }
+    // :147-148 + add_item_to_map :159-181, FLATTENED: placement n takes item place_seq[n] (items_quantity in insertion
+    // order), so a wave iterates max-over-lanes of the TOTAL number of tries, not the sum of per-item maxima.
+    const int total = a.dspec->n_place;
+    int n = 0;
+    while (n < total) {
+        if (len < 1) { flags |= NGW_F_PLACEMENT; break; }                         // :167
+        int idx = (int)bounded(px, (uint32_t)len - 1);                             // :169
+        int w = 0, pc;
+        while (idx >= (pc = __popc(cand[w * EPB]))) { idx -= pc; w++; }             // idx-th remaining, row-major
+        const int bit = nth_set_bit(cand[w * EPB], idx);
+        cand[w * EPB] &= ~(1u << bit);                                             // list.pop(idx)
+        len--;
+        const int pos = w * 32 + bit;
+        const int prow = (int)__umulhi((uint32_t)pos, magicW);
+        const int cell = (2 + prow) * S + 2 + (pos - prow * W);
+        if (cell != agent &&                                                       // :172-174
+            mp[cell] == 0 && mp[cell - S] == 0 && mp[cell + S] == 0 && mp[cell - 1] == 0 && mp[cell + 1] == 0) {
+            mp[cell] = (int8_t)place_seq[n];                                       // :177-180
+            n++;
         }
-        if (flags) break;
     }
-    if (sp.additem_item && !flags) {                                               // AddItem.reset novelty_wrappers.py:1017-1028
-        GLOBAL_AS uint16_t* perm = (GLOBAL_AS uint16_t*)(a.perm + env_local);          // [S2][n_pad] scratch column
-        const int64_t ps = a.n_pad;
-        int n_air = 0;
-        for (int i = 0; i < a.S2; i++)
-            if (mp[i] == 0) { perm[(int64_t)n_air * ps] = (uint16_t)i; n_air++; }   // np.where(map == 0)
-        for (int i = n_air - 1; i >= 1; i--) {                                     // np.random.shuffle
-            int j = (int)bounded(px, (uint32_t)i);
-            uint16_t x = perm[(int64_t)i * ps], y = perm[(int64_t)j * ps];
-            perm[(int64_t)i * ps] = y; perm[(int64_t)j * ps] = x;
-        }
-        const int pct = (int)bounded(px, (uint32_t)(sp.additem_pct_hi - sp.additem_pct_lo - 1));   // randint(lo, hi)
-        const int cnt = (int)ceil((double)n_air * addq[pct]);                      // int(np.ceil(len * (pct / 100)))
-        for (int i = 0; i < cnt; i++) {
-            int cell = perm[(int64_t)i * ps];
-            if (cell != agent) mp[cell] = (int8_t)sp.additem_item;                 // :1027
+    if (sp.additem_item && !flags) {
+        const int span = sp.additem_pct_hi - sp.additem_pct_lo, item = sp.additem_item;
+        if (a.perm_lds) {
+            // shuffle array in LDS, [i][32 lanes] u16: the two halves of the wave take turns (a wave executes divergent
+            // halves one after the other and its LDS operations are in order, so they can share the region)
+            const int lane = threadIdx.x;
+            for (int half = 0; half < 2; half++)
+                if ((lane >> 5) == half) additem_pass(perm_lds + (lane & 31), 32, px, mp, a.S2, agent, item, span, addq);
+        } else {
+            additem_pass((GLOBAL_AS uint16_t*)(a.perm + env_local), a.n_pad, px, mp, a.S2, agent, item, span, addq);
         }
     }
     if (sp.inv_start_item && !flags) inv[sp.inv_start_item] = sp.inv_start_qty;         // AxeEasy.reset :33
@@ -322,8 +337,9 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     uint32_t* cand = lds_cand + tid;
 
     // ---- issue EVERY global load of the prologue before touching LDS: action table, first map round, scalars, inventory
-    constexpr int NACT = NGW_MAX_ACTIONS * NGW_ACT_DW;
-    static_assert(NACT <= 4 * EPB, "the action table is loaded with 4 dwords per lane");
+    constexpr int NACT = NGW_MAX_ACTIONS * NGW_ACT_DW + NGW_MAX_PLACE / 4;       // action descriptors + placement sequence
+    static_assert(NACT <= 4 * EPB, "the LUT block is loaded with 4 dwords per lane");
+    static_assert(offsetof(NgwDevSpec, place_seq) == offsetof(NgwDevSpec, act_desc) + NGW_MAX_ACTIONS * NGW_ACT_DW * 4, "LUT block is contiguous");
     uint32_t sv[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) sv[j] = dspec->act_desc[min(tid + EPB * j, NACT - 1)];
@@ -539,8 +555,10 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
             }
             if (do_reset) {                                                        // cold path, out of line
                 episode++;
-                const ResetArgs ra = {dspec, a.b.perm, a.n_pad, a.seed, S, a.S2, K, a.CW};
-                const uint32_t rr = reset_lane(ra, (LDS_AS int8_t*)mp, (LDS_AS int32_t*)inv, (LDS_AS uint32_t*)cand, env_global, e, episode);
+                const ResetArgs ra = {dspec, a.b.perm, a.n_pad, a.seed, S, a.S2, K, a.CW, a.perm_lds};
+                const uint32_t rr = reset_lane(ra, (LDS_AS int8_t*)mp, (LDS_AS int32_t*)inv, (LDS_AS uint32_t*)cand,
+                                               (const LDS_AS uint8_t*)(lds_act + NGW_MAX_ACTIONS * NGW_ACT_DW),
+                                               (LDS_AS uint16_t*)(lds + a.off_perm), env_global, e, episode);
                 flags |= rr & 0xFFu;
                 r = (int)((rr >> 8) & 0xFFu); c = (int)((rr >> 16) & 0xFFu); f = (int)(rr >> 24);
                 sel = 0; steps = 0;
