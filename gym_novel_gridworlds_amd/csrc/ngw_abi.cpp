@@ -527,6 +527,8 @@ int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stri
     if (e != hipSuccess) { drop_graph(h); return fail(NGW_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e)); }
     e = hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0);
     if (e != hipSuccess) { drop_graph(h); return fail(NGW_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+    (void)hipGraphUpload(h->graph_exec, h->stream);   // pre-stage the graph so the first replay does not pay for it
+    HIP_TRY(hipStreamSynchronize(h->stream));
     h->graph_steps = n_steps;
     return NGW_OK;
 }

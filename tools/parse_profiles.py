@@ -56,6 +56,10 @@ for mode in ('step', 'rollout'):
                    % (d[0], len(steps), st.median(steps), st.mean(steps), len(resets), ', '.join('%.1f' % x for x in resets),
                       len(normal), st.mean(normal), ', '.join('%.1f' % x for x in big), rows[1]['VGPR_Count'],
                       rows[1]['SGPR_Count'], rows[1]['Workgroup_Size_X'], rows[1]['Grid_Size_X']))
+        timed = steps[100:500]
+        out.append('')
+        out.append('The 400 TIMED launches only (after the 100 warm-up launches; this is what `bench.py` brackets with its HIP event pair): '
+                   'mean %.2f us, median %.2f us, max %.1f us.' % (st.mean(timed), st.median(timed), max(timed)))
     else:
         out.append('Per-dispatch: reset-all %.1f us; warm-up rollout (100 steps) %.1f us; timed rollout (400 steps) %.1f us = %.3f us per batched step.'
                    % (d[0], d[1], d[2], d[2] / 400))
