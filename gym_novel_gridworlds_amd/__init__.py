@@ -10,6 +10,7 @@ reference's gym.Env surface.  Everything computes in hand-written HIP kernels re
 from .envs import ENTRY_POINTS, BowV1Env, PogostickV1Env, make       # noqa: F401
 from .novelty import NOVELTY_NAMES, apply_novelty                    # noqa: F401
 from .novelty_wrappers import inject_novelty                         # noqa: F401
+from .observation_wrappers import LidarInFront                      # noqa: F401
 from .spec import ENV_IDS, STEP_COSTS, EnvSpec, make_spec            # noqa: F401
 from .vec_env import VecNovelGridworld                               # noqa: F401
 

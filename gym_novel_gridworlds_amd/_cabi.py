@@ -19,7 +19,8 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_set_autoreset', 'ngw_set_stream', 'ngw_reset', 'ngw_step', 'ngw_step_device', 'ngw_rollout',
            'ngw_get_obs', 'ngw_get_step_out', 'ngw_get_state', 'ngw_set_state', 'ngw_obs_device_ptrs',
            'ngw_out_device_ptrs', 'ngw_sync', 'ngw_error_flags', 'ngw_timing_begin', 'ngw_timing_end',
-           'ngw_graph_build', 'ngw_graph_launch']
+           'ngw_graph_build', 'ngw_graph_launch', 'ngw_lidar_configure', 'ngw_lidar', 'ngw_get_lidar',
+           'ngw_lidar_device_ptr']
 
 _lib = None
 
@@ -77,6 +78,10 @@ def lib():
     L.ngw_timing_end.argtypes = [vp, C.POINTER(C.c_double)]
     L.ngw_graph_build.argtypes = [vp, vp, i64, i32]
     L.ngw_graph_launch.argtypes = [vp, i32]
+    L.ngw_lidar_configure.argtypes = [vp, vp]
+    L.ngw_lidar.argtypes = [vp]
+    L.ngw_get_lidar.argtypes = [vp, vp]
+    L.ngw_lidar_device_ptr.argtypes = [vp, C.POINTER(vp)]
     if L.ngw_spec_size() != C.sizeof(NgwSpec):
         raise NgwError("ngw_spec layout mismatch: library %d bytes, binding %d bytes" % (L.ngw_spec_size(), C.sizeof(NgwSpec)))
     _lib = L

@@ -51,6 +51,12 @@ struct ngw_handle {
     uint8_t* mask_dev = nullptr;
     std::vector<void*> allocs;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing pair
+    // LidarInFront observation
+    ngw_lidar_cfg* lidar_cfg = nullptr;   // device copy
+    int32_t* lidar_out = nullptr;
+    int lidar_len = 0;
+    uint32_t lidar_magic = 0, lidar_off_tab = 0, lidar_off_tile = 0;
+    size_t lidar_lds = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_steps = 0;
@@ -490,6 +496,60 @@ int ngw_error_flags(ngw_handle* h, uint32_t* flags) {
     HIP_TRY(hipMemcpyAsync(flags, h->b.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemsetAsync(h->b.flags, 0, sizeof(uint32_t), h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return NGW_OK;
+}
+
+int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg) {
+    if (!h || !cfg) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    const int K = h->proto.K;
+    if (cfg->num_beams < 1 || cfg->num_beams > NGW_LIDAR_MAX_BEAMS || cfg->max_range < 1 || cfg->max_range > NGW_LIDAR_MAX_RANGE ||
+        cfg->n_chan < 1 || cfg->n_chan > NGW_MAX_ITEMS || cfg->n_inv < 0 || cfg->n_inv > NGW_MAX_ITEMS)
+        return fail(NGW_E_INVALID_ARG, "lidar configuration out of range");
+    for (int i = 0; i < NGW_MAX_ITEMS; i++)
+        if (cfg->chan_of_item[i] > cfg->n_chan || (i < cfg->n_inv && cfg->inv_item[i] >= K))
+            return fail(NGW_E_INVALID_ARG, "lidar item table out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int L = cfg->num_beams * cfg->n_chan + cfg->n_inv;
+    // LDS: maps | ray tables (2 x 4 KiB) | observation tile [64][L|1]
+    uint32_t off = (uint32_t)(NGW_EPB * h->proto.MS / 4);
+    off = (off + 3u) & ~3u;
+    const uint32_t off_tab = off; off += 2 * 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE / 4;
+    const uint32_t off_tile = off; off += (uint32_t)(NGW_EPB * (L | 1));
+    if ((size_t)off * 4 > 160 * 1024) return fail(NGW_E_INVALID_ARG, "lidar observation of %d values needs %zu B of LDS (> 160 KiB)", L, (size_t)off * 4);
+    if (!h->lidar_cfg) { if (int rc = dev_alloc(h, &h->lidar_cfg, 1)) return rc; }
+    if (L != h->lidar_len) { if (int rc = dev_alloc(h, &h->lidar_out, (size_t)h->n_pad * L)) return rc; }
+    HIP_TRY(hipMemcpyAsync(h->lidar_cfg, cfg, sizeof(*cfg), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->lidar_len = L;
+    h->lidar_magic = (uint32_t)((0x100000000ull + (uint32_t)L - 1) / (uint32_t)L);
+    h->lidar_off_tab = off_tab; h->lidar_off_tile = off_tile; h->lidar_lds = (size_t)off * 4;
+    return NGW_OK;
+}
+
+int ngw_lidar(ngw_handle* h) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (!h->lidar_len) return fail(NGW_E_INVALID_ARG, "ngw_lidar before ngw_lidar_configure");
+    HIP_TRY(hipSetDevice(h->device));
+    NgwLaunch a = h->proto;
+    a.b = h->b;
+    HIP_TRY(ngw_lidar_launch(h->lidar_cfg, &a, h->map_mode, h->lidar_out, h->lidar_len, h->lidar_magic, h->lidar_off_tab,
+                             h->lidar_off_tile, (unsigned)(h->n_pad / NGW_EPB), h->lidar_lds, h->stream));
+    return NGW_OK;
+}
+
+int ngw_get_lidar(ngw_handle* h, int32_t* out_host) {
+    if (!h || !out_host) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    if (!h->lidar_len) return fail(NGW_E_INVALID_ARG, "ngw_get_lidar before ngw_lidar_configure");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(out_host, h->lidar_out, (size_t)h->n * h->lidar_len * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NGW_OK;
+}
+
+int ngw_lidar_device_ptr(ngw_handle* h, void** out) {
+    if (!h || !out) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    *out = h->lidar_out;
     return NGW_OK;
 }
 

@@ -80,5 +80,10 @@ struct NgwDevSpec {
 extern "C"
 #endif
 hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, unsigned grid, size_t lds_bytes, hipStream_t stream);
+#ifdef __cplusplus
+extern "C"
+#endif
+hipError_t ngw_lidar_launch(const ngw_lidar_cfg* cfg, const NgwLaunch* a, int map_mode, int32_t* out, int L, uint32_t magicL,
+                            uint32_t off_tab, uint32_t off_tile, unsigned grid, size_t lds_bytes, hipStream_t stream);
 
 #endif

@@ -597,10 +597,122 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     if (flags) atomicOr(a.b.flags, flags);
 }
 
+// ---------------------------------------------------------------- LidarInFront observation kernel
+// observation_wrappers.py:32-80.  Same wave = 64 envs decomposition and the same coalesced map staging as the step
+// kernel; every lane marches its env's beams on the LDS map along the host-computed integer offsets (4 ranges per
+// round: one 8-byte table read + 4 independent cell reads), builds its observation row in an LDS tile with an odd
+// stride, and the wave then writes the tile out as one contiguous block of dwords.
+template <int MAPMODE>
+__global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const ngw_lidar_cfg* __restrict__ cfg, const NgwLaunch a,
+                                                             int32_t* __restrict__ out, int L, uint32_t magicL, uint32_t off_tab,
+                                                             uint32_t off_tile) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    const int64_t env0 = (int64_t)blockIdx.x * EPB;
+    const int64_t e = env0 + tid;
+    const bool live = e < a.n;
+    const int S = a.S, K = a.K, npieces = 4 * a.S2;
+    uint32_t* lds_map = lds;
+    // ray tables: dr | dc, 4096 bytes each, as 16-B pieces (8 per lane)
+    u32x4 tb[8];
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(cfg->dr);
+#pragma unroll
+        for (int j = 0; j < 8; j++) tb[j] = src[tid + EPB * j];
+    }
+    u32x4 buf[PB];
+    const u32x4* gin = reinterpret_cast<const u32x4*>(a.b.map + env0 * a.S2);
+    pieces_load(buf, gin, 0, npieces, tid);
+    int r = 1, c = 1, f = 0;
+    if (live) {
+        const int2 rc = reinterpret_cast<const int2*>(a.b.loc)[e];
+        r = rc.x; c = rc.y;
+        f = a.b.facing[e];
+    }
+    const int B = cfg->num_beams, R = cfg->max_range, NC = cfg->n_chan, NI = cfg->n_inv;
+    {
+        u32x4* dst = reinterpret_cast<u32x4*>(lds + off_tab);
+#pragma unroll
+        for (int j = 0; j < 8; j++) dst[tid + EPB * j] = tb[j];
+    }
+    pieces_lds<true, MAPMODE>(buf, a, lds_map, 0, npieces, tid);
+    for (int base = EPB * PB; base < npieces; base += EPB * PB) {
+        pieces_load(buf, gin, base, npieces, tid);
+        pieces_lds<true, MAPMODE>(buf, a, lds_map, base, npieces, tid);
+    }
+    __syncthreads();
+    const int8_t* mp = reinterpret_cast<const int8_t*>(lds_map) + tid * a.MS;
+    const int8_t* tdr = reinterpret_cast<const int8_t*>(lds + off_tab);
+    const int8_t* tdc = tdr + 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE;
+    const int LP = L | 1;
+    int32_t* row = reinterpret_cast<int32_t*>(lds + off_tile) + tid * LP;
+    for (int j = 0; j < L; j++) row[j] = 0;
+    if (live) {
+        for (int b = 0; b < B; b++) {
+            const int t0 = (f * NGW_LIDAR_MAX_BEAMS + b) * NGW_LIDAR_MAX_RANGE;
+            int hit_k = 0, hit_id = 0;
+            for (int k0 = 0; k0 < R && !hit_k; k0 += 4) {
+                const uint32_t d4 = *reinterpret_cast<const uint32_t*>(tdr + t0 + k0);       // 4 row offsets
+                const uint32_t c4 = *reinterpret_cast<const uint32_t*>(tdc + t0 + k0);       // 4 column offsets
+                int id[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int rr = min(max(r + (int)(int8_t)(d4 >> (8 * q)), 0), S - 1);
+                    const int cc = min(max(c + (int)(int8_t)(c4 >> (8 * q)), 0), S - 1);
+                    id[q] = mp[rr * S + cc];
+                }
+#pragma unroll
+                for (int q = 3; q >= 0; q--)
+                    if (k0 + q < R && id[q] != 0) { hit_k = k0 + q + 1; hit_id = id[q]; }     // first non-air block wins (:59-64)
+            }
+            if (hit_k) {
+                const int ch = cfg->chan_of_item[hit_id];
+                if (ch) row[b * NC + ch - 1] = hit_k;
+            }
+        }
+        const int32_t* gi = a.b.inv + e * K;
+        for (int j = 0; j < NI; j++) row[B * NC + j] = gi[cfg->inv_item[j]];                  // :74-75
+    }
+    __syncthreads();
+    // the wave's 64 rows are one contiguous block of 64 * L dwords in HBM
+    const int32_t* tile = reinterpret_cast<const int32_t*>(lds + off_tile);
+    int32_t* gout = out + env0 * L;
+    const int64_t total = (int64_t)min((int64_t)EPB, a.n - env0) * L;
+    for (int d = tid; d < total; d += EPB) {
+        const uint32_t ee = __umulhi((uint32_t)d, magicL);                                    // d / L
+        gout[d] = tile[ee * LP + (d - ee * L)];
+    }
+}
+
 }  // namespace
 
+extern "C" hipError_t ngw_lidar_launch(const ngw_lidar_cfg* cfg, const NgwLaunch* a, int map_mode, int32_t* out, int L,
+                                       uint32_t magicL, uint32_t off_tab, uint32_t off_tile, unsigned grid, size_t lds_bytes,
+                                       hipStream_t stream) {
+    const void* fn = map_mode == NGW_MAP_STRAIGHT ? reinterpret_cast<const void*>(ngw_lidar_kernel<NGW_MAP_STRAIGHT>)
+                     : map_mode == NGW_MAP_DWORD  ? reinterpret_cast<const void*>(ngw_lidar_kernel<NGW_MAP_DWORD>)
+                                                  : reinterpret_cast<const void*>(ngw_lidar_kernel<NGW_MAP_BYTE>);
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    switch (map_mode) {
+    case NGW_MAP_STRAIGHT:
+        hipLaunchKernelGGL(ngw_lidar_kernel<NGW_MAP_STRAIGHT>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, cfg, *a, out, L, magicL, off_tab, off_tile);
+        break;
+    case NGW_MAP_DWORD:
+        hipLaunchKernelGGL(ngw_lidar_kernel<NGW_MAP_DWORD>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, cfg, *a, out, L, magicL, off_tab, off_tile);
+        break;
+    default:
+        hipLaunchKernelGGL(ngw_lidar_kernel<NGW_MAP_BYTE>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, cfg, *a, out, L, magicL, off_tab, off_tile);
+    }
+    return hipGetLastError();
+}
+
+namespace {
+
 template <int MAPMODE, int MODE>
-static hipError_t launch_one(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
+hipError_t launch_one(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     // CDNA4 has 160 KiB of LDS per CU; anything above the 64 KiB default needs an explicit opt-in per device.
     static size_t lds_opt_in[64] = {0};
     int dev = 0;
@@ -628,6 +740,8 @@ static hipError_t launch_mode(const NgwDevSpec* dspec, const NgwLaunch* a, unsig
 }
 
 __global__ void ngw_nop_kernel(const NgwDevSpec* dspec, const NgwLaunch a) {}
+
+}  // namespace
 
 extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, unsigned grid, size_t lds_bytes,
                                  hipStream_t stream) {

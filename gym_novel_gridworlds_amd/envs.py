@@ -89,8 +89,18 @@ class _NovelGridworldEnv(_EnvBase):
         self._close_backend()
         return [seed]
 
-    def _backend(self):
+    def _sync_spec(self):
+        """The spec follows the env's public attributes (callers edit / rebind them, e.g. env.map_size = 16)."""
         sp = self._spec
+        sp.items, sp.items_id, sp.items_quantity, sp.entities = self.items, self.items_id, self.items_quantity, self.entities
+        sp.actions_id, sp.recipes, sp.unbreakable_items = self.actions_id, self.recipes, self.unbreakable_items
+        sp.goal_item_to_craft = self.goal_item_to_craft
+        sp.map_size = int(self.map_size)
+        sp.reward_intermediate, sp.reward_done = self.reward_intermediate, self.reward_done
+        return sp
+
+    def _backend(self):
+        sp = self._sync_spec()
         # callers may REBIND the public tables (env.items_quantity = {...}); the spec follows the env's attributes
         sp.items, sp.items_id, sp.items_quantity, sp.entities = self.items, self.items_id, self.items_quantity, self.entities
         sp.actions_id, sp.recipes, sp.unbreakable_items = self.actions_id, self.recipes, self.unbreakable_items

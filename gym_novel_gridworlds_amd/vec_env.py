@@ -176,6 +176,29 @@ class VecNovelGridworld:
                 'done': torch.as_tensor(_DevArray(p[1].value, (N,), '|u1'), device=dev),
                 'info': torch.as_tensor(_DevArray(p[2].value, (N,), '<i4'), device=dev)}
 
+    # ------------------------------------------------------------------ LidarInFront observation
+    def lidar_configure(self, lidar_config=None, num_beams=8):
+        """Enable the LidarInFront observation (reference observation_wrappers.py:10-80).  `lidar_config` fixes the lidar
+        item set at wrap time like the reference wrapper does; by default it is built from the current spec."""
+        from .lidar import LidarConfig
+        self.lidar = lidar_config if lidar_config is not None else LidarConfig(self.spec, num_beams)
+        self._lidar_c = self.lidar.compile(self.spec)
+        _cabi.check(_cabi.lib().ngw_lidar_configure(self._h, C.byref(self._lidar_c)))
+        self.lidar_len = self.lidar.obs_len(self.spec)
+        self._lidar_host = np.zeros((self.num_envs, self.lidar_len), np.int32)
+
+    def lidar_observation(self, device=False, copy=False):
+        """[N, num_beams * n_lidar_items + n_inventory] int32 observation of the current state (one kernel launch)."""
+        _cabi.check(_cabi.lib().ngw_lidar(self._h))
+        if device:
+            import torch
+            p = C.c_void_p()
+            _cabi.check(_cabi.lib().ngw_lidar_device_ptr(self._h, C.byref(p)))
+            self.sync()
+            return torch.as_tensor(_DevArray(p.value, (self.num_envs, self.lidar_len), '<i4'), device='cuda:%d' % self.device)
+        _cabi.check(_cabi.lib().ngw_get_lidar(self._h, _cabi._ptr(self._lidar_host, np.int32)))
+        return self._lidar_host.copy() if copy else self._lidar_host
+
     # ------------------------------------------------------------------ state (checkpoint / oracle injection)
     def get_state(self, first=0, count=None):
         count = self.num_envs - first if count is None else count

@@ -112,6 +112,24 @@ typedef struct ngw_spec {
     uint8_t _pad[1];
 } ngw_spec;
 
+/* LidarInFront observation (reference gym_novel_gridworlds/observation_wrappers.py:10-80): `num_beams` rays at equally
+ * spaced angles around the agent; per ray, the distance to the first non-air block, reported in the channel of that
+ * block's item (0 if the block is not a lidar item or nothing is hit within max_range), followed by the inventory of
+ * the breakable items in alphabetical order.  The host precomputes the integer ray offsets with the reference's own
+ * float arithmetic (np.round(np.cos(angle), 2), np.round(range * ratio)), so the GPU only marches integers. */
+#define NGW_LIDAR_MAX_BEAMS 16
+#define NGW_LIDAR_MAX_RANGE 64
+typedef struct ngw_lidar_cfg {
+    int32_t num_beams;                   /* LidarInFront(env, num_beams) */
+    int32_t max_range;                   /* int(sqrt(2 * (map_size - 2)^2)) at wrap time (observation_wrappers.py:25) */
+    int32_t n_chan;                      /* len(lidar_items) = items without air and the goal item (:21-24) */
+    int32_t n_inv;                       /* inventory entries appended (:74-75) */
+    uint8_t chan_of_item[NGW_MAX_ITEMS]; /* 1-based lidar channel of an item id, 0 = not a lidar item */
+    uint8_t inv_item[NGW_MAX_ITEMS];     /* item ids of the appended inventory, in sorted-name order */
+    int8_t dr[4][NGW_LIDAR_MAX_BEAMS][NGW_LIDAR_MAX_RANGE];   /* [facing][beam][range-1] row offset */
+    int8_t dc[4][NGW_LIDAR_MAX_BEAMS][NGW_LIDAR_MAX_RANGE];   /* column offset */
+} ngw_lidar_cfg;
+
 typedef struct ngw_handle ngw_handle;
 
 int ngw_abi_version(void);
@@ -181,6 +199,13 @@ int ngw_timing_end(ngw_handle* h, double* elapsed_ms);
  * Semantically identical to calling ngw_step_device n_steps * reps times with those action rows. */
 int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps);
 int ngw_graph_launch(ngw_handle* h, int32_t reps);
+
+/* LidarInFront: configure once, then ngw_lidar() computes the observation of the CURRENT state of every env into an
+ * int32 [N][num_beams * n_chan + n_inv] device buffer (enqueued on the handle's stream, after the steps before it). */
+int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg);
+int ngw_lidar(ngw_handle* h);
+int ngw_get_lidar(ngw_handle* h, int32_t* out_host);
+int ngw_lidar_device_ptr(ngw_handle* h, void** out);
 
 #ifdef __cplusplus
 }

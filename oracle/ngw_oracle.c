@@ -361,6 +361,31 @@ uint32_t ngwo_rollout_batch(const ngw_spec* sp, int64_t n, int32_t n_steps, int6
     return flags;
 }
 
+/* ------------------------------------------------------------------ LidarInFront observation */
+/* observation_wrappers.py:32-80: per beam march range 1..max_range along the host-computed integer offsets; the
+ * first non-air block stops the beam and, if it is a lidar item, stores the range in its channel; then the inventory. */
+void ngwo_lidar(const ngw_lidar_cfg* cf, int S, int K, int64_t n, const int8_t* map, const int32_t* loc, const int32_t* facing,
+                const int32_t* inv, int32_t* out) {
+    const int L = cf->num_beams * cf->n_chan + cf->n_inv;
+    for (int64_t i = 0; i < n; i++) {
+        const int8_t* m = map + i * S * S;
+        int32_t* o = out + i * L;
+        const int r = loc[2 * i], c = loc[2 * i + 1], f = facing[i];
+        for (int j = 0; j < L; j++) o[j] = 0;
+        for (int b = 0; b < cf->num_beams; b++)
+            for (int k = 1; k <= cf->max_range; k++) {                    /* :52 */
+                const int rr = r + cf->dr[f][b][k - 1], cc = c + cf->dc[f][b][k - 1];
+                const int id = m[rr * S + cc];                            /* :56 */
+                if (id != 0) {                                            /* :59-64 */
+                    if (cf->chan_of_item[id]) o[b * cf->n_chan + cf->chan_of_item[id] - 1] = k;
+                    break;
+                }
+            }
+        for (int j = 0; j < cf->n_inv; j++) o[cf->num_beams * cf->n_chan + j] = inv[i * K + cf->inv_item[j]];   /* :74-75 */
+    }
+}
+int ngwo_lidar_cfg_size(void) { return (int)sizeof(ngw_lidar_cfg); }
+
 #ifdef _OPENMP
 #include <omp.h>
 int ngwo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }

@@ -51,6 +51,7 @@ def lib():
         L.ngwo_rollout_batch.argtypes = [vp, C.c_int64, C.c_int32, C.c_int64, C.c_uint64] + st + \
             [u32p, i32p, u8p, u32p, C.c_int, C.c_int, C.c_uint64, C.c_int64]
         L.ngwo_rollout_batch.restype = C.c_uint32
+        L.ngwo_lidar.argtypes = [vp, C.c_int, C.c_int, C.c_int64, i8p, i32p, i32p, i32p, i32p]
         L.ngwo_set_threads.argtypes = [C.c_int]
         L.ngwo_set_threads.restype = C.c_int
         _lib = L
@@ -60,6 +61,16 @@ def lib():
 def set_threads(n):
     """OpenMP threads used by the batched drivers; returns the count in effect."""
     return lib().ngwo_set_threads(int(n))
+
+
+def lidar(ccfg, S, K, map_, loc, facing, inv):
+    """LidarInFront observation of n states (compiled NgwLidarCfg) -> int32 [n, L]."""
+    assert lib().ngwo_lidar_cfg_size() == C.sizeof(ccfg), "ngw_lidar_cfg layout mismatch"
+    n = len(facing)
+    out = np.zeros((n, ccfg.num_beams * ccfg.n_chan + ccfg.n_inv), np.int32)
+    lib().ngwo_lidar(C.byref(ccfg), S, K, n, np.ascontiguousarray(map_, np.int8).reshape(n, -1), np.ascontiguousarray(loc, np.int32),
+                     np.ascontiguousarray(facing, np.int32), np.ascontiguousarray(inv, np.int32), out)
+    return out
 
 
 class MT19937:

@@ -293,6 +293,16 @@ class OracleVec:
     def sync(self):
         pass
 
+    def lidar_configure(self, lidar_config=None, num_beams=8):
+        from gym_novel_gridworlds_amd.lidar import LidarConfig
+        self.lidar = lidar_config if lidar_config is not None else LidarConfig(self.spec, num_beams)
+        self._lidar_c = self.lidar.compile(self.spec)
+
+    def lidar_observation(self, device=False, copy=False):
+        from oracle.ngw_oracle import lidar
+        st = self.o.st
+        return lidar(self._lidar_c, self.spec.map_size, len(self.spec.items_id), st.map, st.loc, st.facing, st.inv)
+
     def device_observation(self):
         import torch
         st, S = self.o.st, self.spec.map_size

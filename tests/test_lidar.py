@@ -1,0 +1,139 @@
+"""LidarInFront observation: host tables + oracle against vectors captured from the reference
+(tests/golden/lidar.npz, generator gen_lidar.py); the HIP kernel against the same vectors in -m gpu."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import ngw_testlib as T
+from gym_novel_gridworlds_amd.lidar import LidarConfig
+from gym_novel_gridworlds_amd.novelty import apply_novelty
+from gym_novel_gridworlds_amd.spec import make_spec
+
+META = json.load(open(os.path.join(T.GOLDEN, 'lidar.json')))
+LIDAR = dict(np.load(os.path.join(T.GOLDEN, 'lidar.npz')))
+
+
+def lidar_setup(cfg):
+    """The reference order of tests/random_action.py:24-42: observation wrapper first, novelty injected on top."""
+    env_id, S, nov = T.CFGS[cfg]
+    spec = make_spec(env_id, S)
+    lc = LidarConfig(spec, META[cfg]['num_beams'])
+    if nov is not None:
+        apply_novelty(spec, *nov)
+    return spec, lc
+
+
+def post_states(cfg, n):
+    g = T.golden(cfg)
+    m = g['ss_pre_map'][:n].copy()
+    sel = g['ss_md_c'] < n
+    m[g['ss_md_c'][sel], g['ss_md_i'][sel]] = g['ss_md_v'][sel]
+    return m, g['ss_post_loc'][:n], g['ss_post_facing'][:n], g['ss_post_inv'][:n]
+
+
+@pytest.mark.parametrize('cfg', sorted(META))
+def test_lidar_tables_match_reference(cfg):
+    spec, lc = lidar_setup(cfg)
+    ref = META[cfg]
+    assert lc.lidar_items_id == ref['lidar_items_id'] and lc.max_beam_range == ref['max_beam_range']
+    assert lc.inventory_order(spec) == ref['inventory_order'] and lc.obs_len(spec) == ref['obs_len']
+    assert lc.num_beams * len(lc.lidar_items_id) + len(spec.items) - len(spec.unbreakable_items) == ref['obs_len']
+
+
+@pytest.mark.parametrize('cfg', sorted(META))
+def test_oracle_lidar_matches_reference(cfg):
+    from oracle.ngw_oracle import lidar
+    spec, lc = lidar_setup(cfg)
+    n = META[cfg]['n_cases']
+    m, loc, facing, inv = post_states(cfg, n)
+    got = lidar(lc.compile(spec), spec.map_size, len(spec.items_id), m, loc, facing, inv)
+    assert got.shape == LIDAR[cfg + '_obs'].shape
+    bad = np.nonzero((got != LIDAR[cfg + '_obs']).any(1))[0]
+    assert bad.size == 0, (cfg, bad[:5], got[bad[0]], LIDAR[cfg + '_obs'][bad[0]])
+    assert (got[:, :lc.num_beams * len(lc.lidar_items_id)] > 0).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cfg', sorted(META))
+def test_hip_lidar_matches_reference(cfg):
+    from gym_novel_gridworlds_amd import VecNovelGridworld
+    spec, lc = lidar_setup(cfg)
+    n = META[cfg]['n_cases']
+    m, loc, facing, inv = post_states(cfg, n)
+    v = VecNovelGridworld(spec=spec, num_envs=n)
+    v.set_state(0, map=m, loc=loc, facing=facing, inv=inv, selected=np.zeros(n, np.int32), step_count=np.zeros(n, np.int32))
+    v.lidar_configure(lc)
+    got = v.lidar_observation()
+    assert (got == LIDAR[cfg + '_obs']).all()
+    dev = v.lidar_observation(device=True)
+    assert (dev.cpu().numpy() == got).all()
+
+
+def _wrapped_env(cfg, backend):
+    import gym_novel_gridworlds_amd as G
+    env_id, S, nov = T.CFGS[cfg]
+    env = G.make(env_id)
+    if backend == 'oracle':
+        env._make_backend = lambda spec, seed_: T.OracleVec(spec, 1, seed=seed_)
+    env.seed(5)
+    env.map_size = S
+    env = G.LidarInFront(env, num_beams=META[cfg]['num_beams'])     # observation wrapper first ...
+    if nov is not None:
+        env = G.inject_novelty(env, *nov)                           # ... novelty on top (tests/random_action.py:24-42)
+    return env
+
+
+def _replay_wrapper(cfg, backend, n):
+    env = _wrapped_env(cfg, backend)
+    base = env.unwrapped if hasattr(env, 'unwrapped') else env
+    while hasattr(base, 'env') and not hasattr(base, '_spec'):
+        base = base.env
+    spec = base._spec
+    g = T.golden(cfg)
+    first = env.reset()
+    assert isinstance(first, np.ndarray) and first.shape == (META[cfg]['obs_len'],)
+    for c in range(n):
+        T.adapter_inject(base, spec, g['ss_pre_map'][c], g['ss_pre_loc'][c], g['ss_pre_facing'][c], g['ss_pre_sel'][c], g['ss_pre_inv'][c])
+        obs, reward, done, info = env.step(int(g['ss_action'][c]))
+        assert (obs == LIDAR[cfg + '_obs'][c]).all() and obs.dtype.kind == 'i', (cfg, c)
+        assert reward == g['ss_reward'][c] and info['message'] == T.messages()[g['ss_msg'][c]]
+    return n
+
+
+@pytest.mark.parametrize('cfg', ['pogo10', 'axe10', 'bowaxe16'])
+def test_lidar_wrapper_on_single_env_adapter(cfg):
+    """LidarInFront(env) + inject_novelty on the reference-shaped single env (oracle-backed stand-in backend)."""
+    assert _replay_wrapper(cfg, 'oracle', 300) == 300
+    env = _wrapped_env(cfg, 'oracle')
+    assert list(env.observation_space.shape) == META[cfg]['space_shape']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cfg', ['pogo10', 'axe10'])
+def test_lidar_wrapper_on_hip_backend(cfg):
+    assert _replay_wrapper(cfg, 'hip', 120) == 120
+
+
+@pytest.mark.gpu
+def test_lidar_wrapper_on_vec_env_follows_steps():
+    """Batched wrapper: observation after every step equals the oracle's lidar of the oracle's state."""
+    import gym_novel_gridworlds_amd as G
+    from oracle.ngw_oracle import Oracle, lidar
+    spec = T.build_spec('pogo10')
+    n = 3000
+    v = G.VecNovelGridworld(spec=spec, num_envs=n, seed=8, autoreset=True, horizon=20)
+    w = G.LidarInFront(v, num_beams=8)
+    o = Oracle(spec.compile(), n, seed=8, autoreset=True, horizon=20)
+    first = w.reset()
+    o.reset()
+    cc = w._lidar.compile(spec)
+    assert (first == lidar(cc, 10, 9, o.st.map, o.st.loc, o.st.facing, o.st.inv)).all()
+    rs = np.random.RandomState(1)
+    for t in range(45):
+        a = rs.randint(0, 17, size=n).astype(np.int32)
+        obs, reward, done, info = w.step(a)
+        o.step(a)
+        assert (obs == lidar(cc, 10, 9, o.st.map, o.st.loc, o.st.facing, o.st.inv)).all(), t
+        assert (reward == o.reward).all()
