@@ -52,10 +52,10 @@ struct ngw_handle {
     std::vector<void*> allocs;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing pair
     // LidarInFront observation
-    ngw_lidar_cfg* lidar_cfg = nullptr;   // device copy
+    NgwLidarDev* lidar_cfg = nullptr;     // device tables
     int32_t* lidar_out = nullptr;
     int lidar_len = 0;
-    uint32_t lidar_magic = 0, lidar_off_tab = 0, lidar_off_tile = 0;
+    uint32_t lidar_magic = 0, lidar_off_tab = 0, lidar_off_tile = 0, lidar_off_map = 0;
     size_t lidar_lds = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -511,19 +511,37 @@ int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     const int L = cfg->num_beams * cfg->n_chan + cfg->n_inv;
-    // LDS: maps | ray tables (2 x 4 KiB) | observation tile [64][L|1]
-    uint32_t off = (uint32_t)(NGW_EPB * h->proto.MS / 4);
+    // LDS: ray offset table (8 KiB) + item tables | observation tile [64][L] | guard | maps | guard.  After its hit a ray's
+    // remaining prefetched cells may fall outside the lane's own map: the guards keep those (ignored) reads inside the allocation.
+    const uint32_t guard = (uint32_t)((cfg->max_range * (h->proto.S + 1) + 15) / 16 * 4);        // dwords
+    uint32_t off = 0;
+    const uint32_t off_tab = off; off += 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE * 2 / 4 + 2 * NGW_MAX_ITEMS / 4;
     off = (off + 3u) & ~3u;
-    const uint32_t off_tab = off; off += 2 * 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE / 4;
-    const uint32_t off_tile = off; off += (uint32_t)(NGW_EPB * (L | 1));
+    const uint32_t off_tile = off; off += (uint32_t)(NGW_EPB * L);
+    off = ((off + 3u) & ~3u) + guard;
+    const uint32_t off_map = off; off += (uint32_t)(NGW_EPB * h->proto.MS / 4) + guard;
     if ((size_t)off * 4 > 160 * 1024) return fail(NGW_E_INVALID_ARG, "lidar observation of %d values needs %zu B of LDS (> 160 KiB)", L, (size_t)off * 4);
     if (!h->lidar_cfg) { if (int rc = dev_alloc(h, &h->lidar_cfg, 1)) return rc; }
     if (L != h->lidar_len) { if (int rc = dev_alloc(h, &h->lidar_out, (size_t)h->n_pad * L)) return rc; }
-    HIP_TRY(hipMemcpyAsync(h->lidar_cfg, cfg, sizeof(*cfg), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    {
+        static thread_local NgwLidarDev hd;
+        memset(&hd, 0, sizeof(hd));
+        const int S = h->proto.S;
+        for (int f = 0; f < 4; f++)
+            for (int b = 0; b < cfg->num_beams; b++)
+                for (int k = 0; k < NGW_LIDAR_MAX_RANGE; k++) {
+                    const int kk = k < cfg->max_range ? k : cfg->max_range - 1;      // pad: repeats the last in-range cell
+                    hd.off[f][b][k] = (int16_t)(cfg->dr[f][b][kk] * S + cfg->dc[f][b][kk]);
+                }
+        memcpy(hd.chan_of_item, cfg->chan_of_item, NGW_MAX_ITEMS);
+        memcpy(hd.inv_item, cfg->inv_item, NGW_MAX_ITEMS);
+        hd.num_beams = cfg->num_beams; hd.max_range = cfg->max_range; hd.n_chan = cfg->n_chan; hd.n_inv = cfg->n_inv;
+        HIP_TRY(hipMemcpyAsync(h->lidar_cfg, &hd, sizeof(hd), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
     h->lidar_len = L;
     h->lidar_magic = (uint32_t)((0x100000000ull + (uint32_t)L - 1) / (uint32_t)L);
-    h->lidar_off_tab = off_tab; h->lidar_off_tile = off_tile; h->lidar_lds = (size_t)off * 4;
+    h->lidar_off_tab = off_tab; h->lidar_off_tile = off_tile; h->lidar_off_map = off_map; h->lidar_lds = (size_t)off * 4;
     return NGW_OK;
 }
 
@@ -533,7 +551,7 @@ int ngw_lidar(ngw_handle* h) {
     HIP_TRY(hipSetDevice(h->device));
     NgwLaunch a = h->proto;
     a.b = h->b;
-    HIP_TRY(ngw_lidar_launch(h->lidar_cfg, &a, h->map_mode, h->lidar_out, h->lidar_len, h->lidar_magic, h->lidar_off_tab,
+    HIP_TRY(ngw_lidar_launch(h->lidar_cfg, &a, h->map_mode, h->lidar_out, h->lidar_len, h->lidar_off_map, h->lidar_off_tab,
                              h->lidar_off_tile, (unsigned)(h->n_pad / NGW_EPB), h->lidar_lds, h->stream));
     return NGW_OK;
 }

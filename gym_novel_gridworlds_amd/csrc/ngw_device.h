@@ -80,10 +80,18 @@ struct NgwDevSpec {
 extern "C"
 #endif
 hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, unsigned grid, size_t lds_bytes, hipStream_t stream);
+/* Device-side lidar tables, built by ngw_lidar_configure from ngw_lidar_cfg: flat cell offsets dr * S + dc. */
+struct NgwLidarDev {
+    int16_t off[4][NGW_LIDAR_MAX_BEAMS][NGW_LIDAR_MAX_RANGE];   /* [facing][beam][range-1], 8 KiB */
+    uint8_t chan_of_item[NGW_MAX_ITEMS];
+    uint8_t inv_item[NGW_MAX_ITEMS];
+    int32_t num_beams, max_range, n_chan, n_inv;
+};
+
 #ifdef __cplusplus
 extern "C"
 #endif
-hipError_t ngw_lidar_launch(const ngw_lidar_cfg* cfg, const NgwLaunch* a, int map_mode, int32_t* out, int L, uint32_t magicL,
+hipError_t ngw_lidar_launch(const NgwLidarDev* cfg, const NgwLaunch* a, int map_mode, int32_t* out, int L, uint32_t off_map,
                             uint32_t off_tab, uint32_t off_tile, unsigned grid, size_t lds_bytes, hipStream_t stream);
 
 #endif

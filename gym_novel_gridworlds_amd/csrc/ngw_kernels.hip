@@ -603,8 +603,8 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
 // round: one 8-byte table read + 4 independent cell reads), builds its observation row in an LDS tile with an odd
 // stride, and the wave then writes the tile out as one contiguous block of dwords.
 template <int MAPMODE>
-__global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const ngw_lidar_cfg* __restrict__ cfg, const NgwLaunch a,
-                                                             int32_t* __restrict__ out, int L, uint32_t magicL, uint32_t off_tab,
+__global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const NgwLidarDev* __restrict__ cfg, const NgwLaunch a,
+                                                             int32_t* __restrict__ out, int L, uint32_t off_map, uint32_t off_tab,
                                                              uint32_t off_tile) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
@@ -612,14 +612,19 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const ngw_lidar_cfg*
     const int64_t e = env0 + tid;
     const bool live = e < a.n;
     const int S = a.S, K = a.K, npieces = 4 * a.S2;
-    uint32_t* lds_map = lds;
-    // ray tables: dr | dc, 4096 bytes each, as 16-B pieces (8 per lane)
+    uint32_t* lds_map = lds + off_map;
+    // ray offset table (8 KiB = 512 pieces of 16 B, 8 per lane) + the two item tables right behind it
+    constexpr int TAB16 = 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE * 2 / 16;
+    static_assert(TAB16 == 8 * EPB, "ray table is 8 pieces per lane");
+    static_assert(offsetof(NgwLidarDev, chan_of_item) == 16 * TAB16 && offsetof(NgwLidarDev, inv_item) == 16 * TAB16 + NGW_MAX_ITEMS, "tables are contiguous");
     u32x4 tb[8];
     {
-        const u32x4* src = reinterpret_cast<const u32x4*>(cfg->dr);
+        const u32x4* src = reinterpret_cast<const u32x4*>(cfg->off);
 #pragma unroll
         for (int j = 0; j < 8; j++) tb[j] = src[tid + EPB * j];
     }
+    uint32_t it = 0;
+    if (tid < 2 * NGW_MAX_ITEMS / 4) it = reinterpret_cast<const uint32_t*>(cfg->chan_of_item)[tid];
     u32x4 buf[PB];
     const u32x4* gin = reinterpret_cast<const u32x4*>(a.b.map + env0 * a.S2);
     pieces_load(buf, gin, 0, npieces, tid);
@@ -634,6 +639,9 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const ngw_lidar_cfg*
         u32x4* dst = reinterpret_cast<u32x4*>(lds + off_tab);
 #pragma unroll
         for (int j = 0; j < 8; j++) dst[tid + EPB * j] = tb[j];
+        if (tid < 2 * NGW_MAX_ITEMS / 4) lds[off_tab + 4 * TAB16 + tid] = it;
+        u32x4* t4 = reinterpret_cast<u32x4*>(lds + off_tile);                        // zero the observation tile
+        for (int p = tid; p < 16 * L; p += EPB) t4[p] = u32x4{0u, 0u, 0u, 0u};
     }
     pieces_lds<true, MAPMODE>(buf, a, lds_map, 0, npieces, tid);
     for (int base = EPB * PB; base < npieces; base += EPB * PB) {
@@ -642,52 +650,72 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const ngw_lidar_cfg*
     }
     __syncthreads();
     const int8_t* mp = reinterpret_cast<const int8_t*>(lds_map) + tid * a.MS;
-    const int8_t* tdr = reinterpret_cast<const int8_t*>(lds + off_tab);
-    const int8_t* tdc = tdr + 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE;
-    const int LP = L | 1;
-    int32_t* row = reinterpret_cast<int32_t*>(lds + off_tile) + tid * LP;
-    for (int j = 0; j < L; j++) row[j] = 0;
+    const int16_t* toff = reinterpret_cast<const int16_t*>(lds + off_tab);
+    const uint8_t* chan_of_item = reinterpret_cast<const uint8_t*>(lds + off_tab + 4 * TAB16);
+    const uint8_t* inv_item = chan_of_item + NGW_MAX_ITEMS;
+    int32_t* row = reinterpret_cast<int32_t*>(lds + off_tile) + tid * L;
+    // inventory tail (:74-75): issue every (scattered, per-lane) global load NOW, all at once - their latency hides under
+    // the march; the values go into the tile afterwards.  A rolled loop here serialises NI dependent HBM round trips.
+    int32_t ivals[NGW_MAX_ITEMS];
     if (live) {
-        for (int b = 0; b < B; b++) {
-            const int t0 = (f * NGW_LIDAR_MAX_BEAMS + b) * NGW_LIDAR_MAX_RANGE;
-            int hit_k = 0, hit_id = 0;
-            for (int k0 = 0; k0 < R && !hit_k; k0 += 4) {
-                const uint32_t d4 = *reinterpret_cast<const uint32_t*>(tdr + t0 + k0);       // 4 row offsets
-                const uint32_t c4 = *reinterpret_cast<const uint32_t*>(tdc + t0 + k0);       // 4 column offsets
-                int id[4];
+        const int32_t* gi = a.b.inv + e * K;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int rr = min(max(r + (int)(int8_t)(d4 >> (8 * q)), 0), S - 1);
-                    const int cc = min(max(c + (int)(int8_t)(c4 >> (8 * q)), 0), S - 1);
-                    id[q] = mp[rr * S + cc];
+        for (int j = 0; j < NGW_MAX_ITEMS; j++) ivals[j] = (j < NI) ? gi[inv_item[j]] : 0;
+    }
+    if (live) {
+        // 4 beams x 4 ranges per round: 4 table reads (4 int16 offsets each), then 16 independent cell reads in flight.
+        // The march is an LDS latency chain; beams are independent, so they share each latency period.  A ray cannot
+        // leave the map before it hits the wall ring, so cells prefetched beyond the hit are simply ignored.
+        const int8_t* agent = mp + r * S + c;
+        for (int b0 = 0; b0 < B; b0 += 4) {
+            int hit_k[4] = {0, 0, 0, 0}, hit_id[4] = {0, 0, 0, 0};
+            for (int k0 = 0; k0 < R; k0 += 4) {
+                bool open = false;
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) open |= (b0 + bb < B) && !hit_k[bb];
+                if (!open) break;
+                uint2 o4[4];
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++)
+                    o4[bb] = *reinterpret_cast<const uint2*>(toff + (f * NGW_LIDAR_MAX_BEAMS + min(b0 + bb, B - 1)) * NGW_LIDAR_MAX_RANGE + k0);
+                int id[4][4];
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) {
+                    id[bb][0] = agent[(int16_t)(o4[bb].x & 0xFFFFu)];
+                    id[bb][1] = agent[(int16_t)(o4[bb].x >> 16)];
+                    id[bb][2] = agent[(int16_t)(o4[bb].y & 0xFFFFu)];
+                    id[bb][3] = agent[(int16_t)(o4[bb].y >> 16)];
                 }
 #pragma unroll
-                for (int q = 3; q >= 0; q--)
-                    if (k0 + q < R && id[q] != 0) { hit_k = k0 + q + 1; hit_id = id[q]; }     // first non-air block wins (:59-64)
+                for (int bb = 0; bb < 4; bb++)
+                    if (!hit_k[bb]) {
+#pragma unroll
+                        for (int q = 3; q >= 0; q--)
+                            if (k0 + q < R && id[bb][q] != 0) { hit_k[bb] = k0 + q + 1; hit_id[bb] = id[bb][q]; }   // first non-air block (:59-64)
+                    }
             }
-            if (hit_k) {
-                const int ch = cfg->chan_of_item[hit_id];
-                if (ch) row[b * NC + ch - 1] = hit_k;
-            }
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++)
+                if (b0 + bb < B && hit_k[bb]) {
+                    const int ch = chan_of_item[hit_id[bb]];
+                    if (ch) row[(b0 + bb) * NC + ch - 1] = hit_k[bb];
+                }
         }
-        const int32_t* gi = a.b.inv + e * K;
-        for (int j = 0; j < NI; j++) row[B * NC + j] = gi[cfg->inv_item[j]];                  // :74-75
+#pragma unroll
+        for (int j = 0; j < NGW_MAX_ITEMS; j++)
+            if (j < NI) row[B * NC + j] = ivals[j];
     }
     __syncthreads();
-    // the wave's 64 rows are one contiguous block of 64 * L dwords in HBM
-    const int32_t* tile = reinterpret_cast<const int32_t*>(lds + off_tile);
-    int32_t* gout = out + env0 * L;
-    const int64_t total = (int64_t)min((int64_t)EPB, a.n - env0) * L;
-    for (int d = tid; d < total; d += EPB) {
-        const uint32_t ee = __umulhi((uint32_t)d, magicL);                                    // d / L
-        gout[d] = tile[ee * LP + (d - ee * L)];
-    }
+    // the wave's 64 rows are one contiguous block of 64 * L dwords in HBM = 16 * L pieces of 16 B
+    const u32x4* t4 = reinterpret_cast<const u32x4*>(lds + off_tile);
+    u32x4* g4 = reinterpret_cast<u32x4*>(out + env0 * L);                          // out is padded to n_pad rows
+    for (int p = tid; p < 16 * L; p += EPB) g4[p] = t4[p];
 }
 
 }  // namespace
 
-extern "C" hipError_t ngw_lidar_launch(const ngw_lidar_cfg* cfg, const NgwLaunch* a, int map_mode, int32_t* out, int L,
-                                       uint32_t magicL, uint32_t off_tab, uint32_t off_tile, unsigned grid, size_t lds_bytes,
+extern "C" hipError_t ngw_lidar_launch(const NgwLidarDev* cfg, const NgwLaunch* a, int map_mode, int32_t* out, int L,
+                                       uint32_t off_map, uint32_t off_tab, uint32_t off_tile, unsigned grid, size_t lds_bytes,
                                        hipStream_t stream) {
     const void* fn = map_mode == NGW_MAP_STRAIGHT ? reinterpret_cast<const void*>(ngw_lidar_kernel<NGW_MAP_STRAIGHT>)
                      : map_mode == NGW_MAP_DWORD  ? reinterpret_cast<const void*>(ngw_lidar_kernel<NGW_MAP_DWORD>)
@@ -698,13 +726,13 @@ extern "C" hipError_t ngw_lidar_launch(const ngw_lidar_cfg* cfg, const NgwLaunch
     }
     switch (map_mode) {
     case NGW_MAP_STRAIGHT:
-        hipLaunchKernelGGL(ngw_lidar_kernel<NGW_MAP_STRAIGHT>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, cfg, *a, out, L, magicL, off_tab, off_tile);
+        hipLaunchKernelGGL(ngw_lidar_kernel<NGW_MAP_STRAIGHT>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, cfg, *a, out, L, off_map, off_tab, off_tile);
         break;
     case NGW_MAP_DWORD:
-        hipLaunchKernelGGL(ngw_lidar_kernel<NGW_MAP_DWORD>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, cfg, *a, out, L, magicL, off_tab, off_tile);
+        hipLaunchKernelGGL(ngw_lidar_kernel<NGW_MAP_DWORD>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, cfg, *a, out, L, off_map, off_tab, off_tile);
         break;
     default:
-        hipLaunchKernelGGL(ngw_lidar_kernel<NGW_MAP_BYTE>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, cfg, *a, out, L, magicL, off_tab, off_tile);
+        hipLaunchKernelGGL(ngw_lidar_kernel<NGW_MAP_BYTE>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, cfg, *a, out, L, off_map, off_tab, off_tile);
     }
     return hipGetLastError();
 }

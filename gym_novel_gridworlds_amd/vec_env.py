@@ -44,6 +44,9 @@ class VecNovelGridworld:
         self.items_id = dict(spec.items_id)
         self.actions_id = dict(spec.actions_id)
         self.single_action_space_n = spec.action_space_n
+        from . import spaces
+        self.action_space = spaces.Discrete(spec.action_space_n)           # per env; NOT grown by axe/additem
+        self.observation_space = spaces.Dict({'map': spaces.Box(low=0, high=spec.max_items, shape=(spec.map_size, spec.map_size, 1))})
         self._h = C.c_void_p()
         L = _cabi.lib()
         _cabi.check(L.ngw_create(C.byref(self.cspec), self.num_envs, self.device, self.seed, int(env_index_base),
