@@ -19,8 +19,8 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_set_autoreset', 'ngw_set_stream', 'ngw_reset', 'ngw_step', 'ngw_step_device', 'ngw_rollout',
            'ngw_get_obs', 'ngw_get_step_out', 'ngw_get_state', 'ngw_set_state', 'ngw_obs_device_ptrs',
            'ngw_out_device_ptrs', 'ngw_sync', 'ngw_error_flags', 'ngw_timing_begin', 'ngw_timing_end',
-           'ngw_graph_build', 'ngw_graph_launch', 'ngw_lidar_configure', 'ngw_lidar', 'ngw_get_lidar',
-           'ngw_lidar_device_ptr']
+           'ngw_graph_build', 'ngw_graph_launch', 'ngw_lidar_configure', 'ngw_lidar', 'ngw_lidar_fuse',
+           'ngw_get_lidar', 'ngw_lidar_device_ptr']
 
 _lib = None
 
@@ -80,6 +80,7 @@ def lib():
     L.ngw_graph_launch.argtypes = [vp, i32]
     L.ngw_lidar_configure.argtypes = [vp, vp]
     L.ngw_lidar.argtypes = [vp]
+    L.ngw_lidar_fuse.argtypes = [vp, C.c_int]
     L.ngw_get_lidar.argtypes = [vp, vp]
     L.ngw_lidar_device_ptr.argtypes = [vp, C.POINTER(vp)]
     if L.ngw_spec_size() != C.sizeof(NgwSpec):

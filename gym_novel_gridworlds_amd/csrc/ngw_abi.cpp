@@ -56,6 +56,7 @@ struct ngw_handle {
     int32_t* lidar_out = nullptr;
     int lidar_len = 0;
     uint32_t lidar_magic = 0, lidar_off_tab = 0, lidar_off_tile = 0, lidar_off_map = 0;
+    int lidar_fused = 0, lidar_range = 0, lidar_beams = 0, lidar_chan = 0, lidar_ninv = 0;
     size_t lidar_lds = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -123,6 +124,41 @@ int dev_alloc(ngw_handle* h, T** p, size_t count) {
     return NGW_OK;
 }
 
+// LDS carve-up of the step kernel (dword offsets).  With the lidar epilogue fused the maps sit behind a guard (ray
+// offsets prefetched beyond a hit may leave the lane's own map) and the ray table + observation tile follow the rest.
+int layout_lds(ngw_handle* h) {
+    NgwLaunch& p = h->proto;
+    const int S = p.S, S2 = p.S2;
+    const uint32_t guard = h->lidar_fused ? (uint32_t)((h->lidar_range * (S + 1) + 15) / 16 * 4) : 0u;
+    uint32_t off = guard;
+    p.off_map = off; off += (uint32_t)(NGW_EPB * p.MS / 4) + guard;
+    off = (off + 3u) & ~3u;
+    p.off_inv = off; off += (uint32_t)(p.KP * NGW_EPB);
+    p.off_cand = off; off += (uint32_t)(p.CW * NGW_EPB);
+    p.off_act = off; off += (uint32_t)(NGW_MAX_ACTIONS * NGW_ACT_DW + NGW_MAX_PLACE / 4);
+    p.perm_lds = 0; p.off_perm = off;
+    if (h->spec.additem_item) {
+        // Shuffle array in LDS only while the wave's LDS stays small (<= 32 KiB, 5 waves/CU).  Measured at S = 32: the
+        // extra 64 KiB halves the resident waves per CU and costs more (step 50 -> 115 us) than the HBM scratch column.
+        const uint32_t perm_dw = (uint32_t)(S2 * 32 * 2 / 4);
+        if ((size_t)(off + perm_dw) * 4 <= 32 * 1024) { p.perm_lds = 1; off += perm_dw; }
+    }
+    p.lcfg = nullptr; p.lout = nullptr; p.lidar_len = 0; p.off_ltab = p.off_ltile = 0;
+    if (h->lidar_fused) {
+        off = (off + 3u) & ~3u;
+        p.off_ltab = off; off += 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE * 2 / 4 + 2 * NGW_MAX_ITEMS / 4;
+        off = (off + 3u) & ~3u;
+        p.off_ltile = off; off += (uint32_t)(NGW_EPB * h->lidar_len);
+        p.lcfg = h->lidar_cfg; p.lout = h->lidar_out; p.lidar_len = h->lidar_len;
+        p.l_beams = h->lidar_beams; p.l_range = h->lidar_range; p.l_chan = h->lidar_chan; p.l_inv = h->lidar_ninv;
+    }
+    if ((size_t)off * 4 > 160 * 1024)
+        return fail(NGW_E_INVALID_ARG, "map_size %d%s needs %zu B of LDS per wavefront (> 160 KiB)", S,
+                    h->lidar_fused ? " with the fused lidar observation" : "", (size_t)off * 4);
+    h->lds_bytes = (size_t)off * 4;
+    return NGW_OK;
+}
+
 int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, const uint8_t* mask_dev, uint64_t action_seed, int64_t t0) {
     NgwLaunch a = h->proto;
     a.b = h->b;
@@ -135,7 +171,7 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     a.action_seed = action_seed;
     a.t0 = t0;
     const unsigned grid = (unsigned)(h->n_pad / NGW_EPB);
-    HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, grid, h->lds_bytes, h->stream));
+    HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, h->lidar_fused, grid, h->lds_bytes, h->stream));
     return NGW_OK;
 }
 
@@ -259,20 +295,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     const uint32_t div = ((S2 & 3) == 0) ? (uint32_t)(S2 / 4) : (uint32_t)S2;
     p.magic = (uint32_t)((0x100000000ull + div - 1) / div);
     p.CW = ((S - 4) * (S - 4) + 31) / 32;
-    uint32_t off = (uint32_t)(NGW_EPB * p.MS / 4);
-    off = (off + 3u) & ~3u;
-    p.off_inv = off; off += (uint32_t)(p.KP * NGW_EPB);
-    p.off_cand = off; off += (uint32_t)(p.CW * NGW_EPB);
-    p.off_act = off; off += (uint32_t)(NGW_MAX_ACTIONS * NGW_ACT_DW + NGW_MAX_PLACE / 4);
-    p.perm_lds = 0; p.off_perm = off;
-    if (spec->additem_item) {
-        // Shuffle array in LDS only while the wave's LDS stays small (<= 32 KiB, 5 waves/CU).  Measured at S = 32: the
-        // extra 64 KiB halves the resident waves per CU and costs more (step 50 -> 115 us) than the HBM scratch column.
-        const uint32_t perm_dw = (uint32_t)(S2 * 32 * 2 / 4);
-        if ((size_t)(off + perm_dw) * 4 <= 32 * 1024) { p.perm_lds = 1; off += perm_dw; }
-    }
-    h->lds_bytes = (size_t)off * 4;
-    if (h->lds_bytes > 160 * 1024) return bail(fail(NGW_E_INVALID_ARG, "map_size %d needs %zu B of LDS per wavefront (> 160 KiB)", S, h->lds_bytes));
+    if (int rc = layout_lds(h)) return bail(rc);
     if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(NGW_E_HIP, "stream sync failed after allocation"));
     *out = h;
     return NGW_OK;
@@ -540,8 +563,22 @@ int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg) {
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     h->lidar_len = L;
+    h->lidar_range = cfg->max_range; h->lidar_beams = cfg->num_beams; h->lidar_chan = cfg->n_chan; h->lidar_ninv = cfg->n_inv;
+    if (h->lidar_fused) { drop_graph(h); if (int rc = layout_lds(h)) { h->lidar_fused = 0; layout_lds(h); return rc; } }
     h->lidar_magic = (uint32_t)((0x100000000ull + (uint32_t)L - 1) / (uint32_t)L);
     h->lidar_off_tab = off_tab; h->lidar_off_tile = off_tile; h->lidar_off_map = off_map; h->lidar_lds = (size_t)off * 4;
+    return NGW_OK;
+}
+
+int ngw_lidar_fuse(ngw_handle* h, int enable) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (enable && !h->lidar_len) return fail(NGW_E_INVALID_ARG, "ngw_lidar_fuse before ngw_lidar_configure");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    drop_graph(h);                                   // captured launches bake the LDS layout in
+    const int before = h->lidar_fused;
+    h->lidar_fused = enable ? 1 : 0;
+    if (int rc = layout_lds(h)) { h->lidar_fused = before; layout_lds(h); return rc; }
     return NGW_OK;
 }
 

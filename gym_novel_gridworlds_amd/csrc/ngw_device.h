@@ -39,6 +39,12 @@ struct NgwLaunch {
     const uint8_t* reset_mask;   /* device or nullptr, NGW_MODE_RESET */
     int32_t mode, n_steps, autoreset, horizon;
     int32_t S, S2, MS, K, KP, CW; /* MS = LDS bytes per env map (MS/4 odd), KP = K|1 LDS inventory stride, CW = candidate words */
+    uint32_t off_map;            /* LDS dword offset of the maps (0, or a guard when the lidar epilogue is fused) */
+    /* fused LidarInFront epilogue (kernel template flag LIDAR) */
+    const struct NgwLidarDev* lcfg;
+    int32_t* lout;               /* [n_pad][lidar_len] */
+    int32_t lidar_len, l_beams, l_range, l_chan, l_inv;
+    uint32_t off_ltab, off_ltile;
     int32_t perm_lds;            /* AddItem shuffle array: 1 = LDS at off_perm ([S2][32] u16, two half-wave batches), 0 = HBM scratch */
     uint32_t off_perm;
     uint32_t magic;              /* ceil(2^32 / (S2/4)) (or / S2 for odd S): exact division of chunk offsets */
@@ -79,7 +85,8 @@ struct NgwDevSpec {
 #ifdef __cplusplus
 extern "C"
 #endif
-hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, unsigned grid, size_t lds_bytes, hipStream_t stream);
+hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int lidar, unsigned grid, size_t lds_bytes,
+                      hipStream_t stream);
 /* Device-side lidar tables, built by ngw_lidar_configure from ngw_lidar_cfg: flat cell offsets dr * S + dc. */
 struct NgwLidarDev {
     int16_t off[4][NGW_LIDAR_MAX_BEAMS][NGW_LIDAR_MAX_RANGE];   /* [facing][beam][range-1], 8 KiB */

@@ -311,11 +311,60 @@ __device__ __forceinline__ void inv_lds(u32x4 (&q)[IQ], const NgwLaunch& a, int3
     }
 }
 
+// ---------------------------------------------------------------- LidarInFront rays (shared by both kernels)
+// observation_wrappers.py:32-65 on the LDS map.  `agent` = this lane's agent cell; `toff` = flat int16 cell offsets
+// [facing][beam][range-1]; 4 beams x 4 ranges per round: 4 table reads (4 offsets each), then 16 independent cell reads
+// in flight - the march is an LDS latency chain and the beams are independent, so they share each latency period.
+// A ray cannot leave the map before it hits the wall ring, so cells prefetched beyond the hit are simply ignored
+// (the LDS layout keeps a guard on both sides of the maps for them).
+__device__ __forceinline__ void lidar_march(const int8_t* agent, int f, int B, int R, int NC, const int16_t* toff,
+                                            const uint8_t* chan_of_item, int32_t* row) {
+    for (int b0 = 0; b0 < B; b0 += 4) {
+        int hit_k[4] = {0, 0, 0, 0}, hit_id[4] = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < R; k0 += 4) {
+            bool open = false;
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++) open |= (b0 + bb < B) && !hit_k[bb];
+            if (!open) break;
+            uint2 o4[4];
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++)
+                o4[bb] = *reinterpret_cast<const uint2*>(toff + (f * NGW_LIDAR_MAX_BEAMS + min(b0 + bb, B - 1)) * NGW_LIDAR_MAX_RANGE + k0);
+            int id[4][4];
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++) {
+                id[bb][0] = agent[(int16_t)(o4[bb].x & 0xFFFFu)];
+                id[bb][1] = agent[(int16_t)(o4[bb].x >> 16)];
+                id[bb][2] = agent[(int16_t)(o4[bb].y & 0xFFFFu)];
+                id[bb][3] = agent[(int16_t)(o4[bb].y >> 16)];
+            }
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++)
+                if (!hit_k[bb]) {
+#pragma unroll
+                    for (int q = 3; q >= 0; q--)
+                        if (k0 + q < R && id[bb][q] != 0) { hit_k[bb] = k0 + q + 1; hit_id[bb] = id[bb][q]; }   // first non-air block (:59-64)
+                }
+        }
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++)
+            if (b0 + bb < B && hit_k[bb]) {
+                const int ch = chan_of_item[hit_id[bb]];
+                if (ch) row[(b0 + bb) * NC + ch - 1] = hit_k[bb];
+            }
+    }
+}
+
+constexpr int LIDAR_TAB16 = 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE * 2 / 16;     // ray table = 512 pieces of 16 B
+static_assert(LIDAR_TAB16 == 8 * NGW_EPB, "ray table is 8 pieces per lane");
+static_assert(offsetof(NgwLidarDev, chan_of_item) == 16 * LIDAR_TAB16 && offsetof(NgwLidarDev, inv_item) == 16 * LIDAR_TAB16 + NGW_MAX_ITEMS,
+              "lidar tables are contiguous");
+
 // ---------------------------------------------------------------- the kernel
 // LDS reads of the step are issued in TWO parallel levels (L0: action descriptor, block in front and its four
 // neighbours, the inventory slots whose item id is uniform; L1: the slots whose id comes out of L0) and the per-kind
 // bodies then work on registers only - the dependency chain of a step is two LDS latencies plus ALU, whatever the kind.
-template <int MAPMODE, int MODE>
+template <int MAPMODE, int MODE, bool LIDAR>
 __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restrict__ dspec, const NgwLaunch a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if (MODE == NGW_MODE_DBG_NOP) return;
@@ -327,7 +376,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     const int npieces = 4 * a.S2;                                                  // EPB * S2 / 16
 
     // LDS carve-up (dword offsets): maps | inventory [64][KP] | candidate masks [CW][64] | action descriptors
-    uint32_t* lds_map = lds;
+    uint32_t* lds_map = lds + a.off_map;
     int32_t* lds_inv = reinterpret_cast<int32_t*>(lds + a.off_inv);
     uint32_t* lds_cand = lds + a.off_cand;
     const uint32_t* lds_act = lds + a.off_act;
@@ -343,6 +392,14 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     uint32_t sv[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) sv[j] = dspec->act_desc[min(tid + EPB * j, NACT - 1)];
+    u32x4 ltb[LIDAR ? 8 : 1];                                                       // fused lidar: ray table + item tables
+    uint32_t lit = 0;
+    if (LIDAR) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.lcfg->off);
+#pragma unroll
+        for (int j = 0; j < 8; j++) ltb[j] = src[tid + EPB * j];
+        if (tid < 2 * NGW_MAX_ITEMS / 4) lit = reinterpret_cast<const uint32_t*>(a.lcfg->chan_of_item)[tid];
+    }
     u32x4 buf[PB];
     const u32x4* gin = reinterpret_cast<const u32x4*>(a.b.map + env0 * a.S2);
     pieces_load(buf, gin, 0, npieces, tid);
@@ -376,6 +433,12 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
         pieces_lds<true, MAPMODE>(buf, a, lds_map, base, npieces, tid);
     }
     inv_lds<true>(iq, a, lds_inv, tid);
+    if (LIDAR) {
+        u32x4* dst = reinterpret_cast<u32x4*>(lds + a.off_ltab);
+#pragma unroll
+        for (int j = 0; j < 8; j++) dst[tid + EPB * j] = ltb[j];
+        if (tid < 2 * NGW_MAX_ITEMS / 4) lds[a.off_ltab + 4 * LIDAR_TAB16 + tid] = lit;
+    }
     __syncthreads();
 
     uint32_t flags = 0;
@@ -395,6 +458,12 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     g_u8* gdone = (g_u8*)(a.b.done + e);
     g_u32* ginfo = (g_u32*)(a.b.info + e);
     PIN_V(gmap); PIN_V(ginv); PIN_V(gm); PIN_V(gi); PIN_V(gloc); PIN_V(gfac); PIN_V(grew); PIN_V(gdone); PIN_V(ginfo);
+    g_u32x4* glid = LIDAR ? (g_u32x4*)(reinterpret_cast<u32x4*>(a.lout + env0 * a.lidar_len)) : nullptr;
+    int lB = 0, lR = 0, lNC = 0, lNI = 0;
+    if (LIDAR) {
+        lB = a.l_beams; lR = a.l_range; lNC = a.l_chan; lNI = a.l_inv;
+        PIN_V(glid); PIN_S(lB); PIN_S(lR); PIN_S(lNC); PIN_S(lNI);
+    }
     constexpr int mode = MODE;
     int n_steps = (MODE == NGW_MODE_ROLLOUT) ? a.n_steps : 1, autoreset = a.autoreset, horizon = a.horizon;
     PIN_S(n_steps); PIN_S(autoreset); PIN_S(horizon);
@@ -588,6 +657,24 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                 *ginfo = info;
             }
         }
+        if (LIDAR) {
+            // ---- fused LidarInFront observation of the state this step produced (observation_wrappers.py:67-78)
+            const int L = a.lidar_len, LB = lB, LR = lR, LNC = lNC, LNI = lNI;
+            u32x4* t4 = reinterpret_cast<u32x4*>(lds + a.off_ltile);
+            __syncthreads();
+            for (int p = tid; p < 16 * L; p += EPB) t4[p] = u32x4{0u, 0u, 0u, 0u};
+            __syncthreads();
+            if (live) {
+                const int16_t* toff = reinterpret_cast<const int16_t*>(lds + a.off_ltab);
+                const uint8_t* chan_of_item = reinterpret_cast<const uint8_t*>(lds + a.off_ltab + 4 * LIDAR_TAB16);
+                const uint8_t* inv_item = chan_of_item + NGW_MAX_ITEMS;
+                int32_t* row = reinterpret_cast<int32_t*>(lds + a.off_ltile) + tid * L;
+                lidar_march(mp + r * S + c, f, LB, LR, LNC, toff, chan_of_item, row);
+                for (int j = 0; j < LNI; j++) row[LB * LNC + j] = inv[inv_item[j]];           // :74-75, inventory is in LDS
+            }
+            __syncthreads();
+            for (int p = tid; p < 16 * L; p += EPB) glid[p] = t4[p];
+        }
     }
     if (live) {
         a.b.selected[e] = (uint8_t)sel;
@@ -614,9 +701,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const NgwLidarDev* _
     const int S = a.S, K = a.K, npieces = 4 * a.S2;
     uint32_t* lds_map = lds + off_map;
     // ray offset table (8 KiB = 512 pieces of 16 B, 8 per lane) + the two item tables right behind it
-    constexpr int TAB16 = 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE * 2 / 16;
-    static_assert(TAB16 == 8 * EPB, "ray table is 8 pieces per lane");
-    static_assert(offsetof(NgwLidarDev, chan_of_item) == 16 * TAB16 && offsetof(NgwLidarDev, inv_item) == 16 * TAB16 + NGW_MAX_ITEMS, "tables are contiguous");
+    constexpr int TAB16 = LIDAR_TAB16;
     u32x4 tb[8];
     {
         const u32x4* src = reinterpret_cast<const u32x4*>(cfg->off);
@@ -663,44 +748,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const NgwLidarDev* _
         for (int j = 0; j < NGW_MAX_ITEMS; j++) ivals[j] = (j < NI) ? gi[inv_item[j]] : 0;
     }
     if (live) {
-        // 4 beams x 4 ranges per round: 4 table reads (4 int16 offsets each), then 16 independent cell reads in flight.
-        // The march is an LDS latency chain; beams are independent, so they share each latency period.  A ray cannot
-        // leave the map before it hits the wall ring, so cells prefetched beyond the hit are simply ignored.
-        const int8_t* agent = mp + r * S + c;
-        for (int b0 = 0; b0 < B; b0 += 4) {
-            int hit_k[4] = {0, 0, 0, 0}, hit_id[4] = {0, 0, 0, 0};
-            for (int k0 = 0; k0 < R; k0 += 4) {
-                bool open = false;
-#pragma unroll
-                for (int bb = 0; bb < 4; bb++) open |= (b0 + bb < B) && !hit_k[bb];
-                if (!open) break;
-                uint2 o4[4];
-#pragma unroll
-                for (int bb = 0; bb < 4; bb++)
-                    o4[bb] = *reinterpret_cast<const uint2*>(toff + (f * NGW_LIDAR_MAX_BEAMS + min(b0 + bb, B - 1)) * NGW_LIDAR_MAX_RANGE + k0);
-                int id[4][4];
-#pragma unroll
-                for (int bb = 0; bb < 4; bb++) {
-                    id[bb][0] = agent[(int16_t)(o4[bb].x & 0xFFFFu)];
-                    id[bb][1] = agent[(int16_t)(o4[bb].x >> 16)];
-                    id[bb][2] = agent[(int16_t)(o4[bb].y & 0xFFFFu)];
-                    id[bb][3] = agent[(int16_t)(o4[bb].y >> 16)];
-                }
-#pragma unroll
-                for (int bb = 0; bb < 4; bb++)
-                    if (!hit_k[bb]) {
-#pragma unroll
-                        for (int q = 3; q >= 0; q--)
-                            if (k0 + q < R && id[bb][q] != 0) { hit_k[bb] = k0 + q + 1; hit_id[bb] = id[bb][q]; }   // first non-air block (:59-64)
-                    }
-            }
-#pragma unroll
-            for (int bb = 0; bb < 4; bb++)
-                if (b0 + bb < B && hit_k[bb]) {
-                    const int ch = chan_of_item[hit_id[bb]];
-                    if (ch) row[(b0 + bb) * NC + ch - 1] = hit_k[bb];
-                }
-        }
+        lidar_march(mp + r * S + c, f, B, R, NC, toff, chan_of_item, row);
 #pragma unroll
         for (int j = 0; j < NGW_MAX_ITEMS; j++)
             if (j < NI) row[B * NC + j] = ivals[j];
@@ -739,7 +787,7 @@ extern "C" hipError_t ngw_lidar_launch(const NgwLidarDev* cfg, const NgwLaunch* 
 
 namespace {
 
-template <int MAPMODE, int MODE>
+template <int MAPMODE, int MODE, bool LIDAR>
 hipError_t launch_one(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     // CDNA4 has 160 KiB of LDS per CU; anything above the 64 KiB default needs an explicit opt-in per device.
     static size_t lds_opt_in[64] = {0};
@@ -747,23 +795,31 @@ hipError_t launch_one(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (lds_bytes > 64 * 1024 && dev < 64 && lds_bytes > lds_opt_in[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ngw_kernel<MAPMODE, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ngw_kernel<MAPMODE, MODE, LIDAR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes);
         if (e != hipSuccess) return e;
         lds_opt_in[dev] = lds_bytes;
     }
-    hipLaunchKernelGGL((ngw_kernel<MAPMODE, MODE>), dim3(grid), dim3(NGW_EPB), lds_bytes, stream, dspec, *a);
+    hipLaunchKernelGGL((ngw_kernel<MAPMODE, MODE, LIDAR>), dim3(grid), dim3(NGW_EPB), lds_bytes, stream, dspec, *a);
     return hipGetLastError();
 }
 
 template <int MAPMODE>
-static hipError_t launch_mode(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
+static hipError_t launch_mode(const NgwDevSpec* dspec, const NgwLaunch* a, int lidar, unsigned grid, size_t lds_bytes, hipStream_t stream) {
+    if (lidar) {
+        switch (a->mode) {
+        case NGW_MODE_STEP: return launch_one<MAPMODE, NGW_MODE_STEP, true>(dspec, a, grid, lds_bytes, stream);
+        case NGW_MODE_RESET: return launch_one<MAPMODE, NGW_MODE_RESET, true>(dspec, a, grid, lds_bytes, stream);
+        case NGW_MODE_ROLLOUT: return launch_one<MAPMODE, NGW_MODE_ROLLOUT, true>(dspec, a, grid, lds_bytes, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
     switch (a->mode) {
-    case NGW_MODE_STEP: return launch_one<MAPMODE, NGW_MODE_STEP>(dspec, a, grid, lds_bytes, stream);
-    case NGW_MODE_RESET: return launch_one<MAPMODE, NGW_MODE_RESET>(dspec, a, grid, lds_bytes, stream);
-    case NGW_MODE_ROLLOUT: return launch_one<MAPMODE, NGW_MODE_ROLLOUT>(dspec, a, grid, lds_bytes, stream);
-    case NGW_MODE_DBG_COPY: return launch_one<MAPMODE, NGW_MODE_DBG_COPY>(dspec, a, grid, lds_bytes, stream);
-    default: return launch_one<MAPMODE, NGW_MODE_DBG_NOP>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MODE_STEP: return launch_one<MAPMODE, NGW_MODE_STEP, false>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MODE_RESET: return launch_one<MAPMODE, NGW_MODE_RESET, false>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MODE_ROLLOUT: return launch_one<MAPMODE, NGW_MODE_ROLLOUT, false>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MODE_DBG_COPY: return launch_one<MAPMODE, NGW_MODE_DBG_COPY, false>(dspec, a, grid, lds_bytes, stream);
+    default: return launch_one<MAPMODE, NGW_MODE_DBG_NOP, false>(dspec, a, grid, lds_bytes, stream);
     }
 }
 
@@ -771,16 +827,16 @@ __global__ void ngw_nop_kernel(const NgwDevSpec* dspec, const NgwLaunch a) {}
 
 }  // namespace
 
-extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, unsigned grid, size_t lds_bytes,
-                                 hipStream_t stream) {
+extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int lidar, unsigned grid,
+                                 size_t lds_bytes, hipStream_t stream) {
     if (a->mode >= 10 && a->mode <= 12) {       // diagnostics: empty kernels with other workgroup shapes over the same lanes
         const unsigned tpb = a->mode == 10 ? 256 : (a->mode == 11 ? 1024 : 128);
         hipLaunchKernelGGL(ngw_nop_kernel, dim3(grid * NGW_EPB / tpb), dim3(tpb), a->mode == 12 ? lds_bytes * 2 : 0, stream, dspec, *a);
         return hipGetLastError();
     }
     switch (map_mode) {
-    case NGW_MAP_STRAIGHT: return launch_mode<NGW_MAP_STRAIGHT>(dspec, a, grid, lds_bytes, stream);
-    case NGW_MAP_DWORD: return launch_mode<NGW_MAP_DWORD>(dspec, a, grid, lds_bytes, stream);
-    default: return launch_mode<NGW_MAP_BYTE>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MAP_STRAIGHT: return launch_mode<NGW_MAP_STRAIGHT>(dspec, a, lidar, grid, lds_bytes, stream);
+    case NGW_MAP_DWORD: return launch_mode<NGW_MAP_DWORD>(dspec, a, lidar, grid, lds_bytes, stream);
+    default: return launch_mode<NGW_MAP_BYTE>(dspec, a, lidar, grid, lds_bytes, stream);
     }
 }

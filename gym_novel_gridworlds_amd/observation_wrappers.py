@@ -14,9 +14,10 @@ from .vec_env import VecNovelGridworld
 
 
 class LidarInFront(NoveltyWrapper):
-    def __init__(self, env, num_beams=8):
+    def __init__(self, env, num_beams=8, fused=True):
         super().__init__(env)
         self.num_beams = num_beams
+        self._fused = fused                                     # batched envs: compute the observation inside the step launch
         self._vec = env if isinstance(env, VecNovelGridworld) else None
         spec = env.spec if self._vec is not None else self._base()._sync_spec()
         self._lidar = LidarConfig(spec, num_beams)
@@ -43,7 +44,7 @@ class LidarInFront(NoveltyWrapper):
     def _ensure(self, vec):
         key = (id(vec), tuple(vec.spec.items_id.items()))
         if self._configured_for != key:
-            vec.lidar_configure(self._lidar)
+            vec.lidar_configure(self._lidar, fused=self._fused and vec is self._vec)
             self._configured_for = key
 
     def observation(self, obs=None):
@@ -58,9 +59,13 @@ class LidarInFront(NoveltyWrapper):
         return np.array([int(x) for x in vec.lidar_observation()[0]])
 
     def reset(self, **kwargs):
+        if self._vec is not None:
+            self._ensure(self._vec)                              # fused mode must be on before the launch it rides on
         self.env.reset(**kwargs)
         return self.observation()
 
     def step(self, action):
+        if self._vec is not None:
+            self._ensure(self._vec)
         _, reward, done, info = self.env.step(action)
         return self.observation(), reward, done, info

@@ -180,19 +180,24 @@ class VecNovelGridworld:
                 'info': torch.as_tensor(_DevArray(p[2].value, (N,), '<i4'), device=dev)}
 
     # ------------------------------------------------------------------ LidarInFront observation
-    def lidar_configure(self, lidar_config=None, num_beams=8):
+    def lidar_configure(self, lidar_config=None, num_beams=8, fused=False):
         """Enable the LidarInFront observation (reference observation_wrappers.py:10-80).  `lidar_config` fixes the lidar
-        item set at wrap time like the reference wrapper does; by default it is built from the current spec."""
+        item set at wrap time like the reference wrapper does; by default it is built from the current spec.
+        fused=True: every reset / step / rollout launch refreshes the observation in its own epilogue (no extra launch)."""
         from .lidar import LidarConfig
         self.lidar = lidar_config if lidar_config is not None else LidarConfig(self.spec, num_beams)
         self._lidar_c = self.lidar.compile(self.spec)
         _cabi.check(_cabi.lib().ngw_lidar_configure(self._h, C.byref(self._lidar_c)))
         self.lidar_len = self.lidar.obs_len(self.spec)
         self._lidar_host = np.zeros((self.num_envs, self.lidar_len), np.int32)
+        self.lidar_fused = bool(fused)
+        _cabi.check(_cabi.lib().ngw_lidar_fuse(self._h, int(self.lidar_fused)))
 
     def lidar_observation(self, device=False, copy=False):
-        """[N, num_beams * n_lidar_items + n_inventory] int32 observation of the current state (one kernel launch)."""
-        _cabi.check(_cabi.lib().ngw_lidar(self._h))
+        """[N, num_beams * n_lidar_items + n_inventory] int32 observation of the current state (one kernel launch, or
+        none in fused mode - then it is the observation the last reset / step launch produced)."""
+        if not self.lidar_fused:
+            _cabi.check(_cabi.lib().ngw_lidar(self._h))
         if device:
             import torch
             p = C.c_void_p()

@@ -204,6 +204,9 @@ int ngw_graph_launch(ngw_handle* h, int32_t reps);
  * int32 [N][num_beams * n_chan + n_inv] device buffer (enqueued on the handle's stream, after the steps before it). */
 int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg);
 int ngw_lidar(ngw_handle* h);
+/* enable = 1: every following reset / step / rollout launch also refreshes the lidar observation in its epilogue (the
+ * maps are already in LDS there), so ngw_lidar() is not needed; 0 restores the plain kernels. */
+int ngw_lidar_fuse(ngw_handle* h, int enable);
 int ngw_get_lidar(ngw_handle* h, int32_t* out_host);
 int ngw_lidar_device_ptr(ngw_handle* h, void** out);
 

@@ -137,3 +137,47 @@ def test_lidar_wrapper_on_vec_env_follows_steps():
         o.step(a)
         assert (obs == lidar(cc, 10, 9, o.st.map, o.st.loc, o.st.facing, o.st.inv)).all(), t
         assert (reward == o.reward).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cfg,n,steps', [('pogo10', 4000, 60), ('bow20', 700, 40), ('axe10', 2048, 60), ('add32', 128, 30)])
+def test_fused_lidar_epilogue_matches_oracle(cfg, n, steps):
+    """ngw_lidar_fuse: reset / step / rollout launches refresh the lidar observation themselves; it equals the oracle's
+    lidar of the oracle's state after every launch, and the plain state stays bit-exact too."""
+    import torch
+    import gym_novel_gridworlds_amd as G
+    from oracle.ngw_oracle import Oracle, lidar
+    spec, lc = lidar_setup(cfg)
+    A, S, K = len(spec.actions_id), spec.map_size, len(spec.items_id)
+    v = G.VecNovelGridworld(spec=spec, num_envs=n, seed=13, autoreset=True, horizon=17)
+    v.lidar_configure(lc, fused=True)
+    o = Oracle(spec.compile(), n, seed=13, autoreset=True, horizon=17)
+    cc = lc.compile(spec)
+
+    def check(where):
+        got = v.lidar_observation()
+        exp = lidar(cc, S, K, o.st.map, o.st.loc, o.st.facing, o.st.inv)
+        bad = np.nonzero((got != exp).any(1))[0]
+        assert bad.size == 0, (where, bad[:4])
+        st = v.get_state()
+        assert (st['map'] == o.st.map).all() and (st['inv'] == o.st.inv).all() and (st['loc'] == o.st.loc).all()
+
+    v.reset(); o.reset(); check('reset')
+    rs = np.random.RandomState(2)
+    for t in range(steps):
+        a = rs.randint(0, A, size=n).astype(np.int32)
+        v.step(a); o.step(a)
+        check('step %d' % t)
+    acts = torch.randint(0, A, (4, n), dtype=torch.int32, device='cuda')
+    torch.cuda.synchronize()
+    v.graph_build(acts.data_ptr(), n, 4); v.graph_launch(2)
+    an = acts.cpu().numpy()
+    for rep in range(2):
+        for t in range(4):
+            o.step(an[t])
+    check('graph')
+    v.rollout(23, action_seed=3, t0=5); o.rollout(23, 3, 5); check('rollout')
+    mask = (np.arange(n) % 2).astype(np.uint8)
+    v.reset(mask); o.reset(mask); check('masked reset')
+    v.lidar_configure(lc, fused=False)                     # back to the separate launch
+    v.step(an[0]); o.step(an[0]); check('unfused')
