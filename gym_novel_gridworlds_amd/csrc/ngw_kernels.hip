@@ -319,36 +319,49 @@ __device__ __forceinline__ void inv_lds(u32x4 (&q)[IQ], const NgwLaunch& a, int3
 // (the LDS layout keeps a guard on both sides of the maps for them).
 __device__ __forceinline__ void lidar_march(const int8_t* agent, int f, int B, int R, int NC, const int16_t* toff,
                                             const uint8_t* chan_of_item, int32_t* row) {
+    // 4 beams x 12 ranges per chunk: 12 table reads (4 int16 offsets each) and then 48 independent cell reads are in flight
+    // together, so a chunk costs two LDS latencies, not 2 x 12.  The ids of 4 consecutive ranges are packed into one
+    // dword; the first non-air block (:59-64) is its lowest non-zero byte (ffs).  No per-cell range test: beyond max_range
+    // the table repeats the last in-range cell, so a padded entry can never be the FIRST non-zero one.
+    const uint8_t* ag = reinterpret_cast<const uint8_t*>(agent);
     for (int b0 = 0; b0 < B; b0 += 4) {
         int hit_k[4] = {0, 0, 0, 0}, hit_id[4] = {0, 0, 0, 0};
-        for (int k0 = 0; k0 < R; k0 += 4) {
+        for (int k0 = 0; k0 < R; k0 += 12) {
             bool open = false;
 #pragma unroll
             for (int bb = 0; bb < 4; bb++) open |= (b0 + bb < B) && !hit_k[bb];
             if (!open) break;
-            uint2 o4[4];
-#pragma unroll
-            for (int bb = 0; bb < 4; bb++)
-                o4[bb] = *reinterpret_cast<const uint2*>(toff + (f * NGW_LIDAR_MAX_BEAMS + min(b0 + bb, B - 1)) * NGW_LIDAR_MAX_RANGE + k0);
-            int id[4][4];
+            uint2 o[4][3];
 #pragma unroll
             for (int bb = 0; bb < 4; bb++) {
-                id[bb][0] = agent[(int16_t)(o4[bb].x & 0xFFFFu)];
-                id[bb][1] = agent[(int16_t)(o4[bb].x >> 16)];
-                id[bb][2] = agent[(int16_t)(o4[bb].y & 0xFFFFu)];
-                id[bb][3] = agent[(int16_t)(o4[bb].y >> 16)];
+                const int16_t* t = toff + (f * NGW_LIDAR_MAX_BEAMS + min(b0 + bb, B - 1)) * NGW_LIDAR_MAX_RANGE + k0;
+#pragma unroll
+                for (int g = 0; g < 3; g++) o[bb][g] = *reinterpret_cast<const uint2*>(t + 4 * min(g, (NGW_LIDAR_MAX_RANGE - 1 - k0) / 4));
             }
+            uint32_t w[4][3];
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++)
+#pragma unroll
+                for (int g = 0; g < 3; g++) {
+                    const uint32_t i0 = ag[(int16_t)(o[bb][g].x & 0xFFFFu)], i1 = ag[(int16_t)(o[bb][g].x >> 16)];
+                    const uint32_t i2 = ag[(int16_t)(o[bb][g].y & 0xFFFFu)], i3 = ag[(int16_t)(o[bb][g].y >> 16)];
+                    w[bb][g] = i0 | (i1 << 8) | (i2 << 16) | (i3 << 24);
+                }
 #pragma unroll
             for (int bb = 0; bb < 4; bb++)
                 if (!hit_k[bb]) {
 #pragma unroll
-                    for (int q = 3; q >= 0; q--)
-                        if (k0 + q < R && id[bb][q] != 0) { hit_k[bb] = k0 + q + 1; hit_id[bb] = id[bb][q]; }   // first non-air block (:59-64)
+                    for (int g = 2; g >= 0; g--)
+                        if (w[bb][g]) {
+                            const int q = (__ffs((int)w[bb][g]) - 1) >> 3;                   // lowest non-zero byte
+                            hit_k[bb] = k0 + 4 * g + q + 1;
+                            hit_id[bb] = (int)((w[bb][g] >> (8 * q)) & 255u);
+                        }
                 }
         }
 #pragma unroll
         for (int bb = 0; bb < 4; bb++)
-            if (b0 + bb < B && hit_k[bb]) {
+            if (b0 + bb < B && hit_k[bb] && hit_k[bb] <= R) {
                 const int ch = chan_of_item[hit_id[bb]];
                 if (ch) row[(b0 + bb) * NC + ch - 1] = hit_k[bb];
             }
