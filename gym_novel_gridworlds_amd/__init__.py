@@ -13,6 +13,7 @@ from .novelty_wrappers import inject_novelty                         # noqa: F40
 from .observation_wrappers import LidarInFront                      # noqa: F401
 from .spec import ENV_IDS, STEP_COSTS, EnvSpec, make_spec            # noqa: F401
 from .vec_env import VecNovelGridworld                               # noqa: F401
+from .wrappers import LimitActions, limit_actions_vec                # noqa: F401
 
 __version__ = '0.1.0'
 

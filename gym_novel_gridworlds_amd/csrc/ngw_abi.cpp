@@ -96,6 +96,8 @@ int check_spec(const ngw_spec* s) {
     int total_place = 0;
     for (int j = 0; j < s->n_start; j++) total_place += s->start_qty[j];
     if (total_place > NGW_MAX_PLACE) return fail(NGW_E_INVALID_ARG, "items_quantity places %d items per reset (max %d)", total_place, NGW_MAX_PLACE);
+    for (int i = 0; i < K; i++)
+        if (s->breakable[i] && s->break_qty[i] != 1 && s->break_qty[i] != 2) return fail(NGW_E_INVALID_ARG, "break_qty must be 1 or 2");
     int brw = s->reward_step;
     for (int i = 0; i < K; i++)
         if (s->break_reward[i] != s->reward_step) {
@@ -248,6 +250,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
             if (spec->breakable[i]) u.brk_mask |= 1u << i;
             if (spec->entity[i]) u.ent_mask |= 1u << i;
             if (spec->break_reward[i] != spec->reward_step) { u.rew_mask |= 1u << i; u.break_reward = spec->break_reward[i]; }
+            if (spec->break_qty[i] == 2) u.brk2_mask |= 1u << i;
         }
         u.n_actions = spec->n_actions; u.reward_step = spec->reward_step; u.reward_done = spec->reward_done;
         u.craft_reward = spec->craft_reward;
@@ -259,6 +262,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
         u.ext_consume = spec->ext_consume; u.ext_cost_ok = spec->ext_cost_ok;
         u.axe_item = spec->axe_item; u.axe_cost = spec->axe_cost; u.axe_qty = spec->axe_qty;
         u.place_reward = spec->place_reward; u.ext_reward = spec->ext_reward; u.axe_reward = spec->axe_reward;
+        u.axe_required = spec->axe_required;
         for (int j = 0; j < spec->n_start; j++)
             for (int q = 0; q < spec->start_qty[j]; q++) hs.place_seq[hs.n_place++] = spec->start_item[j];
         for (int a = 0; a < spec->n_actions; a++) {

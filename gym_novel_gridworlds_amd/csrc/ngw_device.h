@@ -56,11 +56,13 @@ struct NgwLaunch {
  * from the HBM blob (no LDS latency in the step's dependency chain). */
 struct NgwStepU {
     uint32_t brk_mask, ent_mask, rew_mask;  /* bit i: item i is breakable / an entity / gives break_reward when broken */
+    uint32_t brk2_mask;                     /* bit i: breaking item i without an axe yields 2 (BreakIncrease) */
     int32_t n_actions, reward_step, reward_done, craft_reward, break_reward;
     uint8_t cost_forward, cost_turn, cost_break, cost_place, cost_extract, cost_select, table_item, goal_item;
     uint8_t place_item, place_near, n_entities, ext_src, ext_near, ext_out, ext_qty, ext_consume;
     uint8_t ext_cost_ok, axe_item, axe_cost, axe_qty;
-    int8_t place_reward, ext_reward, axe_reward, _pad;
+    int8_t place_reward, ext_reward, axe_reward;
+    uint8_t axe_required;                   /* AxetoBreak*: Break fails without the selected axe */
 };
 
 /* Per-action descriptor, NGW_ACT_DW dwords, copied to LDS (the only lane-varying LUT of the step):

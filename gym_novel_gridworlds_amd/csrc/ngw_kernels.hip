@@ -485,7 +485,8 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     uint64_t tt = (uint64_t)a.t0;
     PIN_S(key0); PIN_S(key1);
     // uniform step parameters, unpacked into scalars
-    uint32_t brk_mask = U.brk_mask, ent_mask = U.ent_mask, rew_mask = U.rew_mask;
+    uint32_t brk_mask = U.brk_mask, ent_mask = U.ent_mask, rew_mask = U.rew_mask, brk2_mask = U.brk2_mask;
+    int axe_required = U.axe_required;
     int n_actions = U.n_actions, reward_step = U.reward_step, reward_done = U.reward_done, craft_reward = U.craft_reward;
     int break_reward = U.break_reward;
     int cost_forward = U.cost_forward, cost_turn = U.cost_turn, cost_break = U.cost_break, cost_place = U.cost_place;
@@ -494,7 +495,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     int ext_near = U.ext_near, ext_out = U.ext_out, ext_qty = U.ext_qty, ext_consume = U.ext_consume;
     int ext_cost_ok = U.ext_cost_ok, axe_item = U.axe_item, axe_cost = U.axe_cost, axe_qty = U.axe_qty;
     int place_reward = U.place_reward, ext_reward = U.ext_reward, axe_reward = U.axe_reward;
-    PIN_S(brk_mask); PIN_S(ent_mask); PIN_S(rew_mask); PIN_S(n_actions); PIN_S(reward_step); PIN_S(reward_done);
+    PIN_S(brk_mask); PIN_S(ent_mask); PIN_S(rew_mask); PIN_S(brk2_mask); PIN_S(axe_required); PIN_S(n_actions); PIN_S(reward_step); PIN_S(reward_done);
     PIN_S(craft_reward); PIN_S(break_reward); PIN_S(cost_forward); PIN_S(cost_turn); PIN_S(cost_break); PIN_S(cost_place);
     PIN_S(cost_extract); PIN_S(cost_select); PIN_S(table_item); PIN_S(goal_item); PIN_S(place_item); PIN_S(place_near);
     PIN_S(n_entities); PIN_S(ext_src); PIN_S(ext_near); PIN_S(ext_out); PIN_S(ext_qty); PIN_S(ext_consume);
@@ -555,12 +556,17 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                     case NGW_ACT_BREAK:                                            // :280-294, axe: novelty_wrappers.py:144-183
                         cost = cost_break;
                         if ((brk_mask >> front) & 1u) {
-                            mp[fcell] = 0; gm[fcell] = 0;
-                            int nv = inv_front + 1;
-                            if (axe_item && inv_axe >= 1 && sel == axe_item) {
-                                nv = inv_front + axe_qty; rew = axe_reward; cost = axe_cost;
-                            } else if (!axe_item && ((rew_mask >> front) & 1u)) rew = break_reward;
-                            inv[front] = nv; gi[front] = nv;
+                            const bool axe_ok = axe_item && inv_axe >= 1 && sel == axe_item;
+                            if (!axe_ok && axe_required) {                         // AxetoBreak*: novelty_wrappers.py:589-591
+                                result = 0; msg = NGW_MSG_NEED_AXE; arg = axe_item;
+                            } else {
+                                mp[fcell] = 0; gm[fcell] = 0;
+                                int nv = inv_front + 1 + (int)((brk2_mask >> front) & 1u);    // 2 under BreakIncrease
+                                if (axe_ok) {
+                                    nv = inv_front + axe_qty; rew = axe_reward; cost = axe_cost;
+                                } else if (!axe_item && ((rew_mask >> front) & 1u)) rew = break_reward;
+                                inv[front] = nv; gi[front] = nv;
+                            }
                         } else { result = 0; msg = NGW_MSG_CANNOT_BREAK; arg = front; }
                         break;
                     case NGW_ACT_PLACE:                                            // :295-314

@@ -6,8 +6,10 @@ same AssertionError messages, then the same table edits the wrapper constructors
 AxeMedium.__init__ :125-134, AxeEasy.__init__ :16-27, AddItem.__init__ :996-1011 - applied to an
 `EnvSpec`, which is then recompiled into the kernel LUTs.
 
-In scope: 'axe' (easy / medium) and 'additem'.  The other eleven novelties are listed in
-SURVEY.md §8(f) as later rows; they validate like the reference and then raise NotImplementedError.
+In scope: SURVEY.md §8(a) 'axe' (easy / medium) and 'additem'; §8(f) row 2 (LUT-only novelties) 'breakincrease',
+'extractincdec', 'axetobreak' (easy / medium) and 'remapaction'.  The rest ('addchop', 'addjump', 'crate', 'fence',
+'fencerestriction', 'firewall', 'replaceitem', 'axe'/'axetobreak' hard) validate like the reference and then raise
+NotImplementedError.
 """
 
 NOVELTY_NAMES = ['addchop', 'additem', 'addjump', 'axe', 'axetobreak', 'breakincrease', 'crate', 'extractincdec',
@@ -38,6 +40,33 @@ def apply_novelty(spec, novelty_name, difficulty='hard', novelty_arg1='', novelt
             raise NotImplementedError("axe/hard (craftable axe, novelty_wrappers.py:216) is outside this build's "
                                       "hot-path scope (SURVEY.md §8(f) row 2)")
         _axe(spec, difficulty, novelty_arg1, breakincrease)
+    elif novelty_name == 'axetobreak':
+        assert novelty_arg1 in ['wooden', 'iron'], \
+            "For axe novelty, novelty_arg1 (attribute of axe, e.g. wooden, iron) is needed"             # :1623
+        if difficulty == 'hard':
+            raise NotImplementedError("axetobreak/hard (craftable axe, novelty_wrappers.py:627) is outside this build's "
+                                      "scope (SURVEY.md §8(f))")
+        _axe(spec, difficulty, novelty_arg1, 'false', required=True)
+    elif novelty_name == 'breakincrease':
+        if novelty_arg1 and novelty_arg1 not in spec.items:
+            # the reference's assert message dereferences env.itemtobreakmore, which does not exist (:1634, SURVEY
+            # appendix #11): what surfaces is this AttributeError, not an AssertionError
+            raise AttributeError("'%s' object has no attribute 'itemtobreakmore'" % spec.class_name)
+        spec.break_increase = novelty_arg1                         # BreakIncrease.__init__ :1421-1424 ('' = every block)
+    elif novelty_name == 'extractincdec':
+        assert novelty_arg1 in ['increase', 'decrease'], \
+            "For extractincdec novelty, novelty_arg1 ('increase', 'decrease') is needed"                # :1642
+        assert spec.env_id != 'NovelGridworld-Bow-v0', "There is nothing to extract in NovelGridworld-Bow-v0"
+        if spec.env_id == 'NovelGridworld-Bow-v1':
+            assert novelty_arg1 == 'decrease', "In NovelGridworld-Bow-v1, increasing string extraction will not benefit " \
+                                               "as only 3 string are needed"                          # :1648
+        assert not spec.env_id.startswith('NovelGridworld-Pogostick'), "In NovelGridworld-Pogostick, you should not use " \
+            "extractincdec novelty because rubber extraction cannot be decreased, and increasing rubber extraction will" \
+            " not benefit as only 1 rubber is needed"                                                  # :1651
+        # ExtractIncDec.step :1526-1530: 4 * 2 or 4 // 2 strings per wool; everything else as Extract_string
+        spec.extract['qty'] = spec.extract['qty'] * 2 if novelty_arg1 == 'increase' else spec.extract['qty'] // 2
+    elif novelty_name == 'remapaction':
+        _remap_action_difficulty(spec, difficulty)
     else:
         raise NotImplementedError("novelty %r is outside this build's hot-path scope (SURVEY.md §8(f))"
                                   % novelty_name)
@@ -45,7 +74,40 @@ def apply_novelty(spec, novelty_name, difficulty='hard', novelty_arg1='', novelt
     return spec
 
 
-def _axe(spec, difficulty, axe_material, breakincrease):
+def _remap_action(actions_id, start_action_id):
+    """Shuffle the action names with the GLOBAL numpy stream until the mapping changes (pogostick_v1_env.py:476-493),
+    so `np.random.seed(s); inject_novelty(env, 'remapaction', ...)` yields the reference's permutation."""
+    import numpy as np
+    while True:
+        actions = list(actions_id.keys())
+        np.random.shuffle(actions)
+        actions_id_new = {actions[i - start_action_id]: i for i in range(start_action_id, start_action_id + len(actions))}
+        if actions_id != actions_id_new:
+            actions_id = actions_id_new
+            print("New remapped actions: ", actions_id)
+            break
+    return actions_id
+
+
+def _remap_action_difficulty(spec, difficulty):
+    """remap_action_difficulty, novelty_wrappers.py:1203-1227 (the LimitActions branch lives in wrappers.LimitActions)."""
+    if difficulty == 'easy':
+        spec.manipulation_actions_id = _remap_action(spec.manipulation_actions_id, 0)
+        spec.actions_id.update(spec.manipulation_actions_id)
+    elif difficulty == 'medium':
+        spec.manipulation_actions_id = _remap_action(spec.manipulation_actions_id, 0)
+        spec.craft_actions_id = _remap_action(spec.craft_actions_id, len(spec.manipulation_actions_id))
+        spec.actions_id.update(spec.manipulation_actions_id)
+        spec.actions_id.update(spec.craft_actions_id)
+    else:
+        remapped = _remap_action(spec.actions_id, 0)
+        spec.actions_id.clear()
+        spec.actions_id.update(remapped)                           # keep the dict object: the env adapters alias it
+        spec.craft_actions_id = {a: spec.actions_id[a] for a in spec.actions_id if a.startswith('Craft')}
+        spec.select_actions_id = {a: spec.actions_id[a] for a in spec.actions_id if a.startswith('Select')}
+
+
+def _axe(spec, difficulty, axe_material, breakincrease, required=False):
     axe_name = axe_material + '_axe'                               # :128
     spec.add_new_item(axe_name)                                    # add_new_items / items_id.setdefault
     if difficulty == 'medium':
@@ -56,8 +118,10 @@ def _axe(spec, difficulty, axe_material, breakincrease):
     spec.add_select_action(axe_name)                               # :131-132 (action_space is NOT grown)
     # Break override :144-183: selected axe -> cost 3600*0.5 (wooden) / 3600*0.25 (iron), reward +10 for any block,
     # +2 blocks with breakincrease; without it a breakable block gives -1 even for tree_log.
+    # AxetoBreak* (required=True, :439-625): the same, but without the selected axe Break fails with
+    # 'Cannot break without <axe> selected'.
     spec.axe = dict(item=axe_name, cost=3600.0 * (0.5 if axe_material == 'wooden' else 0.25),
-                    qty=2 if breakincrease == 'true' else 1)
+                    qty=2 if breakincrease == 'true' else 1, required=required)
 
 
 def _add_item(spec, difficulty, item_to_add):

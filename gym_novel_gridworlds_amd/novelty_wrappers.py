@@ -52,6 +52,22 @@ class AxeMedium(NoveltyWrapper):
     pass
 
 
+class AxetoBreakEasy(NoveltyWrapper):
+    pass
+
+
+class AxetoBreakMedium(NoveltyWrapper):
+    pass
+
+
+class BreakIncrease(NoveltyWrapper):
+    pass
+
+
+class ExtractIncDec(NoveltyWrapper):
+    pass
+
+
 class AddItem(NoveltyWrapper):
     def reset(self):                                          # novelty_wrappers.py:1013 takes no kwargs
         return self.env.reset()
@@ -66,12 +82,32 @@ def inject_novelty(env, novelty_name, difficulty='hard', novelty_arg1='', novelt
                                  autoreset=env.autoreset, horizon=env.horizon)
     base = getattr(env, 'unwrapped', env)
     base = getattr(base, 'env', base) if isinstance(base, NoveltyWrapper) else base
-    spec = base._spec
+    spec = base._sync_spec()
+    if novelty_name == 'remapaction' and hasattr(env, 'limited_actions_id'):
+        # remap_action_difficulty with LimitActions in the stack: only the limited table is shuffled (:1209-1210)
+        assert difficulty in ['easy', 'medium', 'hard'], "difficulty must be one of 'easy', 'medium', 'hard'"
+        from .novelty import _remap_action
+        env.set_limited_actions_id(_remap_action(env.limited_actions_id, 0))
+        return env
     apply_novelty(spec, novelty_name, difficulty, novelty_arg1, novelty_arg2)     # validates like the reference
+    for name in ('manipulation_actions_id', 'craft_actions_id', 'select_actions_id'):
+        setattr(base, name, getattr(spec, name))                                  # remapaction re-binds these tables
     if novelty_name == 'axe':
         if difficulty == 'medium':
             base.reset()            # AxeMedium.__init__ -> add_new_items -> reset(): the axe appears on the map (:129)
             return AxeMedium(env)
         base.inventory_items_quantity.update({novelty_arg1 + '_axe': 1})          # AxeEasy.__init__ :22
         return AxeEasy(env)
+    if novelty_name == 'axetobreak':
+        if difficulty == 'medium':
+            base.reset()            # AxetoBreakMedium.__init__ -> add_new_items -> reset() (:551)
+            return AxetoBreakMedium(env)
+        base.inventory_items_quantity.update({novelty_arg1 + '_axe': 1})          # AxetoBreakEasy.__init__ :451
+        return AxetoBreakEasy(env)
+    if novelty_name == 'breakincrease':
+        return BreakIncrease(env)
+    if novelty_name == 'extractincdec':
+        return ExtractIncDec(env)
+    if novelty_name == 'remapaction':
+        return env                  # remap_action_difficulty returns the env itself (:1227)
     return AddItem(env)

@@ -34,7 +34,7 @@ def cost_code(value):
 
 ACT_FORWARD, ACT_LEFT, ACT_RIGHT, ACT_BREAK, ACT_PLACE, ACT_EXTRACT, ACT_CRAFT, ACT_SELECT = range(8)
 (MSG_NONE, MSG_BLOCK_IN_PATH, MSG_CANNOT_BREAK, MSG_PLACED, MSG_ALREADY_EXISTS, MSG_NOT_IN_INVENTORY,
- MSG_EXTRACT_NO_SRC, MSG_EXTRACT_NOT_NEAR, MSG_MISSING_ITEMS, MSG_NEED_TABLE, MSG_CRAFTED) = range(11)
+ MSG_EXTRACT_NO_SRC, MSG_EXTRACT_NOT_NEAR, MSG_MISSING_ITEMS, MSG_NEED_TABLE, MSG_CRAFTED, MSG_NEED_AXE) = range(12)
 
 F_INVALID_ACTION, F_PLACEMENT = 1, 2
 
@@ -50,7 +50,7 @@ class NgwSpec(C.Structure):
         ('craft_reward', C.c_int32),
         ('act_kind', C.c_uint8 * MAX_ACTIONS), ('act_arg', C.c_uint8 * MAX_ACTIONS),
         ('breakable', C.c_uint8 * MAX_ITEMS), ('entity', C.c_uint8 * MAX_ITEMS),
-        ('break_reward', C.c_int8 * MAX_ITEMS),
+        ('break_reward', C.c_int8 * MAX_ITEMS), ('break_qty', C.c_uint8 * MAX_ITEMS),
         ('wall_item', C.c_uint8), ('table_item', C.c_uint8), ('goal_item', C.c_uint8), ('n_entities', C.c_uint8),
         ('recipe_in', (C.c_uint8 * MAX_ITEMS) * MAX_RECIPES),
         ('recipe_n_in', C.c_uint8 * MAX_RECIPES),
@@ -65,6 +65,7 @@ class NgwSpec(C.Structure):
         ('ext_src', C.c_uint8), ('ext_near', C.c_uint8), ('ext_out', C.c_uint8), ('ext_qty', C.c_uint8),
         ('ext_consume', C.c_uint8), ('ext_cost_ok', C.c_uint8), ('ext_reward', C.c_int8),
         ('axe_item', C.c_uint8), ('axe_cost', C.c_uint8), ('axe_qty', C.c_uint8), ('axe_reward', C.c_int8),
+        ('axe_required', C.c_uint8), ('_pad2', C.c_uint8 * 3),
         ('n_start', C.c_uint8), ('start_item', C.c_uint8 * MAX_START), ('start_qty', C.c_uint8 * MAX_START),
         ('additem_item', C.c_uint8), ('additem_pct_lo', C.c_uint8), ('additem_pct_hi', C.c_uint8),
         ('inv_start_item', C.c_uint8), ('inv_start_qty', C.c_uint8),
@@ -129,6 +130,7 @@ class EnvSpec:
             raise KeyError("unknown env id %r (supported: %s)" % (env_id, ', '.join(ENV_IDS)))
         d = copy.deepcopy(_ENV_DEFS[env_id])
         self.env_id = env_id
+        self.class_name = {'NovelGridworld-Pogostick-v1': 'PogostickV1Env', 'NovelGridworld-Bow-v1': 'BowV1Env'}[env_id]
         self.map_size = int(map_size)
         self.items = set(d['items'])
         self.items_id = set_items_id(self.items)
@@ -153,7 +155,8 @@ class EnvSpec:
         self.action_space_n = len(self.actions_id)      # NOT grown by AxeMedium/AddItem
         self.max_items = 20
         # novelty state
-        self.axe = None            # dict(item=name, cost=float, qty=int) -> Break override
+        self.axe = None            # dict(item=name, cost=float, qty=int[, required=True]) -> Break override
+        self.break_increase = None # BreakIncrease: '' = every block gives 2, or the one item that does
         self.start_inventory = {}  # AxeEasy: item present in the inventory after every reset
         self.additem = None        # dict(item=name, pct=(lo, hi))
         self.novelties = []
@@ -226,7 +229,12 @@ class EnvSpec:
         for name, i in ids.items():
             s.breakable[i] = int(name not in self.unbreakable_items)
             s.entity[i] = int(name in self.entities)
-            s.break_reward[i] = self.reward_intermediate if name == 'tree_log' else -1
+            if self.break_increase is None:
+                s.break_reward[i] = self.reward_intermediate if name == 'tree_log' else -1       # pogostick_v1_env.py:288-289
+                s.break_qty[i] = 1
+            else:                                         # BreakIncrease.step, novelty_wrappers.py:1444-1456
+                s.break_reward[i] = self.reward_intermediate if name not in self.unbreakable_items else -1
+                s.break_qty[i] = 2 if self.break_increase in ('', name) else 1
         s.wall_item, s.table_item, s.goal_item = ids['wall'], ids['crafting_table'], ids[self.goal_item_to_craft]
         s.n_entities = len(self.entities)
         for r, name in enumerate(rnames):
@@ -255,6 +263,7 @@ class EnvSpec:
         if self.axe:
             s.axe_item, s.axe_cost, s.axe_qty = ids[self.axe['item']], cost_code(self.axe['cost']), self.axe['qty']
             s.axe_reward = self.reward_intermediate
+            s.axe_required = int(bool(self.axe.get('required')))
         s.n_start = len(self.items_quantity)
         for j, (item, q) in enumerate(self.items_quantity.items()):
             s.start_item[j], s.start_qty[j] = ids[item], q
@@ -293,6 +302,8 @@ class EnvSpec:
             return 'Need to be in front of crafting_table'                  # :452
         if code == MSG_CRAFTED:
             return 'Crafted ' + names[arg]                                  # :472
+        if code == MSG_NEED_AXE:
+            return "Cannot break without " + names[arg] + " selected"         # novelty_wrappers.py:591
         raise ValueError("unknown message code %d" % code)
 
     @staticmethod

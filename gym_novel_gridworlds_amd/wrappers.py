@@ -1,0 +1,51 @@
+"""`LimitActions` with the reference's call shape (gym_novel_gridworlds/wrappers.py:57-85).
+
+    env = LimitActions(env, {'Forward', 'Left', 'Right', 'Break', 'Craft_plank'})
+
+limited id i = the i-th name of sorted(limited_actions); `action_space` shrinks to Discrete(len(limited_actions)).
+On the single-env adapter it forwards like the reference wrapper (same AssertionError texts).  On a
+`VecNovelGridworld` it compiles the limited table INTO the kernel's action LUT (a new batched env whose action ids are
+the limited ids), so there is no per-step translation at all."""
+import copy
+
+import numpy as np
+
+from . import spaces
+from .novelty_wrappers import NoveltyWrapper
+from .vec_env import VecNovelGridworld
+
+
+class LimitActions(NoveltyWrapper):
+    def __init__(self, env, limited_actions):
+        super().__init__(env)
+        self.limited_actions = limited_actions
+        self.limited_actions_id = {action: i for i, action in enumerate(sorted(self.limited_actions))}   # wrappers.py:67
+        self.action_space = spaces.Discrete(len(self.limited_actions_id))
+
+    def set_limited_actions_id(self, limited_actions_id):
+        self.limited_actions_id = limited_actions_id
+
+    def step(self, action_id):
+        assert action_id in self.limited_actions_id.values(), "Action ID " + str(action_id) + " is not valid, max" \
+                                                              "action ID is " + str(len(self.limited_actions_id) - 1)
+        last_action = list(self.limited_actions_id.keys())[list(self.limited_actions_id.values()).index(action_id)]
+        assert last_action in self.actions_id, last_action + " is not a valid action for " + self.env_id
+        action_id = self.actions_id[last_action]
+        return self.env.step(action_id)
+
+
+def limit_actions_vec(venv, limited_actions):
+    """Batched form: a new VecNovelGridworld whose action ids ARE the limited ids (LUT edit, no translation pass)."""
+    assert isinstance(venv, VecNovelGridworld)
+    spec = copy.deepcopy(venv.spec)
+    limited = {action: i for i, action in enumerate(sorted(limited_actions))}
+    for action in limited:
+        assert action in spec.actions_id, action + " is not a valid action for " + spec.env_id
+    spec.actions_id.clear()
+    spec.actions_id.update(limited)
+    spec.manipulation_actions_id = {a: i for a, i in limited.items() if not a.startswith(('Craft_', 'Select_'))}
+    spec.craft_actions_id = {a: i for a, i in limited.items() if a.startswith('Craft_')}
+    spec.select_actions_id = {a: i for a, i in limited.items() if a.startswith('Select_')}
+    spec.action_space_n = len(limited)
+    return VecNovelGridworld(spec=spec, num_envs=venv.num_envs, device=venv.device, seed=venv.seed,
+                             autoreset=venv.autoreset, horizon=venv.horizon)

@@ -53,7 +53,8 @@ enum { NGW_MSG_NONE = 0, NGW_MSG_BLOCK_IN_PATH = 1, NGW_MSG_CANNOT_BREAK = 2 /* 
        NGW_MSG_PLACED = 3 /* arg = item */, NGW_MSG_ALREADY_EXISTS = 4 /* arg = front item */,
        NGW_MSG_NOT_IN_INVENTORY = 5, NGW_MSG_EXTRACT_NO_SRC = 6, NGW_MSG_EXTRACT_NOT_NEAR = 7,
        NGW_MSG_MISSING_ITEMS = 8 /* arg = recipe<<8 | mask over the recipe's inputs in dict order */,
-       NGW_MSG_NEED_TABLE = 9, NGW_MSG_CRAFTED = 10 /* arg = crafted item */ };
+       NGW_MSG_NEED_TABLE = 9, NGW_MSG_CRAFTED = 10 /* arg = crafted item */,
+       NGW_MSG_NEED_AXE = 11 /* arg = axe item: "Cannot break without <axe> selected" */ };
 
 /* packed per-env info word produced by the step kernel:
  *   bit 0 result | bit 1 done | bits 2..7 cost code | bits 8..15 message code | bits 16..31 message arg */
@@ -80,7 +81,8 @@ typedef struct ngw_spec {
     uint8_t act_arg[NGW_MAX_ACTIONS];
     uint8_t breakable[NGW_MAX_ITEMS];    /* item not in unbreakable_items (:41,:283) */
     uint8_t entity[NGW_MAX_ITEMS];       /* item in entities, picked up by grab_entities (:538-554) */
-    int8_t break_reward[NGW_MAX_ITEMS];  /* +10 for tree_log else -1 (:288-289) */
+    int8_t break_reward[NGW_MAX_ITEMS];  /* +10 for tree_log else -1 (:288-289); BreakIncrease: +10 for every block */
+    uint8_t break_qty[NGW_MAX_ITEMS];    /* blocks gained by Break without an axe: 1, or 2 (BreakIncrease, novelty_wrappers.py:1449-1454) */
     uint8_t wall_item, table_item, goal_item, n_entities;
     /* recipes (:56-59, craft :413-474) */
     uint8_t recipe_in[NGW_MAX_RECIPES][NGW_MAX_ITEMS];        /* required quantity per item id */
@@ -101,6 +103,8 @@ typedef struct ngw_spec {
     /* Break override of the axe novelties (novelty_wrappers.py:144-183); axe_item = 0 -> base Break */
     uint8_t axe_item, axe_cost, axe_qty;
     int8_t axe_reward;
+    uint8_t axe_required;                /* AxetoBreak*: Break fails without the selected axe (novelty_wrappers.py:589-591) */
+    uint8_t _pad2[3];
     /* reset (:86-157): items placed in insertion order of items_quantity */
     uint8_t n_start;
     uint8_t start_item[NGW_MAX_START_ITEMS];

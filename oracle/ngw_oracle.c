@@ -214,14 +214,18 @@ void ngwo_step(const ngw_spec* sp, int8_t* map, int32_t* loc, int32_t* facing, i
     case NGW_ACT_BREAK:                                           /* :280-294; axe: novelty_wrappers.py:144-183 */
         cost = sp->cost_break;
         if (sp->breakable[front]) {
-            map[fr * S + fc] = 0;
-            if (sp->axe_item && inv[sp->axe_item] >= 1 && *selected == sp->axe_item) {
+            const int axe_ok = sp->axe_item && inv[sp->axe_item] >= 1 && *selected == sp->axe_item;
+            if (axe_ok) {                                         /* axe held AND selected */
+                map[fr * S + fc] = 0;
                 inv[front] += sp->axe_qty;                        /* +2 with breakincrease */
                 reward = sp->axe_reward;                          /* +10 for ANY block */
                 cost = sp->axe_cost;                              /* 3600 * 0.5 / 0.25 */
+            } else if (sp->axe_required) {                        /* AxetoBreak*: novelty_wrappers.py:589-591 */
+                result = 0; msg = NGW_MSG_NEED_AXE; arg = sp->axe_item;
             } else {
-                inv[front] += 1;
-                if (!sp->axe_item) reward = sp->break_reward[front];   /* base env: +10 iff tree_log; axe env: stays -1 */
+                map[fr * S + fc] = 0;
+                inv[front] += sp->break_qty[front];               /* 1, or 2 under BreakIncrease */
+                if (!sp->axe_item) reward = sp->break_reward[front];   /* base: +10 iff tree_log; Axe env: stays -1 */
             }
         } else { result = 0; msg = NGW_MSG_CANNOT_BREAK; arg = front; }
         break;

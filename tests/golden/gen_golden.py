@@ -50,7 +50,17 @@ CFGS = {
     'add11e':   (POGO, 11, ('additem', 'easy', 'arrow', '')),
     'bowaxe16': (BOW, 16, ('axe', 'medium', 'wooden', 'false')),
     'axeeasy10': (POGO, 10, ('axe', 'easy', 'wooden', '')),         # AxeEasy: the axe starts in the inventory
+    # LUT-only novelties
+    'brkinc10':    (POGO, 10, ('breakincrease', 'hard', '', '')),
+    'brkinclog12': (POGO, 12, ('breakincrease', 'hard', 'tree_log', '')),
+    'extdec10':    (BOW, 10, ('extractincdec', 'hard', 'decrease', '')),
+    'axetbe10':    (POGO, 10, ('axetobreak', 'easy', 'wooden', '')),
+    'axetbm12':    (BOW, 12, ('axetobreak', 'medium', 'iron', '')),
+    'remape10':    (POGO, 10, ('remapaction', 'easy', '', '')),
+    'remapm10':    (BOW, 10, ('remapaction', 'medium', '', '')),
+    'remaph10':    (POGO, 10, ('remapaction', 'hard', '', '')),
 }
+REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13}      # np.random.seed right before inject_novelty
 DIRS = ['NORTH', 'SOUTH', 'WEST', 'EAST']
 
 
@@ -59,6 +69,8 @@ def make_env(cfg):
     env = gym.make(env_id)
     env.map_size = S            # on the BASE env, before wrapping
     if nov is not None:
+        if cfg in REMAP_SEED:
+            np.random.seed(REMAP_SEED[cfg])     # remapaction shuffles with the global stream at injection time
         env = inject_novelty(env, *nov)
     return env
 
@@ -142,6 +154,23 @@ def novelty_arg_errors():
     return out
 
 
+def novelty_arg_errors2():
+    """(env id, args) -> exception, for the row-2 novelties."""
+    cases = [(POGO, ('breakincrease', 'hard', 'unobtainium', '')), (POGO, ('extractincdec', 'hard', '', '')),
+             (POGO, ('extractincdec', 'hard', 'increase', '')), (BOW, ('extractincdec', 'hard', 'increase', '')),
+             (BOW, ('extractincdec', 'hard', 'sideways', '')), (POGO, ('axetobreak', 'easy', 'gold', '')),
+             (POGO, ('axetobreak', 'nope', 'wooden', '')), (POGO, ('remapaction', 'nope', '', ''))]
+    out = []
+    for env_id, c in cases:
+        env = gym.make(env_id)
+        try:
+            inject_novelty(env, *c)
+            out.append([env_id, list(c), None, None])
+        except Exception as e:  # noqa: BLE001
+            out.append([env_id, list(c), type(e).__name__, str(e)])
+    return out
+
+
 def exhaustion_cases():
     out = []
     for env_id in (POGO, BOW):
@@ -170,7 +199,7 @@ def gen_resets(cfg, nseeds, out):
         for _ in range(3):
             env.reset()
             m, loc, f, sel, inv = snap(base)
-            assert sel == 0 and (not inv.any() or cfg == 'axeeasy10')
+            assert sel == 0 and (not inv.any() or cfg in ('axeeasy10', 'axetbe10'))
             maps.append(m), locs.append(loc), facs.append(f), invs.append(inv)
         words.append(next_word())
     out['rs_map'] = np.array(maps, np.int8).reshape(nseeds, 3, -1)
@@ -514,12 +543,60 @@ def gen_c1loop(nseeds, out, strings):
         out[p + 'next_word'] = np.array([next_word()], np.uint32)
 
 
+# ---------------------------------------------------------------- LimitActions (wrappers.py:57-85), with and without remapaction on top
+LIMITED = ['Forward', 'Left', 'Right', 'Break', 'Craft_plank', 'Craft_stick', 'Select_tree_log']
+
+
+def gen_limit(out, strings, spec):
+    from gym_novel_gridworlds.wrappers import LimitActions
+    meta = {}
+    for name, remap_seed in (('plain', None), ('remapped', 21)):
+        env = gym.make(POGO)
+        env = LimitActions(env, set(LIMITED))
+        if remap_seed is not None:
+            np.random.seed(remap_seed)
+            env = inject_novelty(env, 'remapaction', 'hard')
+        base = env.unwrapped
+        np.random.seed(77)
+        env.reset()
+        m0, l0, f0, _, _ = snap(base)
+        rs = np.random.RandomState(5)
+        rows = []
+        n = len(env.limited_actions_id)
+        for t in range(600):
+            if t % 50 == 49:
+                base.inventory_items_quantity['tree_log'] += 2
+                base.inventory_items_quantity['plank'] += 2
+            a = int(rs.randint(n))
+            _, r, d, info = env.step(a)
+            m, l, f, s, iv = snap(base)
+            c, ci = cost_pair(info['step_cost'])
+            rows.append((a, r, d, info['result'], c, ci, strings(info['message']), l, f, s, iv, zlib.crc32(m.tobytes())))
+        p = 'lim_%s_' % name
+        out[p + 'map0'], out[p + 'loc0'], out[p + 'facing0'] = m0, l0, f0
+        for j, key in enumerate(['action', 'reward', 'done', 'result', 'cost', 'cost_is_int', 'msg', 'loc', 'facing', 'sel', 'inv', 'crc']):
+            out[p + key] = np.array([r[j] for r in rows])
+        errs = []
+        for a in (n, -1):
+            try:
+                env.step(a)
+                errs.append([a, None, None])
+            except Exception as e:  # noqa: BLE001
+                errs.append([a, type(e).__name__, str(e)])
+        meta[name] = {'limited_actions_id': {k: int(v) for k, v in env.limited_actions_id.items()},
+                      'action_space_n': int(env.action_space.n), 'errors': errs}
+    spec['limit_actions'] = meta
+
+
 # ---------------------------------------------------------------- main
 PLAN = {  # cfg: (reset seeds, traces, steps per trace, single-step cases, solved episodes)
     'pogo10': (48, 6, 1600, 6000, 4), 'bow20': (32, 4, 1600, 3000, 3), 'axe10': (48, 6, 1600, 6000, 4),
     'add32': (24, 3, 1200, 500, 0), 'pogo13': (16, 2, 1000, 1500, 2), 'bow10': (16, 2, 1000, 3000, 2),
     'axe12bi': (16, 3, 1200, 4000, 3), 'add12m': (16, 2, 1000, 1500, 0), 'add11e': (16, 1, 600, 500, 0),
     'bowaxe16': (16, 2, 1000, 2500, 2), 'axeeasy10': (16, 3, 1200, 3000, 2),
+    'brkinc10': (8, 2, 1000, 3000, 2), 'brkinclog12': (8, 2, 800, 2000, 1), 'extdec10': (8, 2, 1000, 3000, 2),
+    'axetbe10': (8, 2, 1000, 3000, 2), 'axetbm12': (8, 2, 1000, 3000, 2), 'remape10': (8, 2, 1000, 2500, 2),
+    'remapm10': (8, 2, 1000, 2500, 2), 'remaph10': (8, 2, 1000, 2500, 2),
 }
 
 
@@ -552,6 +629,10 @@ def main():
         gen_c1loop(6, out, strings)
         np.savez_compressed(os.path.join(OUT, 'c1loop.npz'), **out)
         spec['novelty_arg_errors'] = novelty_arg_errors()
+        spec['novelty_arg_errors2'] = novelty_arg_errors2()
+        lim = {}
+        gen_limit(lim, strings, spec)
+        np.savez_compressed(os.path.join(OUT, 'limit.npz'), **lim)
         spec['exhaustion'] = exhaustion_cases()
     spec['messages'] = strings.lst
     spec['generator'] = {'numpy': np.__version__, 'python': sys.version.split()[0],

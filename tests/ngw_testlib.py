@@ -19,7 +19,12 @@ CFGS = {
     'add12m': (POGO, 12, ('additem', 'medium', 'spring', '')), 'add11e': (POGO, 11, ('additem', 'easy', 'arrow', '')),
     'bowaxe16': (BOW, 16, ('axe', 'medium', 'wooden', 'false')),
     'axeeasy10': (POGO, 10, ('axe', 'easy', 'wooden', '')),
+    'brkinc10': (POGO, 10, ('breakincrease', 'hard', '', '')), 'brkinclog12': (POGO, 12, ('breakincrease', 'hard', 'tree_log', '')),
+    'extdec10': (BOW, 10, ('extractincdec', 'hard', 'decrease', '')), 'axetbe10': (POGO, 10, ('axetobreak', 'easy', 'wooden', '')),
+    'axetbm12': (BOW, 12, ('axetobreak', 'medium', 'iron', '')), 'remape10': (POGO, 10, ('remapaction', 'easy', '', '')),
+    'remapm10': (BOW, 10, ('remapaction', 'medium', '', '')), 'remaph10': (POGO, 10, ('remapaction', 'hard', '', '')),
 }
+REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13}
 HEADLINE = ['pogo10', 'bow20', 'axe10', 'add32']       # BASELINE.json configs 2-5
 
 _spec_json = None
@@ -43,7 +48,12 @@ def build_spec(cfg, map_size=None):
     env_id, S, nov = CFGS[cfg]
     spec = make_spec(env_id, S if map_size is None else map_size)
     if nov is not None:
+        if cfg in REMAP_SEED:
+            state = np.random.get_state()
+            np.random.seed(REMAP_SEED[cfg])       # same global-stream position as the reference had at injection
         apply_novelty(spec, *nov)
+        if cfg in REMAP_SEED:
+            np.random.set_state(state)
     return spec
 
 
@@ -325,6 +335,8 @@ def make_adapter_env(cfg, backend='hip', seed=5):
     env.seed(seed)
     env.map_size = S
     if nov is not None:
+        if cfg in REMAP_SEED:
+            np.random.seed(REMAP_SEED[cfg])
         env = G.inject_novelty(env, *nov)
     return env
 

@@ -1,0 +1,111 @@
+"""SURVEY §8(f) row 2 - LUT-only novelties and LimitActions: argument errors, wrapper behaviour and the LimitActions
+traces against vectors captured from the reference (CPU: oracle-backed stand-in backend; -m gpu: the HIP backend)."""
+import numpy as np
+import pytest
+
+import ngw_testlib as T
+import gym_novel_gridworlds_amd as G
+from gym_novel_gridworlds_amd.spec import make_spec
+from gym_novel_gridworlds_amd.novelty import apply_novelty
+
+ROW2 = ['brkinc10', 'brkinclog12', 'extdec10', 'axetbe10', 'axetbm12', 'remape10', 'remapm10', 'remaph10']
+LIM = dict(np.load(T.GOLDEN + '/limit.npz'))
+LIMITED = {'Forward', 'Left', 'Right', 'Break', 'Craft_plank', 'Craft_stick', 'Select_tree_log'}
+
+
+def test_argument_errors_match_reference():
+    for env_id, args, exc, text in T.spec_json()['novelty_arg_errors2']:
+        with pytest.raises(Exception) as ei:
+            apply_novelty(make_spec(env_id), *args)
+        assert type(ei.value).__name__ == exc and str(ei.value) == text, (args, ei.value)
+    for name in ('addchop', 'addjump', 'crate', 'firewall'):
+        with pytest.raises(NotImplementedError):
+            apply_novelty(make_spec(T.POGO), name, 'hard', 'oak', 'brick')
+
+
+@pytest.mark.parametrize('cfg', ROW2)
+def test_adapter_replays_row2_traces(cfg):
+    """inject_novelty on the reference-shaped single env (incl. remapaction reproducing the reference's permutation)."""
+    np.random.seed(T.REMAP_SEED.get(cfg, 0))
+    assert T.replay_adapter(cfg, 'oracle', max_steps=300, n_single=250) > 400
+
+
+def _limited_env(kind, backend):
+    env = G.make(T.POGO)
+    if backend == 'oracle':
+        env._make_backend = lambda spec, seed_: T.OracleVec(spec, 1, seed=seed_)
+    env.seed(1)
+    env = G.LimitActions(env, set(LIMITED))
+    if kind == 'remapped':
+        np.random.seed(21)
+        env = G.inject_novelty(env, 'remapaction', 'hard')
+    return env
+
+
+def _replay_limit(kind, backend, steps=600):
+    ref = T.spec_json()['limit_actions'][kind]
+    env = _limited_env(kind, backend)
+    assert env.limited_actions_id == ref['limited_actions_id'] and env.action_space.n == ref['action_space_n']
+    base = env.unwrapped if hasattr(env, 'unwrapped') else env
+    while not hasattr(base, '_spec'):
+        base = base.env
+    env.reset()
+    p = 'lim_%s_' % kind
+    T.adapter_inject(base, base._spec, LIM[p + 'map0'], LIM[p + 'loc0'], LIM[p + 'facing0'], 0, np.zeros(9, int))
+    names = base._spec.item_names
+    for t in range(steps):
+        if t % 50 == 49:
+            base.inventory_items_quantity['tree_log'] += 2
+            base.inventory_items_quantity['plank'] += 2
+        obs, reward, done, info = env.step(int(LIM[p + 'action'][t]))
+        assert reward == LIM[p + 'reward'][t] and done == bool(LIM[p + 'done'][t]) and info['result'] == bool(LIM[p + 'result'][t])
+        assert info['step_cost'] == LIM[p + 'cost'][t] and info['message'] == T.messages()[LIM[p + 'msg'][t]], (kind, t)
+        assert obs['agent_location'] == tuple(LIM[p + 'loc'][t]) and obs['agent_facing_id'] == LIM[p + 'facing'][t]
+        assert [obs['inventory_items_quantity'][n] for n in names] == list(LIM[p + 'inv'][t])
+    for a, exc, text in ref['errors']:
+        with pytest.raises(AssertionError) as ei:
+            env.step(a)
+        assert str(ei.value) == text
+    return steps
+
+
+@pytest.mark.parametrize('kind', ['plain', 'remapped'])
+def test_limit_actions_wrapper_matches_reference(kind):
+    assert _replay_limit(kind, 'oracle') == 600
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['plain', 'remapped'])
+def test_limit_actions_wrapper_on_hip_backend(kind):
+    assert _replay_limit(kind, 'hip', steps=200) == 200
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cfg', ['brkinc10', 'axetbm12', 'remaph10'])
+def test_adapter_row2_on_hip_backend(cfg):
+    np.random.seed(T.REMAP_SEED.get(cfg, 0))
+    assert T.replay_adapter(cfg, 'hip', max_steps=150, n_single=100) > 200
+
+
+@pytest.mark.gpu
+def test_limit_actions_compiled_into_batched_env():
+    """limit_actions_vec: the limited ids become the kernel's action table; a batch stepped with limited ids equals the
+    full env stepped with the translated ids."""
+    from oracle.ngw_oracle import Oracle
+    n = 2000
+    full = G.VecNovelGridworld(num_envs=n, seed=4, autoreset=True, horizon=30)
+    lim = G.limit_actions_vec(full, LIMITED)
+    assert lim.action_space.n == 7 and lim.actions_id == {a: i for i, a in enumerate(sorted(LIMITED))}
+    o = Oracle(full.spec.compile(), n, seed=4, autoreset=True, horizon=30)
+    lim.reset(); o.reset()
+    table = np.array([full.actions_id[a] for a in sorted(LIMITED)], np.int32)
+    rs = np.random.RandomState(0)
+    for t in range(80):
+        a = rs.randint(0, 7, size=n).astype(np.int32)
+        _, reward, done, info = lim.step(a)
+        o.step(table[a])
+        assert (reward == o.reward).all() and (info['message_code'] == o.msg_code).all()
+    st = lim.get_state()
+    assert (st['map'] == o.st.map).all() and (st['inv'] == o.st.inv).all()
+    with pytest.raises(ValueError):
+        lim.step(np.full(n, 7, np.int32))
