@@ -81,7 +81,7 @@ int check_spec(const ngw_spec* s) {
         return fail(NGW_E_INVALID_ARG, "spec item id out of range");
     for (int a = 0; a < s->n_actions; a++) {
         const int kind = s->act_kind[a], arg = s->act_arg[a];
-        if (kind > NGW_ACT_SELECT) return fail(NGW_E_INVALID_ARG, "action %d has unknown kind %d", a, kind);
+        if (kind > NGW_ACT_JUMP) return fail(NGW_E_INVALID_ARG, "action %d has unknown kind %d", a, kind);
         if (kind == NGW_ACT_CRAFT && arg >= s->n_recipes) return fail(NGW_E_INVALID_ARG, "action %d: recipe %d out of range", a, arg);
         if (kind == NGW_ACT_SELECT && !item_ok(arg)) return fail(NGW_E_INVALID_ARG, "action %d: item %d out of range", a, arg);
     }
@@ -263,6 +263,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
         u.axe_item = spec->axe_item; u.axe_cost = spec->axe_cost; u.axe_qty = spec->axe_qty;
         u.place_reward = spec->place_reward; u.ext_reward = spec->ext_reward; u.axe_reward = spec->axe_reward;
         u.axe_required = spec->axe_required;
+        u.cost_chop = spec->cost_chop; u.cost_jump = spec->cost_jump; u.chop_reward = spec->chop_reward;
         for (int j = 0; j < spec->n_start; j++)
             for (int q = 0; q < spec->start_qty[j]; q++) hs.place_seq[hs.n_place++] = spec->start_item[j];
         for (int a = 0; a < spec->n_actions; a++) {

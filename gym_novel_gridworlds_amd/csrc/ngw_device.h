@@ -61,6 +61,9 @@ struct NgwStepU {
     uint8_t cost_forward, cost_turn, cost_break, cost_place, cost_extract, cost_select, table_item, goal_item;
     uint8_t place_item, place_near, n_entities, ext_src, ext_near, ext_out, ext_qty, ext_consume;
     uint8_t ext_cost_ok, axe_item, axe_cost, axe_qty;
+    uint8_t cost_chop, cost_jump;
+    int8_t chop_reward;
+    uint8_t _pad;
     int8_t place_reward, ext_reward, axe_reward;
     uint8_t axe_required;                   /* AxetoBreak*: Break fails without the selected axe */
 };

@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     PIN_S(key0); PIN_S(key1);
     // uniform step parameters, unpacked into scalars
     uint32_t brk_mask = U.brk_mask, ent_mask = U.ent_mask, rew_mask = U.rew_mask, brk2_mask = U.brk2_mask;
-    int axe_required = U.axe_required;
+    int axe_required = U.axe_required, cost_chop = U.cost_chop, cost_jump = U.cost_jump, chop_reward = U.chop_reward;
     int n_actions = U.n_actions, reward_step = U.reward_step, reward_done = U.reward_done, craft_reward = U.craft_reward;
     int break_reward = U.break_reward;
     int cost_forward = U.cost_forward, cost_turn = U.cost_turn, cost_break = U.cost_break, cost_place = U.cost_place;
@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     int ext_near = U.ext_near, ext_out = U.ext_out, ext_qty = U.ext_qty, ext_consume = U.ext_consume;
     int ext_cost_ok = U.ext_cost_ok, axe_item = U.axe_item, axe_cost = U.axe_cost, axe_qty = U.axe_qty;
     int place_reward = U.place_reward, ext_reward = U.ext_reward, axe_reward = U.axe_reward;
-    PIN_S(brk_mask); PIN_S(ent_mask); PIN_S(rew_mask); PIN_S(brk2_mask); PIN_S(axe_required); PIN_S(n_actions); PIN_S(reward_step); PIN_S(reward_done);
+    PIN_S(brk_mask); PIN_S(ent_mask); PIN_S(rew_mask); PIN_S(brk2_mask); PIN_S(axe_required); PIN_S(cost_chop); PIN_S(cost_jump); PIN_S(chop_reward); PIN_S(n_actions); PIN_S(reward_step); PIN_S(reward_done);
     PIN_S(craft_reward); PIN_S(break_reward); PIN_S(cost_forward); PIN_S(cost_turn); PIN_S(cost_break); PIN_S(cost_place);
     PIN_S(cost_extract); PIN_S(cost_select); PIN_S(table_item); PIN_S(goal_item); PIN_S(place_item); PIN_S(place_near);
     PIN_S(n_entities); PIN_S(ext_src); PIN_S(ext_near); PIN_S(ext_out); PIN_S(ext_qty); PIN_S(ext_consume);
@@ -532,7 +532,10 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                     const bool okN = fr > 0, okS = fr < S - 1, okW = fc > 0, okE = fc < S - 1;
                     const int nbN = mp[okN ? fcell - S : fcell], nbS = mp[okS ? fcell + S : fcell];
                     const int nbW = mp[okW ? fcell - 1 : fcell], nbE = mp[okE ? fcell + 1 : fcell];
-                                        const int inv_place = inv[place_item], inv_ext = inv[ext_out], inv_axe = inv[axe_item];
+                                        const int fr2 = fr + dr, fc2 = fc + dc;                        // two cells ahead (Jump)
+                    const bool ok2 = fr2 >= 0 && fr2 <= S - 1 && fc2 >= 0 && fc2 <= S - 1;
+                    const int front2 = mp[ok2 ? fr2 * S + fc2 : fcell];
+                    const int inv_place = inv[place_item], inv_ext = inv[ext_out], inv_axe = inv[axe_item];
                     // ---------------- L1: reads whose address came out of L0
                     const int kind = d0 & 255, aarg = (d0 >> 8) & 255, nin = (d0 >> 16) & 255;
                     const int in0 = d1 & 255, in1 = (d1 >> 8) & 255, in2 = (d1 >> 16) & 255, in3 = d1 >> 24;
@@ -568,6 +571,18 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                                 inv[front] = nv; gi[front] = nv;
                             }
                         } else { result = 0; msg = NGW_MSG_CANNOT_BREAK; arg = front; }
+                        break;
+                    case NGW_ACT_CHOP:                                             // AddChopAction.step, novelty_wrappers.py:1288-1308
+                        cost = cost_chop;
+                        if ((brk_mask >> front) & 1u) {
+                            mp[fcell] = 0; gm[fcell] = 0;
+                            inv[front] = inv_front + 2; gi[front] = inv_front + 2;
+                            rew = chop_reward;
+                        } else { result = 0; msg = NGW_MSG_CANNOT_CHOP; arg = front; }
+                        break;
+                    case NGW_ACT_JUMP:                                             // AddJumpAction.step :1362-1381 (cell between ignored)
+                        if (ok2 && front2 == 0) { r = fr2; c = fc2; } else { result = 0; msg = NGW_MSG_BLOCK_IN_PATH; }
+                        cost = cost_jump;
                         break;
                     case NGW_ACT_PLACE:                                            // :295-314
                         if (inv_place >= 1) {

@@ -7,7 +7,7 @@ AxeMedium.__init__ :125-134, AxeEasy.__init__ :16-27, AddItem.__init__ :996-1011
 `EnvSpec`, which is then recompiled into the kernel LUTs.
 
 In scope: SURVEY.md §8(a) 'axe' (easy / medium) and 'additem'; §8(f) row 2 (LUT-only novelties) 'breakincrease',
-'extractincdec', 'axetobreak' (easy / medium) and 'remapaction'.  The rest ('addchop', 'addjump', 'crate', 'fence',
+'extractincdec', 'axetobreak' (easy / medium), 'remapaction', 'addchop' and 'addjump'.  The rest ('crate', 'fence',
 'fencerestriction', 'firewall', 'replaceitem', 'axe'/'axetobreak' hard) validate like the reference and then raise
 NotImplementedError.
 """
@@ -67,6 +67,12 @@ def apply_novelty(spec, novelty_name, difficulty='hard', novelty_arg1='', novelt
         spec.extract['qty'] = spec.extract['qty'] * 2 if novelty_arg1 == 'increase' else spec.extract['qty'] // 2
     elif novelty_name == 'remapaction':
         _remap_action_difficulty(spec, difficulty)
+    elif novelty_name in ('addchop', 'addjump'):
+        # AddChopAction.__init__ :1273-1278 / AddJumpAction.__init__ :1345-1350: a new manipulation action at the end
+        name = 'Chop' if novelty_name == 'addchop' else 'Jump'
+        spec.manipulation_actions_id[name] = len(spec.actions_id)
+        spec.actions_id.update(spec.manipulation_actions_id)
+        spec.action_space_n = len(spec.actions_id)                 # these wrappers DO grow their action_space (:1278, :1350)
     else:
         raise NotImplementedError("novelty %r is outside this build's hot-path scope (SURVEY.md §8(f))"
                                   % novelty_name)

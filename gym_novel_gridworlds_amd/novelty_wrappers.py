@@ -68,6 +68,14 @@ class ExtractIncDec(NoveltyWrapper):
     pass
 
 
+class AddChopAction(NoveltyWrapper):
+    pass
+
+
+class AddJumpAction(NoveltyWrapper):
+    pass
+
+
 class AddItem(NoveltyWrapper):
     def reset(self):                                          # novelty_wrappers.py:1013 takes no kwargs
         return self.env.reset()
@@ -110,4 +118,9 @@ def inject_novelty(env, novelty_name, difficulty='hard', novelty_arg1='', novelt
         return ExtractIncDec(env)
     if novelty_name == 'remapaction':
         return env                  # remap_action_difficulty returns the env itself (:1227)
+    if novelty_name in ('addchop', 'addjump'):
+        w = AddChopAction(env) if novelty_name == 'addchop' else AddJumpAction(env)
+        from . import spaces
+        w.action_space = spaces.Discrete(len(base.actions_id))     # these two wrappers DO grow their action_space (:1278, :1350)
+        return w
     return AddItem(env)

@@ -22,7 +22,7 @@ ABI_VERSION = 1
 
 # step_cost values with their Python types (SURVEY.md §8(a) "Distinct step_cost values")
 STEP_COSTS = [0, 24.0, 27.906975, 120.0, 300.0, 360.0, 480.0, 720.0, 840.0, 1200.0, 1800.0, 2400.0, 3600.0,
-              7200.0, 8400.0, 5000, 50000, 900.0]
+              7200.0, 8400.0, 5000, 50000, 900.0, 3600.0 * 1.2, 27.906975 * 2]
 
 
 def cost_code(value):
@@ -32,9 +32,10 @@ def cost_code(value):
     raise KeyError("step cost %r has no code" % (value,))
 
 
-ACT_FORWARD, ACT_LEFT, ACT_RIGHT, ACT_BREAK, ACT_PLACE, ACT_EXTRACT, ACT_CRAFT, ACT_SELECT = range(8)
+ACT_FORWARD, ACT_LEFT, ACT_RIGHT, ACT_BREAK, ACT_PLACE, ACT_EXTRACT, ACT_CRAFT, ACT_SELECT, ACT_CHOP, ACT_JUMP = range(10)
 (MSG_NONE, MSG_BLOCK_IN_PATH, MSG_CANNOT_BREAK, MSG_PLACED, MSG_ALREADY_EXISTS, MSG_NOT_IN_INVENTORY,
- MSG_EXTRACT_NO_SRC, MSG_EXTRACT_NOT_NEAR, MSG_MISSING_ITEMS, MSG_NEED_TABLE, MSG_CRAFTED, MSG_NEED_AXE) = range(12)
+ MSG_EXTRACT_NO_SRC, MSG_EXTRACT_NOT_NEAR, MSG_MISSING_ITEMS, MSG_NEED_TABLE, MSG_CRAFTED, MSG_NEED_AXE,
+ MSG_CANNOT_CHOP) = range(13)
 
 F_INVALID_ACTION, F_PLACEMENT = 1, 2
 
@@ -61,6 +62,7 @@ class NgwSpec(C.Structure):
         ('cost_ok', C.c_uint8 * MAX_RECIPES),
         ('cost_forward', C.c_uint8), ('cost_turn', C.c_uint8), ('cost_break', C.c_uint8),
         ('cost_place', C.c_uint8), ('cost_extract', C.c_uint8), ('cost_select', C.c_uint8),
+        ('cost_chop', C.c_uint8), ('cost_jump', C.c_uint8), ('chop_reward', C.c_int8), ('_pad3', C.c_uint8),
         ('place_item', C.c_uint8), ('place_near', C.c_uint8), ('place_reward', C.c_int8),
         ('ext_src', C.c_uint8), ('ext_near', C.c_uint8), ('ext_out', C.c_uint8), ('ext_qty', C.c_uint8),
         ('ext_consume', C.c_uint8), ('ext_cost_ok', C.c_uint8), ('ext_reward', C.c_int8),
@@ -213,8 +215,9 @@ class EnvSpec:
         s.reward_step, s.reward_done, s.craft_reward = -1, self.reward_done, self.craft_reward
         rnames = self.recipe_names
         for name, a in self.actions_id.items():
-            if name in ('Forward', 'Left', 'Right', 'Break'):
-                kind, arg = {'Forward': ACT_FORWARD, 'Left': ACT_LEFT, 'Right': ACT_RIGHT, 'Break': ACT_BREAK}[name], 0
+            if name in ('Forward', 'Left', 'Right', 'Break', 'Chop', 'Jump'):
+                kind, arg = {'Forward': ACT_FORWARD, 'Left': ACT_LEFT, 'Right': ACT_RIGHT, 'Break': ACT_BREAK,
+                             'Chop': ACT_CHOP, 'Jump': ACT_JUMP}[name], 0
             elif name.startswith('Place_'):
                 kind, arg = ACT_PLACE, ids[name[6:]]
             elif name.startswith('Extract_'):
@@ -252,6 +255,8 @@ class EnvSpec:
             s.cost_missing[r], s.cost_no_table[r], s.cost_ok[r] = cost_code(cm), cost_code(cn), cost_code(ck)
         s.cost_forward, s.cost_turn, s.cost_break = cost_code(27.906975), cost_code(24.0), cost_code(3600.0)
         s.cost_place, s.cost_extract, s.cost_select = cost_code(300.0), cost_code(120.0), cost_code(120.0)
+        s.cost_chop, s.cost_jump = cost_code(3600.0 * 1.2), cost_code(27.906975 * 2)
+        s.chop_reward = self.reward_intermediate
         if self.place:
             s.place_item, s.place_near = ids[self.place['item']], ids[self.place['near']]
             s.place_reward = self.reward_intermediate
@@ -302,6 +307,8 @@ class EnvSpec:
             return 'Need to be in front of crafting_table'                  # :452
         if code == MSG_CRAFTED:
             return 'Crafted ' + names[arg]                                  # :472
+        if code == MSG_CANNOT_CHOP:
+            return "Cannot chop " + names[arg]                              # novelty_wrappers.py:1308
         if code == MSG_NEED_AXE:
             return "Cannot break without " + names[arg] + " selected"         # novelty_wrappers.py:591
         raise ValueError("unknown message code %d" % code)

@@ -46,7 +46,8 @@ extern "C" {
 
 /* action kinds (act_kind[]); act_arg[] = recipe index (CRAFT) or item id (SELECT) */
 enum { NGW_ACT_FORWARD = 0, NGW_ACT_LEFT = 1, NGW_ACT_RIGHT = 2, NGW_ACT_BREAK = 3, NGW_ACT_PLACE = 4,
-       NGW_ACT_EXTRACT = 5, NGW_ACT_CRAFT = 6, NGW_ACT_SELECT = 7 };
+       NGW_ACT_EXTRACT = 5, NGW_ACT_CRAFT = 6, NGW_ACT_SELECT = 7,
+       NGW_ACT_CHOP = 8 /* AddChopAction, novelty_wrappers.py:1267 */, NGW_ACT_JUMP = 9 /* AddJumpAction, :1340 */ };
 
 /* info['message'] codes; the host formats the string (reference strings cited in spec.py) */
 enum { NGW_MSG_NONE = 0, NGW_MSG_BLOCK_IN_PATH = 1, NGW_MSG_CANNOT_BREAK = 2 /* arg = item */,
@@ -54,7 +55,8 @@ enum { NGW_MSG_NONE = 0, NGW_MSG_BLOCK_IN_PATH = 1, NGW_MSG_CANNOT_BREAK = 2 /* 
        NGW_MSG_NOT_IN_INVENTORY = 5, NGW_MSG_EXTRACT_NO_SRC = 6, NGW_MSG_EXTRACT_NOT_NEAR = 7,
        NGW_MSG_MISSING_ITEMS = 8 /* arg = recipe<<8 | mask over the recipe's inputs in dict order */,
        NGW_MSG_NEED_TABLE = 9, NGW_MSG_CRAFTED = 10 /* arg = crafted item */,
-       NGW_MSG_NEED_AXE = 11 /* arg = axe item: "Cannot break without <axe> selected" */ };
+       NGW_MSG_NEED_AXE = 11 /* arg = axe item: "Cannot break without <axe> selected" */,
+       NGW_MSG_CANNOT_CHOP = 12 /* arg = item */ };
 
 /* packed per-env info word produced by the step kernel:
  *   bit 0 result | bit 1 done | bits 2..7 cost code | bits 8..15 message code | bits 16..31 message arg */
@@ -94,6 +96,9 @@ typedef struct ngw_spec {
     uint8_t cost_missing[NGW_MAX_RECIPES], cost_no_table[NGW_MAX_RECIPES], cost_ok[NGW_MAX_RECIPES];
     /* fixed-action cost codes */
     uint8_t cost_forward, cost_turn, cost_break, cost_place, cost_extract, cost_select;
+    uint8_t cost_chop, cost_jump;        /* 3600.0 * 1.2 (novelty_wrappers.py:1294), 27.906975 * 2 (:1381) */
+    int8_t chop_reward;                  /* reward_intermediate for any breakable block (:1303) */
+    uint8_t _pad3;
     /* Place_<item> (:295-314): place `place_item` in front; +place_reward iff a 4-neighbour of the front cell is place_near */
     uint8_t place_item, place_near;
     int8_t place_reward;

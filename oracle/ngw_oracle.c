@@ -229,6 +229,21 @@ void ngwo_step(const ngw_spec* sp, int8_t* map, int32_t* loc, int32_t* facing, i
             }
         } else { result = 0; msg = NGW_MSG_CANNOT_BREAK; arg = front; }
         break;
+    case NGW_ACT_CHOP:                                            /* AddChopAction.step, novelty_wrappers.py:1288-1308 */
+        cost = sp->cost_chop;                                     /* 3600.0 * 1.2 */
+        if (sp->breakable[front]) {
+            map[fr * S + fc] = 0;
+            inv[front] += 2;                                      /* 1 * 2 */
+            reward = sp->chop_reward;                             /* reward_intermediate */
+        } else { result = 0; msg = NGW_MSG_CANNOT_CHOP; arg = front; }
+        break;
+    case NGW_ACT_JUMP: {                                          /* AddJumpAction.step, :1362-1381: two cells ahead, the cell between is ignored */
+        const int r2 = r + 2 * DR[f], c2 = c + 2 * DC[f];
+        if (r2 >= 0 && r2 <= S - 1 && c2 >= 0 && c2 <= S - 1 && map[r2 * S + c2] == 0) { r = r2; c = c2; }
+        else { result = 0; msg = NGW_MSG_BLOCK_IN_PATH; }
+        cost = sp->cost_jump;                                     /* 27.906975 * 2 */
+        break;
+    }
     case NGW_ACT_PLACE:                                           /* :295-314 */
         if (inv[sp->place_item] >= 1) {
             if (front == 0) {

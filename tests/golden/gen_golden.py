@@ -59,6 +59,8 @@ CFGS = {
     'remape10':    (POGO, 10, ('remapaction', 'easy', '', '')),
     'remapm10':    (BOW, 10, ('remapaction', 'medium', '', '')),
     'remaph10':    (POGO, 10, ('remapaction', 'hard', '', '')),
+    'chop10':      (POGO, 10, ('addchop', 'hard', '', '')),
+    'jump12':      (BOW, 12, ('addjump', 'hard', '', '')),
 }
 REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13}      # np.random.seed right before inject_novelty
 DIRS = ['NORTH', 'SOUTH', 'WEST', 'EAST']
@@ -596,7 +598,8 @@ PLAN = {  # cfg: (reset seeds, traces, steps per trace, single-step cases, solve
     'bowaxe16': (16, 2, 1000, 2500, 2), 'axeeasy10': (16, 3, 1200, 3000, 2),
     'brkinc10': (8, 2, 1000, 3000, 2), 'brkinclog12': (8, 2, 800, 2000, 1), 'extdec10': (8, 2, 1000, 3000, 2),
     'axetbe10': (8, 2, 1000, 3000, 2), 'axetbm12': (8, 2, 1000, 3000, 2), 'remape10': (8, 2, 1000, 2500, 2),
-    'remapm10': (8, 2, 1000, 2500, 2), 'remaph10': (8, 2, 1000, 2500, 2),
+    'remapm10': (8, 2, 1000, 2500, 2), 'remaph10': (8, 2, 1000, 2500, 2), 'chop10': (8, 2, 1000, 3000, 1),
+    'jump12': (8, 2, 1000, 3000, 1),
 }
 
 

@@ -23,6 +23,7 @@ CFGS = {
     'extdec10': (BOW, 10, ('extractincdec', 'hard', 'decrease', '')), 'axetbe10': (POGO, 10, ('axetobreak', 'easy', 'wooden', '')),
     'axetbm12': (BOW, 12, ('axetobreak', 'medium', 'iron', '')), 'remape10': (POGO, 10, ('remapaction', 'easy', '', '')),
     'remapm10': (BOW, 10, ('remapaction', 'medium', '', '')), 'remaph10': (POGO, 10, ('remapaction', 'hard', '', '')),
+    'chop10': (POGO, 10, ('addchop', 'hard', '', '')), 'jump12': (BOW, 12, ('addjump', 'hard', '', '')),
 }
 REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13}
 HEADLINE = ['pogo10', 'bow20', 'axe10', 'add32']       # BASELINE.json configs 2-5

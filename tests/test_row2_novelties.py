@@ -8,7 +8,7 @@ import gym_novel_gridworlds_amd as G
 from gym_novel_gridworlds_amd.spec import make_spec
 from gym_novel_gridworlds_amd.novelty import apply_novelty
 
-ROW2 = ['brkinc10', 'brkinclog12', 'extdec10', 'axetbe10', 'axetbm12', 'remape10', 'remapm10', 'remaph10']
+ROW2 = ['brkinc10', 'brkinclog12', 'extdec10', 'axetbe10', 'axetbm12', 'remape10', 'remapm10', 'remaph10', 'chop10', 'jump12']
 LIM = dict(np.load(T.GOLDEN + '/limit.npz'))
 LIMITED = {'Forward', 'Left', 'Right', 'Break', 'Craft_plank', 'Craft_stick', 'Select_tree_log'}
 
@@ -18,7 +18,7 @@ def test_argument_errors_match_reference():
         with pytest.raises(Exception) as ei:
             apply_novelty(make_spec(env_id), *args)
         assert type(ei.value).__name__ == exc and str(ei.value) == text, (args, ei.value)
-    for name in ('addchop', 'addjump', 'crate', 'firewall'):
+    for name in ('crate', 'firewall', 'fence', 'replaceitem'):
         with pytest.raises(NotImplementedError):
             apply_novelty(make_spec(T.POGO), name, 'hard', 'oak', 'brick')
 
