@@ -7,7 +7,7 @@ reference's gym.Env surface.  Everything computes in hand-written HIP kernels re
     env = gym.make('NovelGridworld-Pogostick-v1')           # or gym_novel_gridworlds_amd.make(...)
     venv = gym_novel_gridworlds_amd.VecNovelGridworld('NovelGridworld-Pogostick-v1', num_envs=65536)
 """
-from .envs import ENTRY_POINTS, BowV1Env, PogostickV1Env, make       # noqa: F401
+from .envs import ENTRY_POINTS, BowV0Env, BowV1Env, PogostickV0Env, PogostickV1Env, make   # noqa: F401
 from .novelty import NOVELTY_NAMES, apply_novelty                    # noqa: F401
 from .novelty_wrappers import inject_novelty                         # noqa: F401
 from .observation_wrappers import LidarInFront                      # noqa: F401

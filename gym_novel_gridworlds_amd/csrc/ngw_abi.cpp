@@ -77,7 +77,8 @@ int check_spec(const ngw_spec* s) {
     auto item_ok = [&](int i) { return i >= 0 && i < K; };
     if (!item_ok(s->wall_item) || !item_ok(s->table_item) || !item_ok(s->goal_item) || !item_ok(s->place_item) ||
         !item_ok(s->place_near) || !item_ok(s->ext_src) || !item_ok(s->ext_near) || !item_ok(s->ext_out) ||
-        !item_ok(s->axe_item) || !item_ok(s->additem_item) || !item_ok(s->inv_start_item))
+        !item_ok(s->axe_item) || !item_ok(s->additem_item) || !item_ok(s->inv_start_item) || !item_ok(s->tap_item) ||
+        !item_ok(s->tap_near))
         return fail(NGW_E_INVALID_ARG, "spec item id out of range");
     for (int a = 0; a < s->n_actions; a++) {
         const int kind = s->act_kind[a], arg = s->act_arg[a];
@@ -293,6 +294,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     p.n = h->n; p.n_pad = h->n_pad; p.env_base = h->env_base; p.seed = seed;
     p.S = S; p.S2 = S2; p.K = K; p.KP = K | 1;
     p.magicK = (uint32_t)((0x100000000ull + (uint32_t)K - 1) / (uint32_t)K);
+    p.magicS = (uint32_t)((0x100000000ull + (uint32_t)S - 1) / (uint32_t)S);
     const int S2r = (S2 + 3) / 4;                       // dwords per map, rounded up
     const int MSdw = (S2r & 1) ? S2r : S2r + 1;         // odd dword stride -> conflict-free per-lane cell reads
     p.MS = ((S2 & 3) == 0 && (S2r & 1)) ? S2 : MSdw * 4;

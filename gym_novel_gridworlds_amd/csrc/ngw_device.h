@@ -49,6 +49,7 @@ struct NgwLaunch {
     uint32_t off_perm;
     uint32_t magic;              /* ceil(2^32 / (S2/4)) (or / S2 for odd S): exact division of chunk offsets */
     uint32_t magicK;             /* ceil(2^32 / K): exact division of inventory chunk offsets (< 64*K) */
+    uint32_t magicS;             /* ceil(2^32 / S): cell / S */
     uint32_t off_inv, off_cand, off_act;    /* LDS dword offsets */
 };
 

@@ -105,6 +105,7 @@ struct ResetArgs {
     int64_t n_pad;
     uint64_t seed;
     int S, S2, K, CW, perm_lds;
+    uint32_t magicS;                // ceil(2^32 / S): cell / S for cell < S*S
 };
 
 // AddItem.reset (novelty_wrappers.py:1017-1028) on a shuffle array `perm` with element stride `ps`.
@@ -173,6 +174,25 @@ __device__ __noinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t* mp
             mp[cell] == 0 && mp[cell - S] == 0 && mp[cell + S] == 0 && mp[cell - 1] == 0 && mp[cell + 1] == 0) {
             mp[cell] = (int8_t)place_seq[n];                                       // :177-180
             n++;
+        }
+    }
+    if (sp.tap_item && !flags) {                                                   // Pogostick-v0, pogostick_v0_env.py:156-178
+        const int near = sp.tap_near;
+        int nl = 0;
+        for (int i = 0; i < a.S2; i++) nl += (mp[i] == near);                     // np.where(map == tree_log)
+        if (nl <= 1) flags |= NGW_F_PLACEMENT;                                     // assert len(result[0]) > 1
+        for (int tries = 0; !flags; tries++) {
+            if (tries >= 4096) { flags |= NGW_F_PLACEMENT; break; }               // no log has a free neighbour: give up loudly
+            const int d = (int)bounded(px, 3);                                     // np.random.choice(4 directions)
+            int idx = (int)bounded(px, (uint32_t)nl - 1), cell = 0;
+            for (int i = 0; i < a.S2; i++)                                         // idx-th log, row-major
+                if (mp[i] == near) { if (idx == 0) { cell = i; break; } idx--; }
+            const int lr = (int)__umulhi((uint32_t)cell, a.magicS);                // cell / S
+            const int rr = lr + ((d == 0) ? -1 : (d == 1 ? 1 : 0)), cc = cell - lr * S + ((d == 2) ? -1 : (d == 3 ? 1 : 0));
+            if (rr >= 0 && rr <= S - 1 && cc >= 0 && cc <= S - 1 && mp[rr * S + cc] == 0 && rr * S + cc != agent) {
+                mp[rr * S + cc] = (int8_t)sp.tap_item;
+                break;
+            }
         }
     }
     if (sp.additem_item && !flags) {
@@ -658,7 +678,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
             }
             if (do_reset) {                                                        // cold path, out of line
                 episode++;
-                const ResetArgs ra = {dspec, a.b.perm, a.n_pad, a.seed, S, a.S2, K, a.CW, a.perm_lds};
+                const ResetArgs ra = {dspec, a.b.perm, a.n_pad, a.seed, S, a.S2, K, a.CW, a.perm_lds, a.magicS};
                 const uint32_t rr = reset_lane(ra, (LDS_AS int8_t*)mp, (LDS_AS int32_t*)inv, (LDS_AS uint32_t*)cand,
                                                (const LDS_AS uint8_t*)(lds_act + NGW_MAX_ACTIONS * NGW_ACT_DW),
                                                (LDS_AS uint16_t*)(lds + a.off_perm), env_global, e, episode);

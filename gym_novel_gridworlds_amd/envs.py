@@ -284,7 +284,18 @@ class BowV1Env(_NovelGridworldEnv):
     ENV_ID = 'NovelGridworld-Bow-v1'
 
 
-ENTRY_POINTS = {'NovelGridworld-Pogostick-v1': PogostickV1Env, 'NovelGridworld-Bow-v1': BowV1Env}
+class PogostickV0Env(_NovelGridworldEnv):
+    """pogostick_v0_env.py: starts with sticks / planks on the map and a tree_tap already next to a tree_log."""
+    ENV_ID = 'NovelGridworld-Pogostick-v0'
+
+
+class BowV0Env(_NovelGridworldEnv):
+    """bow_v0_env.py: sticks and strings lie on the map."""
+    ENV_ID = 'NovelGridworld-Bow-v0'
+
+
+ENTRY_POINTS = {'NovelGridworld-Pogostick-v1': PogostickV1Env, 'NovelGridworld-Bow-v1': BowV1Env,
+                'NovelGridworld-Pogostick-v0': PogostickV0Env, 'NovelGridworld-Bow-v0': BowV0Env}
 
 
 def make(env_id, **kwargs):

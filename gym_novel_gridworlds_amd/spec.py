@@ -69,9 +69,10 @@ class NgwSpec(C.Structure):
         ('axe_item', C.c_uint8), ('axe_cost', C.c_uint8), ('axe_qty', C.c_uint8), ('axe_reward', C.c_int8),
         ('axe_required', C.c_uint8), ('_pad2', C.c_uint8 * 3),
         ('n_start', C.c_uint8), ('start_item', C.c_uint8 * MAX_START), ('start_qty', C.c_uint8 * MAX_START),
+        ('tap_item', C.c_uint8), ('tap_near', C.c_uint8),
         ('additem_item', C.c_uint8), ('additem_pct_lo', C.c_uint8), ('additem_pct_hi', C.c_uint8),
         ('inv_start_item', C.c_uint8), ('inv_start_qty', C.c_uint8),
-        ('_pad', C.c_uint8 * 1),
+        ('_pad', C.c_uint8 * 3),
     ]
 
 
@@ -107,6 +108,16 @@ _ENV_DEFS = {
         extract=dict(src='wool', near=None, out='string', qty=4, consume=True, cost_ok=5000),
     ),
 }
+# v0 variants: same skeleton, different start items / break rewards / craft reward, and
+# Pogostick-v0 pre-places a tree_tap next to a tree_log at reset (pogostick_v0_env.py:44,156-178,312,479; bow_v0_env.py:44,286,424)
+_ENV_DEFS['NovelGridworld-Pogostick-v0'] = dict(
+    copy.deepcopy(_ENV_DEFS['NovelGridworld-Pogostick-v1']),
+    items_quantity={'crafting_table': 1, 'stick': 4, 'plank': 2, 'tree_log': 2}, craft_reward='done',
+    break_reward_items=['stick', 'plank'], tap_pass=dict(item='tree_tap', near='tree_log'))
+_ENV_DEFS['NovelGridworld-Bow-v0'] = dict(
+    copy.deepcopy(_ENV_DEFS['NovelGridworld-Bow-v1']),
+    items_quantity={'crafting_table': 1, 'stick': 3, 'string': 3}, craft_reward='intermediate',
+    break_reward_items=['stick', 'string'])
 ENV_IDS = tuple(_ENV_DEFS)
 
 
@@ -132,7 +143,8 @@ class EnvSpec:
             raise KeyError("unknown env id %r (supported: %s)" % (env_id, ', '.join(ENV_IDS)))
         d = copy.deepcopy(_ENV_DEFS[env_id])
         self.env_id = env_id
-        self.class_name = {'NovelGridworld-Pogostick-v1': 'PogostickV1Env', 'NovelGridworld-Bow-v1': 'BowV1Env'}[env_id]
+        self.class_name = {'NovelGridworld-Pogostick-v1': 'PogostickV1Env', 'NovelGridworld-Bow-v1': 'BowV1Env',
+                           'NovelGridworld-Pogostick-v0': 'PogostickV0Env', 'NovelGridworld-Bow-v0': 'BowV0Env'}[env_id]
         self.map_size = int(map_size)
         self.items = set(d['items'])
         self.items_id = set_items_id(self.items)
@@ -145,6 +157,8 @@ class EnvSpec:
         self.reward_intermediate, self.reward_done = 10, 50
         self.craft_reward = self.reward_intermediate if d['craft_reward'] == 'intermediate' else self.reward_done
         self.place, self.extract = d['place'], d['extract']
+        self.break_reward_items = list(d.get('break_reward_items', ['tree_log']))   # Break gives +10 for these (:288 / v0 :312)
+        self.tap_pass = d.get('tap_pass')
         self.actions_id = {}
         self.manipulation_actions_id = {a: i for i, a in enumerate(d['manipulation'])}
         self.actions_id.update(self.manipulation_actions_id)
@@ -233,7 +247,7 @@ class EnvSpec:
             s.breakable[i] = int(name not in self.unbreakable_items)
             s.entity[i] = int(name in self.entities)
             if self.break_increase is None:
-                s.break_reward[i] = self.reward_intermediate if name == 'tree_log' else -1       # pogostick_v1_env.py:288-289
+                s.break_reward[i] = self.reward_intermediate if name in self.break_reward_items else -1   # pogostick_v1_env.py:288-289
                 s.break_qty[i] = 1
             else:                                         # BreakIncrease.step, novelty_wrappers.py:1444-1456
                 s.break_reward[i] = self.reward_intermediate if name not in self.unbreakable_items else -1
@@ -274,6 +288,8 @@ class EnvSpec:
             s.start_item[j], s.start_qty[j] = ids[item], q
         for item, q in self.start_inventory.items():
             s.inv_start_item, s.inv_start_qty = ids[item], q
+        if self.tap_pass:
+            s.tap_item, s.tap_near = ids[self.tap_pass['item']], ids[self.tap_pass['near']]
         if self.additem:
             s.additem_item = ids[self.additem['item']]
             s.additem_pct_lo, s.additem_pct_hi = self.additem['pct']

@@ -114,6 +114,9 @@ typedef struct ngw_spec {
     uint8_t n_start;
     uint8_t start_item[NGW_MAX_START_ITEMS];
     uint8_t start_qty[NGW_MAX_START_ITEMS];
+    /* Pogostick-v0 reset pass (pogostick_v0_env.py:156-178): put one `tap_item` on a free 4-neighbour (random direction)
+     * of a random `tap_near` block; tap_item = 0 -> disabled */
+    uint8_t tap_item, tap_near;
     /* AddItem second reset pass (novelty_wrappers.py:1013-1034); additem_item = 0 -> disabled */
     uint8_t additem_item, additem_pct_lo, additem_pct_hi;
     /* AxeEasy: item present in the inventory after every reset (novelty_wrappers.py:29-35); item 0 = none */

@@ -148,6 +148,22 @@ static int reset_env(const ngw_spec* sp, ngwo_rng* rng, int8_t* map, int32_t* lo
         }
     }
     free(avail);
+    if (sp->tap_item) {                                           /* Pogostick-v0, pogostick_v0_env.py:156-178 */
+        int16_t* logs = (int16_t*)malloc(sizeof(int16_t) * (size_t)(S * S));
+        int nl = 0;
+        for (int i = 0; i < S * S; i++) if (map[i] == sp->tap_near) logs[nl++] = (int16_t)i;   /* np.where, row-major */
+        if (nl <= 1) { free(logs); return NGW_E_PLACEMENT; }      /* assert len(result[0]) > 1 */
+        for (;;) {
+            const int d = (int)rng_bounded(rng, 3);               /* np.random.choice(4 directions) */
+            const int cell = logs[rng_bounded(rng, (uint32_t)nl - 1)];
+            const int rr = cell / S + DR[d], cc = cell % S + DC[d];
+            if (rr >= 0 && rr <= S - 1 && cc >= 0 && cc <= S - 1 && map[rr * S + cc] == 0 && rr * S + cc != agent) {
+                map[rr * S + cc] = (int8_t)sp->tap_item;
+                break;                                            /* a tap is on the map now */
+            }
+        }
+        free(logs);
+    }
     if (sp->additem_item) {                                       /* AddItem.reset, novelty_wrappers.py:1017-1028 */
         int n_air = 0;
         int16_t* air = (int16_t*)malloc(sizeof(int16_t) * (size_t)(S * S));

@@ -35,6 +35,7 @@ from gym_novel_gridworlds.novelty_wrappers import inject_novelty
 OUT = os.path.dirname(os.path.abspath(__file__))
 POGO = 'NovelGridworld-Pogostick-v1'
 BOW = 'NovelGridworld-Bow-v1'
+POGO0, BOW0 = 'NovelGridworld-Pogostick-v0', 'NovelGridworld-Bow-v0'
 
 # name -> (env_id, map_size, novelty args or None)
 CFGS = {
@@ -61,6 +62,10 @@ CFGS = {
     'remaph10':    (POGO, 10, ('remapaction', 'hard', '', '')),
     'chop10':      (POGO, 10, ('addchop', 'hard', '', '')),
     'jump12':      (BOW, 12, ('addjump', 'hard', '', '')),
+    # the v0 variants
+    'pogov0_10':   (POGO0, 10, None),
+    'pogov0_14':   (POGO0, 14, ('axe', 'medium', 'wooden', '')),
+    'bowv0_12':    (BOW0, 12, None),
 }
 REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13}      # np.random.seed right before inject_novelty
 DIRS = ['NORTH', 'SOUTH', 'WEST', 'EAST']
@@ -599,7 +604,8 @@ PLAN = {  # cfg: (reset seeds, traces, steps per trace, single-step cases, solve
     'brkinc10': (8, 2, 1000, 3000, 2), 'brkinclog12': (8, 2, 800, 2000, 1), 'extdec10': (8, 2, 1000, 3000, 2),
     'axetbe10': (8, 2, 1000, 3000, 2), 'axetbm12': (8, 2, 1000, 3000, 2), 'remape10': (8, 2, 1000, 2500, 2),
     'remapm10': (8, 2, 1000, 2500, 2), 'remaph10': (8, 2, 1000, 2500, 2), 'chop10': (8, 2, 1000, 3000, 1),
-    'jump12': (8, 2, 1000, 3000, 1),
+    'jump12': (8, 2, 1000, 3000, 1), 'pogov0_10': (32, 3, 1200, 4000, 0), 'pogov0_14': (16, 2, 1000, 2500, 0),
+    'bowv0_12': (16, 2, 1000, 3000, 0),
 }
 
 

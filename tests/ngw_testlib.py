@@ -24,6 +24,9 @@ CFGS = {
     'axetbm12': (BOW, 12, ('axetobreak', 'medium', 'iron', '')), 'remape10': (POGO, 10, ('remapaction', 'easy', '', '')),
     'remapm10': (BOW, 10, ('remapaction', 'medium', '', '')), 'remaph10': (POGO, 10, ('remapaction', 'hard', '', '')),
     'chop10': (POGO, 10, ('addchop', 'hard', '', '')), 'jump12': (BOW, 12, ('addjump', 'hard', '', '')),
+    'pogov0_10': ('NovelGridworld-Pogostick-v0', 10, None),
+    'pogov0_14': ('NovelGridworld-Pogostick-v0', 14, ('axe', 'medium', 'wooden', '')),
+    'bowv0_12': ('NovelGridworld-Bow-v0', 12, None),
 }
 REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13}
 HEADLINE = ['pogo10', 'bow20', 'axe10', 'add32']       # BASELINE.json configs 2-5

@@ -90,6 +90,8 @@ def test_gym_registration_with_classic_gym_standin():
         assert sorted(G.register_with_gym()) == sorted(G.ENTRY_POINTS)
         env = gym.make('NovelGridworld-Bow-v1')
         assert isinstance(env, G.BowV1Env) and env.action_space.n == 15
+        env = gym.make('NovelGridworld-Pogostick-v0')
+        assert isinstance(env, G.PogostickV0Env) and env.items_quantity == {'crafting_table': 1, 'stick': 4, 'plank': 2, 'tree_log': 2}
     finally:
         sys.path.remove(shim)
         for m in [m for m in sys.modules if m == 'gym' or m.startswith('gym.')]:

@@ -44,7 +44,8 @@ def test_solved_episodes_match_reference(cfg):
 # ------------------------------------------------------------------ oracle on the same seeded inputs
 @pytest.mark.parametrize('cfg,n', [('pogo10', 5000), ('bow20', 1500), ('axe10', 4096), ('add32', 300), ('pogo13', 777),
                                    ('bow10', 1000), ('axe12bi', 1000), ('add12m', 640), ('add11e', 500), ('bowaxe16', 900),
-                                   ('axeeasy10', 700)])
+                                   ('axeeasy10', 700), ('pogov0_10', 2000), ('pogov0_14', 600), ('bowv0_12', 600), ('axetbm12', 500),
+                                   ('chop10', 300)])
 def test_reset_matches_oracle(cfg, n):
     """reset(): template + per-env Philox item scatter (+ AddItem pass), three episodes, ragged N, masked reset."""
     spec = T.build_spec(cfg)
