@@ -550,19 +550,26 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                     const int front = mp[fcell];                                   // block in front (:369-389)
                     // 4-neighbourhood of the front cell, only in-bounds cells count (is_block_in_front_next_to :391-411)
                     const bool okN = fr > 0, okS = fr < S - 1, okW = fc > 0, okE = fc < S - 1;
-                    const int nbN = mp[okN ? fcell - S : fcell], nbS = mp[okS ? fcell + S : fcell];
-                    const int nbW = mp[okW ? fcell - 1 : fcell], nbE = mp[okE ? fcell + 1 : fcell];
+                    int nbN = mp[okN ? fcell - S : fcell], nbS = mp[okS ? fcell + S : fcell];
+                    int nbW = mp[okW ? fcell - 1 : fcell], nbE = mp[okE ? fcell + 1 : fcell];
                                         const int fr2 = fr + dr, fc2 = fc + dc;                        // two cells ahead (Jump)
                     const bool ok2 = fr2 >= 0 && fr2 <= S - 1 && fc2 >= 0 && fc2 <= S - 1;
-                    const int front2 = mp[ok2 ? fr2 * S + fc2 : fcell];
-                    const int inv_place = inv[place_item], inv_ext = inv[ext_out], inv_axe = inv[axe_item];
+                    int front2 = mp[ok2 ? fr2 * S + fc2 : fcell];
+                    int inv_place = inv[place_item], inv_ext = inv[ext_out], inv_axe = inv[axe_item];
+                    // (LLVM sinks a load into the only branch that uses it, which would put one LDS latency back into
+                    //  every divergent case; the empty asm makes each value "used" here, so the reads stay together)
+                    { int p0 = (int)d0, p1 = (int)d1, p2 = (int)d2, p3 = (int)d3, p4 = (int)d4;
+                      PIN_V(p0); PIN_V(p1); PIN_V(p2); PIN_V(p3); PIN_V(p4); }
                     // ---------------- L1: reads whose address came out of L0
                     const int kind = d0 & 255, aarg = (d0 >> 8) & 255, nin = (d0 >> 16) & 255;
                     const int in0 = d1 & 255, in1 = (d1 >> 8) & 255, in2 = (d1 >> 16) & 255, in3 = d1 >> 24;
                     const int out_item = d3 & 255;
-                    const int inv_front = inv[front];
-                    const int inv_arg = inv[min(aarg, K - 1)];
-                    const int iv0 = inv[in0], iv1 = inv[in1], iv2 = inv[in2], iv3 = inv[in3], inv_out = inv[out_item];
+                    int inv_front = inv[front];
+                    int inv_arg = inv[min(aarg, K - 1)];
+                    int iv0 = inv[in0], iv1 = inv[in1], iv2 = inv[in2], iv3 = inv[in3], inv_out = inv[out_item];
+                    PIN_V(inv_front); PIN_V(inv_arg); PIN_V(iv0); PIN_V(iv1); PIN_V(iv2);
+                    PIN_V(iv3); PIN_V(inv_out); PIN_V(front2); PIN_V(nbN); PIN_V(nbS);
+                    PIN_V(nbW); PIN_V(nbE); PIN_V(inv_place); PIN_V(inv_ext); PIN_V(inv_axe);
                     // ---------------- register-only bodies
                     int rew = reward_step, result = 1, cost = 0, msg = NGW_MSG_NONE, arg = 0;   // :239-242
                     switch (kind) {
