@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     int32_t* lds_inv = reinterpret_cast<int32_t*>(lds + a.off_inv);
     uint32_t* lds_cand = lds + a.off_cand;
     const uint32_t* lds_act = lds + a.off_act;
-    const NgwStepU U = dspec->u;                                                   // uniform: ONE scalar load, kept in SGPRs
+    const NgwStepU& U = a.u;                                                       // uniform: scalar loads from the kernarg segment
     int8_t* mp = reinterpret_cast<int8_t*>(lds_map) + tid * a.MS;                 // this lane's map
     int32_t* inv = lds_inv + tid * a.KP;                                           // this lane's inventory row
     uint32_t* cand = lds_cand + tid;
