@@ -243,7 +243,7 @@ class VecNovelGridworld:
         return ms.value
 
     def graph_build(self, actions_ptr, step_stride, n_steps):
-        """Capture n_steps (even) step_device launches reading actions_ptr + i * step_stride into one hipGraph."""
+        """Capture n_steps step_device launches reading actions_ptr + i * step_stride (int32 elements) into one hipGraph."""
         _cabi.check(_cabi.lib().ngw_graph_build(self._h, C.c_void_p(int(actions_ptr)), int(step_stride), int(n_steps)))
 
     def graph_launch(self, reps=1):
