@@ -10,7 +10,7 @@ import numpy as np
 from .spec import NgwSpec
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libngw_hip.so')
+LIB_PATH = os.environ.get('NGW_LIB') or os.path.join(_HERE, 'libngw_hip.so')   # NGW_LIB: A/B builds while tuning
 
 E_INVALID_ARG, E_HIP, E_INVALID_ACTION, E_PLACEMENT, E_NO_DEVICE = -1, -2, -3, -4, -5
 

@@ -246,8 +246,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
         memset(&hs, 0, sizeof(hs));
         hs.sp = *spec;
         for (int i = 0; i < 32; i++) hs.addq[i] = (double)(spec->additem_pct_lo + i) / 100.0;
-        NgwStepU& u = h->proto.u;
-        memset(&u, 0, sizeof(u));
+        NgwStepU& u = hs.u;
         for (int i = 0; i < K; i++) {
             if (spec->breakable[i]) u.brk_mask |= 1u << i;
             if (spec->entity[i]) u.ent_mask |= 1u << i;

@@ -31,23 +31,8 @@ struct NgwBufs {
     uint16_t* perm;       /* [S*S][n_pad] AddItem shuffle scratch, or nullptr */
 };
 
-/* Uniform step parameters: every lane uses the same value, so the kernel reads them with SCALAR loads straight
- * from the HBM blob (no LDS latency in the step's dependency chain). */
-struct NgwStepU {
-    uint32_t brk_mask, ent_mask, rew_mask;  /* bit i: item i is breakable / an entity / gives break_reward when broken */
-    uint32_t brk2_mask;                     /* bit i: breaking item i without an axe yields 2 (BreakIncrease) */
-    /* every field below is a plain 32-bit scalar on purpose: the step kernel gets it with one s_load from the kernarg
-     * segment (the struct travels BY VALUE inside NgwLaunch) - no pointer chase, no byte extraction */
-    int32_t n_actions, reward_step, reward_done, craft_reward, break_reward;
-    int32_t cost_forward, cost_turn, cost_break, cost_place, cost_extract, cost_select, table_item, goal_item;
-    int32_t place_item, place_near, n_entities, ext_src, ext_near, ext_out, ext_qty, ext_consume;
-    int32_t ext_cost_ok, axe_item, axe_cost, axe_qty, cost_chop, cost_jump, chop_reward;
-    int32_t place_reward, ext_reward, axe_reward, axe_required;
-};
-
 struct NgwLaunch {
     NgwBufs b;
-    NgwStepU u;                  /* uniform step parameters, by value */
     int64_t n, n_pad, env_base, t0;
     uint64_t seed, action_seed;
     const int32_t* actions;      /* device, NGW_MODE_STEP */
@@ -68,6 +53,22 @@ struct NgwLaunch {
     uint32_t off_inv, off_cand, off_act;    /* LDS dword offsets */
 };
 
+/* Uniform step parameters: every lane uses the same value, so the kernel reads them with SCALAR loads straight
+ * from the HBM blob (no LDS latency in the step's dependency chain). */
+struct NgwStepU {
+    uint32_t brk_mask, ent_mask, rew_mask;  /* bit i: item i is breakable / an entity / gives break_reward when broken */
+    uint32_t brk2_mask;                     /* bit i: breaking item i without an axe yields 2 (BreakIncrease) */
+    int32_t n_actions, reward_step, reward_done, craft_reward, break_reward;
+    uint8_t cost_forward, cost_turn, cost_break, cost_place, cost_extract, cost_select, table_item, goal_item;
+    uint8_t place_item, place_near, n_entities, ext_src, ext_near, ext_out, ext_qty, ext_consume;
+    uint8_t ext_cost_ok, axe_item, axe_cost, axe_qty;
+    uint8_t cost_chop, cost_jump;
+    int8_t chop_reward;
+    uint8_t _pad;
+    int8_t place_reward, ext_reward, axe_reward;
+    uint8_t axe_required;                   /* AxetoBreak*: Break fails without the selected axe */
+};
+
 /* Per-action descriptor, NGW_ACT_DW dwords, copied to LDS (the only lane-varying LUT of the step):
  *   d0 = kind | arg<<8 | n_inputs<<16 | needs_table<<24      d1 = input item ids (4 bytes, dict order)
  *   d2 = input quantities (4 bytes)                          d3 = out_item | out_qty<<8 | cost_missing<<16 | cost_no_table<<24
@@ -77,6 +78,7 @@ struct NgwLaunch {
 /* Blob kept in HBM (one per handle). */
 #define NGW_MAX_PLACE 64            /* items placed by one reset (sum of items_quantity); reference: 6-7 */
 struct NgwDevSpec {
+    NgwStepU u;
     /* --- the two tables below are contiguous: 256 dwords copied to LDS by every wavefront */
     uint32_t act_desc[NGW_MAX_ACTIONS * NGW_ACT_DW];
     uint8_t place_seq[NGW_MAX_PLACE];   /* item id of the n-th placement of a reset (items_quantity flattened in order) */

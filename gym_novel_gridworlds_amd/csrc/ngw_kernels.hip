@@ -15,7 +15,11 @@
 // Semantics follow the reference line by line (citations at each branch):
 //   gym_novel_gridworlds/envs/pogostick_v1_env.py  reset :86-181, step :230-367, craft :413-474, grab :538-554
 //   gym_novel_gridworlds/envs/bow_v1_env.py        Extract_string :293-304, craft :386-441
-//   gym_novel_gridworlds/novelty_wrappers.py       AxeEasy :9-114, AxeMedium :117-213, AddItem :991-1034
+//   gym_novel_gridworlds/novelty_wrappers.py       AxeEasy :9-114, AxeMedium :117-213, AddItem :991-1034,
+//                                                  AxetoBreak :439-625, AddChop :1267-1337, AddJump :1340-1412,
+//                                                  BreakIncrease :1415-1488, ExtractIncDec :1491-1581
+//   gym_novel_gridworlds/envs/pogostick_v0_env.py  tree_tap reset pass :156-178
+//   gym_novel_gridworlds/observation_wrappers.py   LidarInFront :10-80 (ngw_lidar_kernel and the fused epilogue)
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -413,7 +417,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     int32_t* lds_inv = reinterpret_cast<int32_t*>(lds + a.off_inv);
     uint32_t* lds_cand = lds + a.off_cand;
     const uint32_t* lds_act = lds + a.off_act;
-    const NgwStepU& U = a.u;                                                       // uniform: scalar loads from the kernarg segment
+    const NgwStepU U = dspec->u;                                                   // uniform: ONE scalar load, kept in SGPRs
     int8_t* mp = reinterpret_cast<int8_t*>(lds_map) + tid * a.MS;                 // this lane's map
     int32_t* inv = lds_inv + tid * a.KP;                                           // this lane's inventory row
     uint32_t* cand = lds_cand + tid;
@@ -480,7 +484,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     uint32_t aw0 = 0, aw1 = 0, aw2 = 0, aw3 = 0;                                   // rollout: 4 actions per Philox block
 
     // ---- everything the step loop needs, fetched once and pinned in registers
-    // per-lane output addresses for both ping-pong parities (VGPR pairs; 1 wave per SIMD leaves plenty)
+    // per-lane output addresses (VGPR pairs; 1 wave per SIMD leaves plenty)
     g_u32x4* gmap = (g_u32x4*)(reinterpret_cast<u32x4*>(a.b.map + env0 * a.S2) + tid);     // coalesced chunk (reset only)
     g_u32x4* ginv = (g_u32x4*)(reinterpret_cast<u32x4*>(a.b.inv + env0 * K) + tid);
     GLOBAL_AS int8_t* gm = (GLOBAL_AS int8_t*)(a.b.map + e * a.S2);                      // this env's map / inventory row
