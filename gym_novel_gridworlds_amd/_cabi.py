@@ -20,7 +20,7 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_get_obs', 'ngw_get_step_out', 'ngw_get_state', 'ngw_set_state', 'ngw_obs_device_ptrs',
            'ngw_out_device_ptrs', 'ngw_sync', 'ngw_error_flags', 'ngw_timing_begin', 'ngw_timing_end',
            'ngw_graph_build', 'ngw_graph_launch', 'ngw_lidar_configure', 'ngw_lidar', 'ngw_lidar_fuse',
-           'ngw_get_lidar', 'ngw_lidar_device_ptr']
+           'ngw_get_lidar', 'ngw_lidar_device_ptr', 'ngw_host_alloc', 'ngw_host_free']
 
 _lib = None
 
@@ -29,13 +29,26 @@ class NgwError(RuntimeError):
     pass
 
 
+_PTR_CACHE = {}      # id(array) -> (weakref, address): `arr.ctypes` costs ~40 us on arrays over foreign (pinned) buffers
+
+
 def _ptr(arr, dtype):
     """Host pointer of a C-contiguous ndarray of `dtype`, or NULL for None."""
     if arr is None:
         return None
+    ent = _PTR_CACHE.get(id(arr))
+    if ent is not None and ent[0]() is arr:
+        return ent[1]
     assert isinstance(arr, np.ndarray) and arr.dtype == dtype and arr.flags['C_CONTIGUOUS'], \
         "expected a C-contiguous %s array" % np.dtype(dtype).name
-    return arr.ctypes.data_as(C.c_void_p)
+    addr = C.c_void_p(arr.__array_interface__['data'][0])
+    if arr.base is not None and len(_PTR_CACHE) < 4096:        # long-lived views (the env's own buffers): remember
+        import weakref
+        try:
+            _PTR_CACHE[id(arr)] = (weakref.ref(arr, lambda _r, k=id(arr): _PTR_CACHE.pop(k, None)), addr)
+        except TypeError:
+            pass
+    return addr
 
 
 def lib():
@@ -83,10 +96,37 @@ def lib():
     L.ngw_lidar_fuse.argtypes = [vp, C.c_int]
     L.ngw_get_lidar.argtypes = [vp, vp]
     L.ngw_lidar_device_ptr.argtypes = [vp, C.POINTER(vp)]
+    L.ngw_host_alloc.argtypes = [u64]
+    L.ngw_host_alloc.restype = vp
+    L.ngw_host_free.argtypes = [vp]
     if L.ngw_spec_size() != C.sizeof(NgwSpec):
         raise NgwError("ngw_spec layout mismatch: library %d bytes, binding %d bytes" % (L.ngw_spec_size(), C.sizeof(NgwSpec)))
     _lib = L
     return L
+
+
+def pinned_array(shape, dtype):
+    """numpy array over page-locked host memory (freed with the array); falls back to np.zeros if pinning fails."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    p = lib().ngw_host_alloc(n)
+    if not p:
+        return np.zeros(shape, dt)
+    buf = (C.c_char * max(n, 1)).from_address(p)
+    arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+    _PINNED[id(buf)] = (buf, p)
+    import weakref
+    weakref.finalize(arr, _free_pinned, id(buf))
+    return arr
+
+
+_PINNED = {}
+
+
+def _free_pinned(key):
+    ent = _PINNED.pop(key, None)
+    if ent is not None and _lib is not None:
+        _lib.ngw_host_free(C.c_void_p(ent[1]))
 
 
 def last_error():

@@ -503,6 +503,18 @@ int ngw_set_state(ngw_handle* h, int64_t first, int64_t count, const int8_t* map
     return NGW_OK;
 }
 
+void* ngw_host_alloc(uint64_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fail(NGW_E_HIP, "hipHostMalloc(%llu) failed", (unsigned long long)bytes); return nullptr; }
+    memset(p, 0, bytes);
+    return p;
+}
+
+int ngw_host_free(void* p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return NGW_OK;
+}
+
 int ngw_obs_device_ptrs(ngw_handle* h, void** map, void** loc, void** facing, void** inv) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     if (map) *map = h->b.map;

@@ -54,10 +54,12 @@ class VecNovelGridworld:
         self.autoreset, self.horizon = bool(autoreset), int(horizon)
         _cabi.check(L.ngw_set_autoreset(self._h, int(self.autoreset), self.horizon))
         N, S, K = self.num_envs, self.map_size, self.n_items
-        self._obs = {'map': np.zeros((N, S, S), np.int8), 'agent_location': np.zeros((N, 2), np.int32),
-                     'agent_facing_id': np.zeros(N, np.int32), 'inventory_items_quantity': np.zeros((N, K), np.int32)}
-        self._reward = np.zeros(N, np.int32)
-        self._done = np.zeros(N, np.uint8)
+        pin = _cabi.pinned_array                              # page-locked: D2H / H2D at full PCIe rate (API mode)
+        self._obs = {'map': pin((N, S, S), np.int8), 'agent_location': pin((N, 2), np.int32),
+                     'agent_facing_id': pin((N,), np.int32), 'inventory_items_quantity': pin((N, K), np.int32)}
+        self._reward = pin((N,), np.int32)
+        self._done = pin((N,), np.uint8)
+        self._act_pinned = pin((N,), np.int32)
         self._result = np.zeros(N, np.uint8)
         self._cost = np.zeros(N, np.uint8)
         self._msg = np.zeros(N, np.uint16)
@@ -100,7 +102,8 @@ class VecNovelGridworld:
         `messages(info, actions)` formats the reference's strings lazily."""
         a = np.ascontiguousarray(actions, np.int32)
         assert a.shape == (self.num_envs,)
-        _cabi.check(_cabi.lib().ngw_step(self._h, _cabi._ptr(a, np.int32)))
+        self._act_pinned[...] = a
+        _cabi.check(_cabi.lib().ngw_step(self._h, _cabi._ptr(self._act_pinned, np.int32)))
         self._last_actions = a
         obs = self.get_observation(copy)
         reward, done, info = self.get_step_out(copy)

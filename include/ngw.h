@@ -194,6 +194,11 @@ int ngw_set_state(ngw_handle* h, int64_t first, int64_t count, const int8_t* map
                   const int32_t* facing, const int32_t* inv, const int32_t* selected,
                   const int32_t* step_count, const uint32_t* episode);
 
+/* Page-locked host memory for the arrays handed to ngw_step / ngw_get_obs / ngw_get_step_out: copies to and from
+ * pinned buffers run at full PCIe rate without a staging pass (API mode).  Plain malloc'ed arrays work too. */
+void* ngw_host_alloc(uint64_t bytes);
+int ngw_host_free(void* p);
+
 /* Device pointers of the observation / output buffers (fixed for the handle's lifetime; contents are the state
  * after the last enqueued step and are updated in place by the next one). */
 int ngw_obs_device_ptrs(ngw_handle* h, void** map, void** loc, void** facing, void** inv);
