@@ -10,10 +10,10 @@ reference's gym.Env surface.  Everything computes in hand-written HIP kernels re
 from .envs import ENTRY_POINTS, BowV0Env, BowV1Env, PogostickV0Env, PogostickV1Env, make   # noqa: F401
 from .novelty import NOVELTY_NAMES, apply_novelty                    # noqa: F401
 from .novelty_wrappers import inject_novelty                         # noqa: F401
-from .observation_wrappers import LidarInFront                      # noqa: F401
+from .observation_wrappers import AgentMap, LidarInFront                    # noqa: F401
 from .spec import ENV_IDS, STEP_COSTS, EnvSpec, make_spec            # noqa: F401
 from .vec_env import VecNovelGridworld                               # noqa: F401
-from .wrappers import LimitActions, limit_actions_vec                # noqa: F401
+from .wrappers import LimitActions, SaveTrajectories, limit_actions_vec             # noqa: F401
 
 __version__ = '0.1.0'
 

@@ -20,7 +20,8 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_get_obs', 'ngw_get_step_out', 'ngw_get_state', 'ngw_set_state', 'ngw_obs_device_ptrs',
            'ngw_out_device_ptrs', 'ngw_sync', 'ngw_error_flags', 'ngw_timing_begin', 'ngw_timing_end',
            'ngw_graph_build', 'ngw_graph_launch', 'ngw_lidar_configure', 'ngw_lidar', 'ngw_lidar_fuse',
-           'ngw_get_lidar', 'ngw_lidar_device_ptr', 'ngw_host_alloc', 'ngw_host_free']
+           'ngw_get_lidar', 'ngw_lidar_device_ptr', 'ngw_host_alloc', 'ngw_host_free', 'ngw_agent_view',
+           'ngw_get_agent_view', 'ngw_agent_view_device_ptr']
 
 _lib = None
 
@@ -96,6 +97,9 @@ def lib():
     L.ngw_lidar_fuse.argtypes = [vp, C.c_int]
     L.ngw_get_lidar.argtypes = [vp, vp]
     L.ngw_lidar_device_ptr.argtypes = [vp, C.POINTER(vp)]
+    L.ngw_agent_view.argtypes = [vp, C.c_int]
+    L.ngw_get_agent_view.argtypes = [vp, vp]
+    L.ngw_agent_view_device_ptr.argtypes = [vp, C.POINTER(vp)]
     L.ngw_host_alloc.argtypes = [u64]
     L.ngw_host_alloc.restype = vp
     L.ngw_host_free.argtypes = [vp]

@@ -58,6 +58,8 @@ struct ngw_handle {
     uint32_t lidar_magic = 0, lidar_off_tab = 0, lidar_off_tile = 0, lidar_off_map = 0;
     int lidar_fused = 0, lidar_range = 0, lidar_beams = 0, lidar_chan = 0, lidar_ninv = 0;
     size_t lidar_lds = 0;
+    int8_t* view_out = nullptr;           // AgentMap windows
+    int view_size = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_steps = 0;
@@ -624,6 +626,39 @@ int ngw_get_lidar(ngw_handle* h, int32_t* out_host) {
 int ngw_lidar_device_ptr(ngw_handle* h, void** out) {
     if (!h || !out) return fail(NGW_E_INVALID_ARG, "NULL argument");
     *out = h->lidar_out;
+    return NGW_OK;
+}
+
+int ngw_agent_view(ngw_handle* h, int view_size) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (view_size < 1 || view_size > 127) return fail(NGW_E_INVALID_ARG, "view_size must be in 1..127");   // :99 'Increase the agent_view_size'
+    const size_t W = 2 * (size_t)view_size + 1, bytes = (size_t)h->n * W * W;
+    if (bytes + 4 > 0xffffffffull) return fail(NGW_E_INVALID_ARG, "agent view of %zu B exceeds the 4 GiB index range", bytes);
+    HIP_TRY(hipSetDevice(h->device));
+    if (view_size != h->view_size) {
+        h->view_size = 0;
+        if (int rc = dev_alloc(h, &h->view_out, (bytes + 3) / 4 * 4)) return rc;
+        h->view_size = view_size;
+    }
+    HIP_TRY(ngw_agent_view_launch(h->b.map, h->b.loc, reinterpret_cast<uint32_t*>(h->view_out), (uint32_t)((bytes + 3) / 4),
+                                  h->proto.S, view_size, h->stream));
+    return NGW_OK;
+}
+
+int ngw_get_agent_view(ngw_handle* h, int8_t* out_host) {
+    if (!h || !out_host) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    if (!h->view_size) return fail(NGW_E_INVALID_ARG, "ngw_get_agent_view before ngw_agent_view");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t W = 2 * (size_t)h->view_size + 1;
+    HIP_TRY(hipMemcpyAsync(out_host, h->view_out, (size_t)h->n * W * W, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NGW_OK;
+}
+
+int ngw_agent_view_device_ptr(ngw_handle* h, void** out) {
+    if (!h || !out) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    if (!h->view_size) return fail(NGW_E_INVALID_ARG, "ngw_agent_view_device_ptr before ngw_agent_view");
+    *out = h->view_out;
     return NGW_OK;
 }
 

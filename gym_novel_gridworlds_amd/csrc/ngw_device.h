@@ -104,6 +104,12 @@ struct NgwLidarDev {
 #ifdef __cplusplus
 extern "C"
 #endif
+/* AgentMap window gather: out = [n][2V+1][2V+1] int8 packed as n_dwords dwords */
+hipError_t ngw_agent_view_launch(const int8_t* map, const int32_t* loc, uint32_t* out, uint32_t n_dwords, int S, int V,
+                                 hipStream_t stream);
+#ifdef __cplusplus
+extern "C"
+#endif
 hipError_t ngw_lidar_launch(const NgwLidarDev* cfg, const NgwLaunch* a, int map_mode, int32_t* out, int L, uint32_t off_map,
                             uint32_t off_tab, uint32_t off_tile, unsigned grid, size_t lds_bytes, hipStream_t stream);
 

@@ -825,7 +825,41 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const NgwLidarDev* _
     for (int p = tid; p < 16 * L; p += EPB) g4[p] = t4[p];
 }
 
+// AgentMap (reference observation_wrappers.py:104-121): the (2V+1) x (2V+1) window of the map centred on the agent, 0 outside
+// the map.  HBM-bound byte gather: one lane produces 4 consecutive output bytes (one coalesced dword store); the map reads
+// hit each env's 100-B row image, which one wave covers with a handful of cache lines.
+__global__ __launch_bounds__(256) void ngw_agent_view_kernel(const int8_t* __restrict__ map, const int32_t* __restrict__ loc,
+                                                             uint32_t* __restrict__ out, uint32_t n_dwords, int S, int V,
+                                                             uint32_t magicW) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_dwords) return;
+    const uint32_t W = 2u * (uint32_t)V + 1u, WW = W * W;
+    uint32_t idx = t * 4u;
+    uint32_t e = idx / WW;                           // one full division per lane; the rest are small-operand magics
+    uint32_t rem = idx - e * WW;
+    uint32_t word = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t r = __umulhi(rem, magicW), c = rem - r * W;
+        const int mr = loc[2 * (size_t)e] + (int)r - V, mc = loc[2 * (size_t)e + 1] + (int)c - V;
+        uint32_t v = 0;
+        if ((unsigned)mr < (unsigned)S && (unsigned)mc < (unsigned)S) v = (uint8_t)map[(size_t)e * (S * S) + mr * S + mc];
+        word |= v << (8 * j);
+        if (++rem == WW) { rem = 0; ++e; }
+    }
+    out[t] = word;
+}
+
 }  // namespace
+
+extern "C" hipError_t ngw_agent_view_launch(const int8_t* map, const int32_t* loc, uint32_t* out, uint32_t n_dwords, int S, int V,
+                                            hipStream_t stream) {
+    const uint32_t W = 2u * (uint32_t)V + 1u;
+    const uint32_t magicW = (uint32_t)((0x100000000ull + W - 1) / W);     // exact for operands < W * W
+    hipLaunchKernelGGL(ngw_agent_view_kernel, dim3((n_dwords + 255u) / 256u), dim3(256), 0, stream, map, loc, out, n_dwords, S, V,
+                       magicW);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t ngw_lidar_launch(const NgwLidarDev* cfg, const NgwLaunch* a, int map_mode, int32_t* out, int L,
                                        uint32_t off_map, uint32_t off_tab, uint32_t off_tile, unsigned grid, size_t lds_bytes,

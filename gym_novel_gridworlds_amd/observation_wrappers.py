@@ -4,7 +4,10 @@
 np.array of ints from reset()/step()) and on `VecNovelGridworld` (returns int32 [N, L] batches computed by the
 `ngw_lidar_kernel`).  As in the reference, the set of lidar items and the beam range are fixed when the wrapper is
 constructed, while the appended inventory follows the env's current items - so a novelty injected AFTER wrapping adds
-an inventory entry but no lidar channel (tests/random_action.py:24-42 order)."""
+an inventory entry but no lidar channel (tests/random_action.py:24-42 order).
+
+`AgentMap(env)` (reference :83-129): the 11 x 11 window of the map around the agent (agent_view_size = 5, 0 outside the
+map) + agent_facing_id + inventory_items_quantity; the window is gathered by `ngw_agent_view_kernel`."""
 import numpy as np
 
 from . import spaces
@@ -69,3 +72,50 @@ class LidarInFront(NoveltyWrapper):
             self._ensure(self._vec)
         _, reward, done, info = self.env.step(action)
         return self.observation(), reward, done, info
+
+
+class AgentMap(NoveltyWrapper):
+    def __init__(self, env):
+        super().__init__(env)
+        self.max_items = 20                                                  # observation_wrappers.py:95-96
+        self.agent_view_size = 5
+        self._vec = env if isinstance(env, VecNovelGridworld) else None
+        items = env.spec.items if self._vec is not None else self.env.items
+        assert not self.max_items < len(items), "Cannot have more than " + str(self.max_items) + " items"
+        assert self.agent_view_size >= 1, "Increase the agent_view_size"
+        # the reference declares (5, 5, 1) although get_agentView returns (11, 11) (:101-102 vs :104-121); kept as declared
+        self.observation_space = spaces.Box(low=0, high=self.max_items,
+                                            shape=(self.agent_view_size, self.agent_view_size, 1))
+        self.observation_space = spaces.Dict({'agent_map': self.observation_space})
+
+    def _base(self):
+        env = self.env
+        while isinstance(env, NoveltyWrapper):
+            env = env.env
+        return env
+
+    def get_agentView(self):
+        """Local view of the agent (:104-121): single env -> int64 [11, 11] like the reference's np.full window; batched
+        env -> int8 [N, 11, 11]."""
+        if self._vec is not None:
+            return self._vec.agent_view(self.agent_view_size, copy=True)
+        base = self._base()
+        vec = base._backend()
+        base._push(vec)                     # host attributes are the truth between calls (envs.py)
+        return vec.agent_view(self.agent_view_size)[0].astype(np.int64)
+
+    def observation(self, obs=None):
+        if self._vec is not None:
+            cur = self._vec.get_observation() if obs is None else obs
+            return {'agent_map': self.get_agentView(), 'agent_facing_id': cur['agent_facing_id'],
+                    'inventory_items_quantity': cur['inventory_items_quantity']}
+        return {'agent_map': self.get_agentView(), 'agent_facing_id': self.env.agent_facing_id,           # :123-129
+                'inventory_items_quantity': self.env.inventory_items_quantity}
+
+    def reset(self, **kwargs):
+        obs = self.env.reset(**kwargs)
+        return self.observation(obs if self._vec is not None else None)
+
+    def step(self, action):
+        obs, reward, done, info = self.env.step(action)
+        return self.observation(obs if self._vec is not None else None), reward, done, info

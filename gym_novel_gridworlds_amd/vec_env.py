@@ -251,3 +251,19 @@ class VecNovelGridworld:
 
     def graph_launch(self, reps=1):
         _cabi.check(_cabi.lib().ngw_graph_launch(self._h, int(reps)))
+
+    def agent_view(self, view_size=5, device=False, copy=False):
+        """AgentMap window (reference observation_wrappers.py:104-121): int8 [N, 2*view_size+1, 2*view_size+1], the map
+        around each agent with 0 outside the map; one gather launch on the current state."""
+        _cabi.check(_cabi.lib().ngw_agent_view(self._h, int(view_size)))
+        W = 2 * int(view_size) + 1
+        if device:
+            import torch
+            p = C.c_void_p()
+            _cabi.check(_cabi.lib().ngw_agent_view_device_ptr(self._h, C.byref(p)))
+            return torch.as_tensor(_DevArray(p.value, (self.num_envs, W, W), '|i1'), device='cuda:%d' % self.device)
+        host = getattr(self, '_view_host', None)
+        if host is None or host.shape[1] != W:
+            host = self._view_host = np.zeros((self.num_envs, W, W), np.int8)
+        _cabi.check(_cabi.lib().ngw_get_agent_view(self._h, _cabi._ptr(host, np.int8)))
+        return host.copy() if copy else host

@@ -1,4 +1,4 @@
-"""`LimitActions` with the reference's call shape (gym_novel_gridworlds/wrappers.py:57-85).
+"""`SaveTrajectories` (gym_novel_gridworlds/wrappers.py:9-54) and `LimitActions` (:57-85) with the reference's call shape.
 
     env = LimitActions(env, {'Forward', 'Left', 'Right', 'Break', 'Craft_plank'})
 
@@ -7,12 +7,48 @@ On the single-env adapter it forwards like the reference wrapper (same Assertion
 `VecNovelGridworld` it compiles the limited table INTO the kernel's action LUT (a new batched env whose action ids are
 the limited ids), so there is no per-step translation at all."""
 import copy
+import os
+import pickle
+from datetime import datetime
 
 import numpy as np
 
 from . import spaces
 from .novelty_wrappers import NoveltyWrapper
 from .vec_env import VecNovelGridworld
+
+
+class SaveTrajectories(NoveltyWrapper):
+    """Reference wrappers.py:9-54: after every step append a snapshot of the env's state; `save()` pickles the list to
+    `<save_path>/<timestamp>_<env_id>.bin`.  Host-side bookkeeping over the single-env adapter's attributes (the values
+    are references to the live objects, exactly as in the reference, so entries alias `env.map` until it is rebound)."""
+
+    def __init__(self, env, save_path):
+        super().__init__(env)
+        self.save_path = save_path
+        os.makedirs(self.save_path, exist_ok=True)
+        self.state_trajectories = []
+
+    def step(self, action_id):
+        obs, reward, done, info = self.env.step(action_id)
+        self.state_trajectories.append(self.get_state())
+        return obs, reward, done, info
+
+    def get_state(self):
+        env = self.env
+        return {"map_size": env.map_size, "map": env.map, "agent_location": env.agent_location,           # :29-45
+                "agent_facing_str": env.agent_facing_str, "block_in_front_id": env.block_in_front_id,
+                "items_id": env.items_id, "items_quantity": env.items_quantity,
+                "inventory_items_quantity": env.inventory_items_quantity,
+                "action_str": env.actions_id, "last_action": env.last_action, "last_done": self.last_done}
+
+    def save(self):
+        path = os.path.join(self.save_path,
+                            datetime.now().strftime("%Y-%m-%d-%H-%M-%S") + "_{env}.bin".format(env=self.env.env_id))
+        with open(path, 'wb') as f:
+            pickle.dump(self.state_trajectories, f)
+        print("Trajectories saved at: ", path)
+        return path
 
 
 class LimitActions(NoveltyWrapper):

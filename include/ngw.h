@@ -227,6 +227,14 @@ int ngw_lidar_fuse(ngw_handle* h, int enable);
 int ngw_get_lidar(ngw_handle* h, int32_t* out_host);
 int ngw_lidar_device_ptr(ngw_handle* h, void** out);
 
+/* AgentMap (observation_wrappers.py:83-129): ngw_agent_view() gathers, for every env, the (2*view_size+1)^2 window of the
+ * CURRENT map centred on the agent (0 outside the map; get_agentView :104-121) into an internal int8
+ * [n_envs][2*view_size+1][2*view_size+1] buffer.  The reference fixes view_size = 5 (:96).  The other two entries of that
+ * wrapper's observation (agent_facing_id, inventory_items_quantity) are the ngw_get_obs buffers. */
+int ngw_agent_view(ngw_handle* h, int view_size);
+int ngw_get_agent_view(ngw_handle* h, int8_t* out_host);
+int ngw_agent_view_device_ptr(ngw_handle* h, void** out);
+
 #ifdef __cplusplus
 }
 #endif

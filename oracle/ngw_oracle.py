@@ -73,6 +73,24 @@ def lidar(ccfg, S, K, map_, loc, facing, inv):
     return out
 
 
+def agent_view(map_, loc, view_size=5):
+    """AgentMap.get_agentView for n states (reference observation_wrappers.py:104-121): pad the map with `view_size`
+    zeros on every side and slice the (2 * view_size + 1)^2 window whose top-left corner, in padded coordinates, is the
+    agent location.  int8 [n, W, W]."""
+    m = np.asarray(map_, np.int8)
+    n = m.shape[0]
+    S = m.shape[-1] if m.ndim == 3 else int(round((m.size // max(n, 1)) ** 0.5))
+    m = m.reshape(n, S, S)
+    V, W = int(view_size), 2 * int(view_size) + 1
+    ext = np.zeros((n, S + 2 * V, S + 2 * V), np.int8)
+    ext[:, V:V + S, V:V + S] = m
+    out = np.empty((n, W, W), np.int8)
+    for e in range(n):
+        r, c = int(loc[e][0]), int(loc[e][1])
+        out[e] = ext[e, r:r + W, c:c + W]
+    return out
+
+
 class MT19937:
     """numpy-legacy global stream: np.random.seed(int) + raw words / bounded draws."""
 

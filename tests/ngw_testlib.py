@@ -312,6 +312,10 @@ class OracleVec:
         self.lidar = lidar_config if lidar_config is not None else LidarConfig(self.spec, num_beams)
         self._lidar_c = self.lidar.compile(self.spec)
 
+    def agent_view(self, view_size=5, device=False, copy=False):
+        from oracle.ngw_oracle import agent_view
+        return agent_view(self.o.st.map, self.o.st.loc, view_size)
+
     def lidar_observation(self, device=False, copy=False):
         from oracle.ngw_oracle import lidar
         st = self.o.st
