@@ -79,9 +79,12 @@ int check_spec(const ngw_spec* s) {
     auto item_ok = [&](int i) { return i >= 0 && i < K; };
     if (!item_ok(s->wall_item) || !item_ok(s->table_item) || !item_ok(s->goal_item) || !item_ok(s->place_item) ||
         !item_ok(s->place_near) || !item_ok(s->ext_src) || !item_ok(s->ext_near) || !item_ok(s->ext_out) ||
-        !item_ok(s->axe_item) || !item_ok(s->additem_item) || !item_ok(s->inv_start_item) || !item_ok(s->tap_item) ||
+        !item_ok(s->axe_item) || !item_ok(s->additem_item) || !item_ok(s->tap_item) ||
         !item_ok(s->tap_near))
         return fail(NGW_E_INVALID_ARG, "spec item id out of range");
+    if (s->n_inv_start > NGW_MAX_INV_START) return fail(NGW_E_INVALID_ARG, "n_inv_start %d out of range", s->n_inv_start);
+    for (int j = 0; j < s->n_inv_start; j++)
+        if (!item_ok(s->inv_start_item[j]) || !s->inv_start_item[j]) return fail(NGW_E_INVALID_ARG, "inv_start_item[%d] out of range", j);
     for (int a = 0; a < s->n_actions; a++) {
         const int kind = s->act_kind[a], arg = s->act_arg[a];
         if (kind > NGW_ACT_JUMP) return fail(NGW_E_INVALID_ARG, "action %d has unknown kind %d", a, kind);
@@ -256,7 +259,6 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
             if (spec->break_qty[i] == 2) u.brk2_mask |= 1u << i;
         }
         u.n_actions = spec->n_actions; u.reward_step = spec->reward_step; u.reward_done = spec->reward_done;
-        u.craft_reward = spec->craft_reward;
         u.cost_forward = spec->cost_forward; u.cost_turn = spec->cost_turn; u.cost_break = spec->cost_break;
         u.cost_place = spec->cost_place; u.cost_extract = spec->cost_extract; u.cost_select = spec->cost_select;
         u.table_item = spec->table_item; u.goal_item = spec->goal_item;
@@ -283,7 +285,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
                 }
                 d[3] = spec->recipe_out_item[r] | ((uint32_t)spec->recipe_out_qty[r] << 8) |
                        ((uint32_t)spec->cost_missing[r] << 16) | ((uint32_t)spec->cost_no_table[r] << 24);
-                d[4] = spec->cost_ok[r];
+                d[4] = spec->cost_ok[r] | ((uint32_t)(uint8_t)spec->recipe_reward[r] << 8);
             }
         }
         if (hipMemcpyAsync(h->dspec, &hs, sizeof(hs), hipMemcpyHostToDevice, h->stream) != hipSuccess ||

@@ -58,7 +58,7 @@ struct NgwLaunch {
 struct NgwStepU {
     uint32_t brk_mask, ent_mask, rew_mask;  /* bit i: item i is breakable / an entity / gives break_reward when broken */
     uint32_t brk2_mask;                     /* bit i: breaking item i without an axe yields 2 (BreakIncrease) */
-    int32_t n_actions, reward_step, reward_done, craft_reward, break_reward;
+    int32_t n_actions, reward_step, reward_done, break_reward;
     uint8_t cost_forward, cost_turn, cost_break, cost_place, cost_extract, cost_select, table_item, goal_item;
     uint8_t place_item, place_near, n_entities, ext_src, ext_near, ext_out, ext_qty, ext_consume;
     uint8_t ext_cost_ok, axe_item, axe_cost, axe_qty;

@@ -211,7 +211,8 @@ __device__ __noinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t* mp
             additem_pass((GLOBAL_AS uint16_t*)(a.perm + env_local), a.n_pad, px, mp, a.S2, agent, item, span, addq);
         }
     }
-    if (sp.inv_start_item && !flags) inv[sp.inv_start_item] = sp.inv_start_qty;         // AxeEasy.reset :33
+    if (!flags)
+        for (int j = 0; j < sp.n_inv_start; j++) inv[sp.inv_start_item[j]] = sp.inv_start_qty[j];   // AxeEasy.reset :33, AxetoBreakHard.reset :667-670
     return flags | ((uint32_t)r_out << 8) | ((uint32_t)c_out << 16) | ((uint32_t)f_out << 24);
 }
 
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     // uniform step parameters, unpacked into scalars
     uint32_t brk_mask = U.brk_mask, ent_mask = U.ent_mask, rew_mask = U.rew_mask, brk2_mask = U.brk2_mask;
     int axe_required = U.axe_required, cost_chop = U.cost_chop, cost_jump = U.cost_jump, chop_reward = U.chop_reward;
-    int n_actions = U.n_actions, reward_step = U.reward_step, reward_done = U.reward_done, craft_reward = U.craft_reward;
+    int n_actions = U.n_actions, reward_step = U.reward_step, reward_done = U.reward_done;
     int break_reward = U.break_reward;
     int cost_forward = U.cost_forward, cost_turn = U.cost_turn, cost_break = U.cost_break, cost_place = U.cost_place;
     int cost_extract = U.cost_extract, cost_select = U.cost_select, table_item = U.table_item, goal_item = U.goal_item;
@@ -520,7 +521,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     int ext_cost_ok = U.ext_cost_ok, axe_item = U.axe_item, axe_cost = U.axe_cost, axe_qty = U.axe_qty;
     int place_reward = U.place_reward, ext_reward = U.ext_reward, axe_reward = U.axe_reward;
     PIN_S(brk_mask); PIN_S(ent_mask); PIN_S(rew_mask); PIN_S(brk2_mask); PIN_S(axe_required); PIN_S(cost_chop); PIN_S(cost_jump); PIN_S(chop_reward); PIN_S(n_actions); PIN_S(reward_step); PIN_S(reward_done);
-    PIN_S(craft_reward); PIN_S(break_reward); PIN_S(cost_forward); PIN_S(cost_turn); PIN_S(cost_break); PIN_S(cost_place);
+    PIN_S(break_reward); PIN_S(cost_forward); PIN_S(cost_turn); PIN_S(cost_break); PIN_S(cost_place);
     PIN_S(cost_extract); PIN_S(cost_select); PIN_S(table_item); PIN_S(goal_item); PIN_S(place_item); PIN_S(place_near);
     PIN_S(n_entities); PIN_S(ext_src); PIN_S(ext_near); PIN_S(ext_out); PIN_S(ext_qty); PIN_S(ext_consume);
     PIN_S(ext_cost_ok); PIN_S(axe_item); PIN_S(axe_cost); PIN_S(axe_qty); PIN_S(place_reward); PIN_S(ext_reward); PIN_S(axe_reward);
@@ -648,14 +649,14 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                         } else if (((d0 >> 24) & 1u) && front != table_item) {   // :444-453
                             result = 0; msg = NGW_MSG_NEED_TABLE; cost = d3 >> 24;
                         } else {                                                   // :455-474 (ids of a recipe are distinct)
-                            rew = craft_reward;
+                            rew = (int)(int8_t)(d4 >> 8);
                             if (nin > 0) { inv[in0] = iv0 - nd0; gi[in0] = iv0 - nd0; }
                             if (nin > 1) { inv[in1] = iv1 - nd1; gi[in1] = iv1 - nd1; }
                             if (nin > 2) { inv[in2] = iv2 - nd2; gi[in2] = iv2 - nd2; }
                             if (nin > 3) { inv[in3] = iv3 - nd3; gi[in3] = iv3 - nd3; }
                             const int nout = inv_out + (int)((d3 >> 8) & 255);
                             inv[out_item] = nout; gi[out_item] = nout;
-                            cost = (int)d4; msg = NGW_MSG_CRAFTED; arg = out_item;
+                            cost = (int)(d4 & 255u); msg = NGW_MSG_CRAFTED; arg = out_item;
                         }
                         break;
                     }

@@ -7,8 +7,8 @@ AxeMedium.__init__ :125-134, AxeEasy.__init__ :16-27, AddItem.__init__ :996-1011
 `EnvSpec`, which is then recompiled into the kernel LUTs.
 
 In scope: SURVEY.md §8(a) 'axe' (easy / medium) and 'additem'; §8(f) row 2 (LUT-only novelties) 'breakincrease',
-'extractincdec', 'axetobreak' (easy / medium), 'remapaction', 'addchop' and 'addjump'.  The rest ('crate', 'fence',
-'fencerestriction', 'firewall', 'replaceitem', 'axe'/'axetobreak' hard) validate like the reference and then raise
+'extractincdec', 'axetobreak', 'remapaction', 'addchop' and 'addjump'; 'axe' / 'axetobreak' hard (craftable axe).  The rest
+('crate', 'fence', 'fencerestriction', 'firewall', 'replaceitem') validate like the reference and then raise
 NotImplementedError.
 """
 
@@ -37,16 +37,16 @@ def apply_novelty(spec, novelty_name, difficulty='hard', novelty_arg1='', novelt
                 "For axe novelty, novelty_arg2 (breakincrease) must be 'true' or 'false'"               # :1607
             breakincrease = novelty_arg2
         if difficulty == 'hard':
-            raise NotImplementedError("axe/hard (craftable axe, novelty_wrappers.py:216) is outside this build's "
-                                      "hot-path scope (SURVEY.md §8(f) row 2)")
-        _axe(spec, difficulty, novelty_arg1, breakincrease)
+            _axe_hard(spec, novelty_arg1, breakincrease)
+        else:
+            _axe(spec, difficulty, novelty_arg1, breakincrease)
     elif novelty_name == 'axetobreak':
         assert novelty_arg1 in ['wooden', 'iron'], \
             "For axe novelty, novelty_arg1 (attribute of axe, e.g. wooden, iron) is needed"             # :1623
         if difficulty == 'hard':
-            raise NotImplementedError("axetobreak/hard (craftable axe, novelty_wrappers.py:627) is outside this build's "
-                                      "scope (SURVEY.md §8(f))")
-        _axe(spec, difficulty, novelty_arg1, 'false', required=True)
+            _axe_hard(spec, novelty_arg1, 'false', required=True)
+        else:
+            _axe(spec, difficulty, novelty_arg1, 'false', required=True)
     elif novelty_name == 'breakincrease':
         if novelty_arg1 and novelty_arg1 not in spec.items:
             # the reference's assert message dereferences env.itemtobreakmore, which does not exist (:1634, SURVEY
@@ -126,6 +126,40 @@ def _axe(spec, difficulty, axe_material, breakincrease, required=False):
     # +2 blocks with breakincrease; without it a breakable block gives -1 even for tree_log.
     # AxetoBreak* (required=True, :439-625): the same, but without the selected axe Break fails with
     # 'Cannot break without <axe> selected'.
+    spec.axe = dict(item=axe_name, cost=3600.0 * (0.5 if axe_material == 'wooden' else 0.25),
+                    qty=2 if breakincrease == 'true' else 1, required=required)
+
+
+def _axe_hard(spec, axe_material, breakincrease, required=False):
+    """AxeHard.__init__ (novelty_wrappers.py:225-258) / AxetoBreakHard.__init__ + reset (:636-672): the axe has to be
+    crafted ({'stick': 2, 'plank': 3} wooden / {'stick': 2, 'iron': 3} iron, at the crafting_table).  AxeHard scatters the
+    ingredients on the map; AxetoBreakHard puts them in the inventory at every reset.  Craft costs of the axe, from the
+    wrappers' own craft() (:288-353 / :694-758): 0 (int) when inputs are missing, 600.0 away from the table, 6000.0."""
+    axe_name = axe_material + '_axe'
+    spec.add_new_item(axe_name)
+    spec.entities.add(axe_name)
+    axe_recipe = {'stick': 2, 'plank': 3} if axe_material == 'wooden' else {'stick': 2, 'iron': 3}
+    if required:
+        for item in axe_recipe:                                    # :651-655 - ingredients start in the inventory
+            if item not in spec.items:
+                spec.add_new_item(item)
+        spec.start_inventory = dict(axe_recipe)                    # reset :667-670
+    else:
+        for item in axe_recipe:                                    # :241-250 - ingredients are placed on the map
+            if item in spec.items:
+                spec.items_quantity.update({item: spec.items_quantity.get(item, 0) + axe_recipe[item]})
+            else:
+                spec.add_new_item(item)                            # add_new_items (pogostick_v1_env.py:495-501)
+                spec.items_quantity.update({item: axe_recipe[item]})
+    spec.recipes.update({axe_name: {'input': axe_recipe, 'output': {axe_name: 1}}})
+    spec.craft_costs[axe_name] = (0, 600.0, 6000.0)
+    spec.recipe_rewards[axe_name] = spec.reward_intermediate       # the wrappers' craft() (:331 / :737), also in Bow
+    if not required:
+        spec.craft_actions_id.update({'Craft_' + axe_name: len(spec.actions_id)})   # :252 (AxetoBreakHard leaves this table alone, :658)
+    spec.actions_id.update({'Craft_' + axe_name: len(spec.actions_id)})
+    spec.add_select_action(axe_name)
+    spec.base_action_space_n = len(spec.actions_id)                # only the BASE env's action_space is re-made (:256 / :662);
+                                                                   # the wrapper keeps the copy it took before (action_space_n)
     spec.axe = dict(item=axe_name, cost=3600.0 * (0.5 if axe_material == 'wooden' else 0.25),
                     qty=2 if breakincrease == 'true' else 1, required=required)
 

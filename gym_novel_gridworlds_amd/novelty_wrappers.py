@@ -52,6 +52,15 @@ class AxeMedium(NoveltyWrapper):
     pass
 
 
+class AxeHard(NoveltyWrapper):
+    pass
+
+
+class AxetoBreakHard(NoveltyWrapper):
+    def reset(self):                                          # novelty_wrappers.py:664 takes no kwargs
+        return self.env.reset()
+
+
 class AxetoBreakEasy(NoveltyWrapper):
     pass
 
@@ -100,6 +109,17 @@ def inject_novelty(env, novelty_name, difficulty='hard', novelty_arg1='', novelt
     apply_novelty(spec, novelty_name, difficulty, novelty_arg1, novelty_arg2)     # validates like the reference
     for name in ('manipulation_actions_id', 'craft_actions_id', 'select_actions_id'):
         setattr(base, name, getattr(spec, name))                                  # remapaction re-binds these tables
+    if novelty_name in ('axe', 'axetobreak') and difficulty == 'hard':
+        from . import spaces
+        had_iron = 'iron' in base.inventory_items_quantity or novelty_arg1 != 'iron'
+        w = AxeHard(env) if novelty_name == 'axe' else AxetoBreakHard(env)     # copies the OLD action_space (gym.Wrapper.__init__)
+        base.action_space = spaces.Discrete(len(base.actions_id))              # :256 / :662 re-make the base env's space
+        base.inventory_items_quantity.update({novelty_arg1 + '_axe': 0})       # :230 / :643
+        if novelty_name == 'axetobreak':
+            base.inventory_items_quantity.update(spec.start_inventory)         # :656 - ingredients in the inventory right away
+        elif not had_iron:
+            base.reset()            # AxeHard.__init__ -> add_new_items({'iron': 3}) -> reset() (:250)
+        return w
     if novelty_name == 'axe':
         if difficulty == 'medium':
             base.reset()            # AxeMedium.__init__ -> add_new_items -> reset(): the axe appears on the map (:129)

@@ -16,13 +16,13 @@ messages as (code, arg) pairs formatted here by `format_message`.
 import copy
 import ctypes as C
 
-MAX_ITEMS, MAX_ACTIONS, MAX_RECIPES, MAX_RECIPE_INPUTS, MAX_START = 24, 48, 8, 4, 8
+MAX_ITEMS, MAX_ACTIONS, MAX_RECIPES, MAX_RECIPE_INPUTS, MAX_START, MAX_INV_START = 24, 48, 8, 4, 8, 4
 MAX_MAP_SIZE = 64
 ABI_VERSION = 1
 
 # step_cost values with their Python types (SURVEY.md §8(a) "Distinct step_cost values")
 STEP_COSTS = [0, 24.0, 27.906975, 120.0, 300.0, 360.0, 480.0, 720.0, 840.0, 1200.0, 1800.0, 2400.0, 3600.0,
-              7200.0, 8400.0, 5000, 50000, 900.0, 3600.0 * 1.2, 27.906975 * 2]
+              7200.0, 8400.0, 5000, 50000, 900.0, 3600.0 * 1.2, 27.906975 * 2, 600.0, 6000.0]
 
 
 def cost_code(value):
@@ -48,7 +48,6 @@ class NgwSpec(C.Structure):
     _fields_ = [
         ('abi_version', C.c_int32), ('map_size', C.c_int32), ('n_items', C.c_int32), ('n_actions', C.c_int32),
         ('n_recipes', C.c_int32), ('reward_step', C.c_int32), ('reward_done', C.c_int32),
-        ('craft_reward', C.c_int32),
         ('act_kind', C.c_uint8 * MAX_ACTIONS), ('act_arg', C.c_uint8 * MAX_ACTIONS),
         ('breakable', C.c_uint8 * MAX_ITEMS), ('entity', C.c_uint8 * MAX_ITEMS),
         ('break_reward', C.c_int8 * MAX_ITEMS), ('break_qty', C.c_uint8 * MAX_ITEMS),
@@ -59,7 +58,7 @@ class NgwSpec(C.Structure):
         ('recipe_out_item', C.c_uint8 * MAX_RECIPES), ('recipe_out_qty', C.c_uint8 * MAX_RECIPES),
         ('recipe_needs_table', C.c_uint8 * MAX_RECIPES),
         ('cost_missing', C.c_uint8 * MAX_RECIPES), ('cost_no_table', C.c_uint8 * MAX_RECIPES),
-        ('cost_ok', C.c_uint8 * MAX_RECIPES),
+        ('cost_ok', C.c_uint8 * MAX_RECIPES), ('recipe_reward', C.c_int8 * MAX_RECIPES),
         ('cost_forward', C.c_uint8), ('cost_turn', C.c_uint8), ('cost_break', C.c_uint8),
         ('cost_place', C.c_uint8), ('cost_extract', C.c_uint8), ('cost_select', C.c_uint8),
         ('cost_chop', C.c_uint8), ('cost_jump', C.c_uint8), ('chop_reward', C.c_int8), ('_pad3', C.c_uint8),
@@ -71,8 +70,8 @@ class NgwSpec(C.Structure):
         ('n_start', C.c_uint8), ('start_item', C.c_uint8 * MAX_START), ('start_qty', C.c_uint8 * MAX_START),
         ('tap_item', C.c_uint8), ('tap_near', C.c_uint8),
         ('additem_item', C.c_uint8), ('additem_pct_lo', C.c_uint8), ('additem_pct_hi', C.c_uint8),
-        ('inv_start_item', C.c_uint8), ('inv_start_qty', C.c_uint8),
-        ('_pad', C.c_uint8 * 3),
+        ('n_inv_start', C.c_uint8), ('inv_start_item', C.c_uint8 * MAX_INV_START), ('inv_start_qty', C.c_uint8 * MAX_INV_START),
+        ('_pad', C.c_uint8 * 2),
     ]
 
 
@@ -175,6 +174,7 @@ class EnvSpec:
         self.break_increase = None # BreakIncrease: '' = every block gives 2, or the one item that does
         self.start_inventory = {}  # AxeEasy: item present in the inventory after every reset
         self.additem = None        # dict(item=name, pct=(lo, hi))
+        self.recipe_rewards = {}   # recipe -> reward of a successful craft when it differs from craft_reward (craftable axe)
         self.novelties = []
 
     # -- table edits used by inject_novelty ---------------------------------------------------
@@ -226,7 +226,7 @@ class EnvSpec:
         s = NgwSpec()
         s.abi_version = ABI_VERSION
         s.map_size, s.n_items, s.n_actions, s.n_recipes = self.map_size, len(ids), len(self.actions_id), len(self.recipes)
-        s.reward_step, s.reward_done, s.craft_reward = -1, self.reward_done, self.craft_reward
+        s.reward_step, s.reward_done = -1, self.reward_done
         rnames = self.recipe_names
         for name, a in self.actions_id.items():
             if name in ('Forward', 'Left', 'Right', 'Break', 'Chop', 'Jump'):
@@ -267,6 +267,7 @@ class EnvSpec:
             s.recipe_needs_table[r] = int(len(rec['input']) > 1)
             cm, cn, ck = self.craft_costs.get(name, (0, 0, 0))
             s.cost_missing[r], s.cost_no_table[r], s.cost_ok[r] = cost_code(cm), cost_code(cn), cost_code(ck)
+            s.recipe_reward[r] = self.recipe_rewards.get(name, self.craft_reward)
         s.cost_forward, s.cost_turn, s.cost_break = cost_code(27.906975), cost_code(24.0), cost_code(3600.0)
         s.cost_place, s.cost_extract, s.cost_select = cost_code(300.0), cost_code(120.0), cost_code(120.0)
         s.cost_chop, s.cost_jump = cost_code(3600.0 * 1.2), cost_code(27.906975 * 2)
@@ -286,8 +287,11 @@ class EnvSpec:
         s.n_start = len(self.items_quantity)
         for j, (item, q) in enumerate(self.items_quantity.items()):
             s.start_item[j], s.start_qty[j] = ids[item], q
-        for item, q in self.start_inventory.items():
-            s.inv_start_item, s.inv_start_qty = ids[item], q
+        if len(self.start_inventory) > MAX_INV_START:
+            raise ValueError("start_inventory holds more than %d items" % MAX_INV_START)
+        s.n_inv_start = len(self.start_inventory)
+        for j, (item, q) in enumerate(self.start_inventory.items()):
+            s.inv_start_item[j], s.inv_start_qty[j] = ids[item], q
         if self.tap_pass:
             s.tap_item, s.tap_near = ids[self.tap_pass['item']], ids[self.tap_pass['near']]
         if self.additem:

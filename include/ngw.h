@@ -30,6 +30,7 @@ extern "C" {
 #define NGW_MAX_RECIPES 8
 #define NGW_MAX_RECIPE_INPUTS 4  /* the reference's recipes have <= 3 inputs (pogostick_v1_env.py:56-59) */
 #define NGW_MAX_START_ITEMS 8
+#define NGW_MAX_INV_START 4
 #define NGW_MAX_MAP_SIZE 64     /* S; the LDS-resident kernel supports S*S <= 4096 */
 
 /* error codes */
@@ -78,7 +79,6 @@ typedef struct ngw_spec {
     int32_t n_recipes;                   /* R */
     int32_t reward_step;                 /* -1  (:239) */
     int32_t reward_done;                 /* 50  (:82, forced while inv[goal] >= 1, :354-357) */
-    int32_t craft_reward;                /* 10 Pogostick (:455) / 50 Bow (bow_v1_env.py:424) */
     uint8_t act_kind[NGW_MAX_ACTIONS];
     uint8_t act_arg[NGW_MAX_ACTIONS];
     uint8_t breakable[NGW_MAX_ITEMS];    /* item not in unbreakable_items (:41,:283) */
@@ -94,6 +94,9 @@ typedef struct ngw_spec {
     uint8_t recipe_out_qty[NGW_MAX_RECIPES];
     uint8_t recipe_needs_table[NGW_MAX_RECIPES];             /* len(input) > 1 (:444) */
     uint8_t cost_missing[NGW_MAX_RECIPES], cost_no_table[NGW_MAX_RECIPES], cost_ok[NGW_MAX_RECIPES];
+    /* reward of a successful craft: 10 Pogostick-v1 (:455) / 50 Bow-v1 (bow_v1_env.py:424); the craftable axe of
+     * AxeHard / AxetoBreakHard always gives 10 (the wrappers' own craft(), novelty_wrappers.py:331) */
+    int8_t recipe_reward[NGW_MAX_RECIPES];
     /* fixed-action cost codes */
     uint8_t cost_forward, cost_turn, cost_break, cost_place, cost_extract, cost_select;
     uint8_t cost_chop, cost_jump;        /* 3600.0 * 1.2 (novelty_wrappers.py:1294), 27.906975 * 2 (:1381) */
@@ -119,9 +122,11 @@ typedef struct ngw_spec {
     uint8_t tap_item, tap_near;
     /* AddItem second reset pass (novelty_wrappers.py:1013-1034); additem_item = 0 -> disabled */
     uint8_t additem_item, additem_pct_lo, additem_pct_hi;
-    /* AxeEasy: item present in the inventory after every reset (novelty_wrappers.py:29-35); item 0 = none */
-    uint8_t inv_start_item, inv_start_qty;
-    uint8_t _pad[1];
+    /* items present in the inventory after every reset: AxeEasy / AxetoBreakEasy (novelty_wrappers.py:29-35, :456-462: the
+     * axe), AxetoBreakHard (:663-672: the axe's ingredients) */
+    uint8_t n_inv_start;
+    uint8_t inv_start_item[NGW_MAX_INV_START], inv_start_qty[NGW_MAX_INV_START];
+    uint8_t _pad[2];
 } ngw_spec;
 
 /* LidarInFront observation (reference gym_novel_gridworlds/observation_wrappers.py:10-80): `num_beams` rays at equally

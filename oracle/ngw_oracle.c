@@ -178,7 +178,7 @@ static int reset_env(const ngw_spec* sp, ngwo_rng* rng, int8_t* map, int32_t* lo
             if (air[i] != agent) map[air[i]] = (int8_t)sp->additem_item;  /* :1027 skips the agent cell */
         free(air);
     }
-    if (sp->inv_start_item) inv[sp->inv_start_item] = sp->inv_start_qty;
+    for (int j = 0; j < sp->n_inv_start; j++) inv[sp->inv_start_item[j]] = sp->inv_start_qty[j];   /* AxeEasy.reset :33, AxetoBreakHard.reset :667-670 */
     return 0;
 }
 
@@ -294,7 +294,7 @@ void ngwo_step(const ngw_spec* sp, int8_t* map, int32_t* loc, int32_t* facing, i
         } else if (sp->recipe_needs_table[rx] && front != sp->table_item) {   /* :444-453 */
             result = 0; msg = NGW_MSG_NEED_TABLE; cost = sp->cost_no_table[rx];
         } else {                                                  /* :455-474 */
-            reward = sp->craft_reward;
+            reward = sp->recipe_reward[rx];
             for (int j = 0; j < sp->recipe_n_in[rx]; j++) {
                 int item = sp->recipe_in_item[rx][j];
                 inv[item] -= sp->recipe_in[rx][item];

@@ -62,6 +62,10 @@ CFGS = {
     'remaph10':    (POGO, 10, ('remapaction', 'hard', '', '')),
     'chop10':      (POGO, 10, ('addchop', 'hard', '', '')),
     'jump12':      (BOW, 12, ('addjump', 'hard', '', '')),
+    'axehard10':   (POGO, 10, ('axe', 'hard', 'wooden', '')),       # craftable axe, ingredients on the map
+    'axehardi12':  (BOW, 12, ('axe', 'hard', 'iron', 'true')),      # new item 'iron' (add_new_items -> reset at injection)
+    'atbhard10':   (POGO, 10, ('axetobreak', 'hard', 'wooden', '')),   # ingredients start in the inventory
+    'atbhardi11':  (BOW, 11, ('axetobreak', 'hard', 'iron', '')),
     # the v0 variants
     'pogov0_10':   (POGO0, 10, None),
     'pogov0_14':   (POGO0, 14, ('axe', 'medium', 'wooden', '')),
@@ -206,7 +210,7 @@ def gen_resets(cfg, nseeds, out):
         for _ in range(3):
             env.reset()
             m, loc, f, sel, inv = snap(base)
-            assert sel == 0 and (not inv.any() or cfg in ('axeeasy10', 'axetbe10'))
+            assert sel == 0 and (not inv.any() or cfg in ('axeeasy10', 'axetbe10', 'atbhard10', 'atbhardi11'))
             maps.append(m), locs.append(loc), facs.append(f), invs.append(inv)
         words.append(next_word())
     out['rs_map'] = np.array(maps, np.int8).reshape(nseeds, 3, -1)
@@ -606,6 +610,8 @@ PLAN = {  # cfg: (reset seeds, traces, steps per trace, single-step cases, solve
     'remapm10': (8, 2, 1000, 2500, 2), 'remaph10': (8, 2, 1000, 2500, 2), 'chop10': (8, 2, 1000, 3000, 1),
     'jump12': (8, 2, 1000, 3000, 1), 'pogov0_10': (32, 3, 1200, 4000, 0), 'pogov0_14': (16, 2, 1000, 2500, 0),
     'bowv0_12': (16, 2, 1000, 3000, 0),
+    'axehard10': (12, 2, 1200, 4000, 2), 'axehardi12': (8, 2, 1000, 3000, 1), 'atbhard10': (12, 2, 1200, 4000, 0),
+    'atbhardi11': (8, 2, 1000, 3000, 0),
 }
 
 

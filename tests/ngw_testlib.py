@@ -27,6 +27,8 @@ CFGS = {
     'pogov0_10': ('NovelGridworld-Pogostick-v0', 10, None),
     'pogov0_14': ('NovelGridworld-Pogostick-v0', 14, ('axe', 'medium', 'wooden', '')),
     'bowv0_12': ('NovelGridworld-Bow-v0', 12, None),
+    'axehard10': (POGO, 10, ('axe', 'hard', 'wooden', '')), 'axehardi12': (BOW, 12, ('axe', 'hard', 'iron', 'true')),
+    'atbhard10': (POGO, 10, ('axetobreak', 'hard', 'wooden', '')), 'atbhardi11': (BOW, 11, ('axetobreak', 'hard', 'iron', '')),
 }
 REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13}
 HEADLINE = ['pogo10', 'bow20', 'axe10', 'add32']       # BASELINE.json configs 2-5

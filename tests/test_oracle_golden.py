@@ -20,7 +20,9 @@ def test_spec_tables_match_reference(cfg):
     assert spec.items_id == ref['items_id']
     assert spec.actions_id == ref['actions_id']
     assert spec.action_space_n == ref['action_space_n']          # the wrapper's; only addchop / addjump grow it
-    assert ref['base_action_space_n'] == (17 if 'Pogostick' in ref['env_id'] else 15)
+    hard = ref['novelty'] is not None and ref['novelty'][0] in ('axe', 'axetobreak') and ref['novelty'][1] == 'hard'
+    assert ref['base_action_space_n'] == (17 if 'Pogostick' in ref['env_id'] else 15) + (2 if hard else 0)
+    assert getattr(spec, 'base_action_space_n', ref['base_action_space_n']) == ref['base_action_space_n']
     assert [[k, v] for k, v in spec.items_quantity.items()] == ref['items_quantity']
     assert sorted(spec.entities) == ref['entities']
     assert sorted(spec.unbreakable_items) == ref['unbreakable_items']
