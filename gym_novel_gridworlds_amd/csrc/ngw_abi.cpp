@@ -58,6 +58,7 @@ struct ngw_handle {
     uint32_t lidar_magic = 0, lidar_off_tab = 0, lidar_off_tile = 0, lidar_off_map = 0;
     int lidar_fused = 0, lidar_range = 0, lidar_beams = 0, lidar_chan = 0, lidar_ninv = 0;
     size_t lidar_lds = 0;
+    int ext = 0;                          // spec uses FireWall / FenceRestriction / Crate step predicates -> EXT kernels
     int8_t* view_out = nullptr;           // AgentMap windows
     int view_size = 0;
     hipGraph_t graph = nullptr;
@@ -116,8 +117,16 @@ int check_spec(const ngw_spec* s) {
             for (int k = 0; k < j; k++)
                 if (s->recipe_in_item[r][j] == s->recipe_in_item[r][k]) return fail(NGW_E_INVALID_ARG, "recipe %d lists an input twice", r);
         }
-    if (s->additem_item && !(s->additem_pct_lo < s->additem_pct_hi && s->additem_pct_hi - s->additem_pct_lo <= 32 && s->additem_pct_hi <= 100))
-        return fail(NGW_E_INVALID_ARG, "additem percent range invalid");
+    auto pct_ok = [](int lo, int hi) { return lo < hi && hi - lo <= 64 && hi <= 100; };
+    if (s->additem_item && !pct_ok(s->additem_pct_lo, s->additem_pct_hi)) return fail(NGW_E_INVALID_ARG, "additem percent range invalid");
+    if (s->replace_to && !pct_ok(s->replace_pct_lo, s->replace_pct_hi)) return fail(NGW_E_INVALID_ARG, "replace percent range invalid");
+    if (s->fence_item && !pct_ok(s->fence_pct_lo, s->fence_pct_hi)) return fail(NGW_E_INVALID_ARG, "fence percent range invalid");
+    if (!item_ok(s->replace_from) || !item_ok(s->replace_to) || !item_ok(s->fence_item) || !item_ok(s->fire_item) ||
+        !item_ok(s->crate_item) || s->fence_mode > 2)
+        return fail(NGW_E_INVALID_ARG, "novelty item id / fence_mode out of range");
+    for (int i = 0; i < NGW_MAX_ITEMS; i++)
+        if (s->crate_add[i] && (i >= K || !s->crate_item || s->crate_add[i] > 15)) return fail(NGW_E_INVALID_ARG, "crate_add[%d] invalid", i);
+    if (s->fence_mode && !s->fence_item) return fail(NGW_E_INVALID_ARG, "fence_mode without fence_item");
     return NGW_OK;
 }
 
@@ -145,7 +154,7 @@ int layout_lds(ngw_handle* h) {
     p.off_cand = off; off += (uint32_t)(p.CW * NGW_EPB);
     p.off_act = off; off += (uint32_t)(NGW_MAX_ACTIONS * NGW_ACT_DW + NGW_MAX_PLACE / 4);
     p.perm_lds = 0; p.off_perm = off;
-    if (h->spec.additem_item) {
+    if (h->spec.additem_item || h->spec.replace_to || h->spec.fence_item) {
         // Shuffle array in LDS only while the wave's LDS stays small (<= 32 KiB, 5 waves/CU).  Measured at S = 32: the
         // extra 64 KiB halves the resident waves per CU and costs more (step 50 -> 115 us) than the HBM scratch column.
         const uint32_t perm_dw = (uint32_t)(S2 * 32 * 2 / 4);
@@ -179,7 +188,7 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     a.action_seed = action_seed;
     a.t0 = t0;
     const unsigned grid = (unsigned)(h->n_pad / NGW_EPB);
-    HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, h->lidar_fused, grid, h->lds_bytes, h->stream));
+    HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, (h->lidar_fused ? 1 : 0) | (h->ext ? 2 : 0), grid, h->lds_bytes, h->stream));
     return NGW_OK;
 }
 
@@ -243,14 +252,22 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     if (!rc) rc = dev_alloc(h, &h->b.flags, 1);
     if (!rc) rc = dev_alloc(h, &h->actions_dev, np);
     if (!rc) rc = dev_alloc(h, &h->mask_dev, np);
-    if (!rc && spec->additem_item) rc = dev_alloc(h, &h->b.perm, np * S2);   // HBM fallback for maps too big for the LDS shuffle
+    if (!rc && (spec->additem_item || spec->replace_to || spec->fence_item)) rc = dev_alloc(h, &h->b.perm, np * S2);   // HBM fallback for maps too big for the LDS shuffle
     if (!rc) rc = dev_alloc(h, &h->dspec, 1);
     if (rc) return bail(rc);
     {
         NgwDevSpec hs;
         memset(&hs, 0, sizeof(hs));
         hs.sp = *spec;
-        for (int i = 0; i < 32; i++) hs.addq[i] = (double)(spec->additem_pct_lo + i) / 100.0;
+        hs.x.fire_item = spec->fire_item; hs.x.fire_reward = spec->fire_reward; hs.x.fence_item = spec->fence_item;
+        hs.x.fence_mode = spec->fence_mode; hs.x.crate_item = spec->crate_item;
+        for (int i = 0; i < K; i++) hs.x.crate_add[i >> 3] |= (uint32_t)(spec->crate_add[i] & 15u) << (4 * (i & 7));
+        h->ext = (spec->fire_item || spec->fence_mode || spec->crate_item) ? 1 : 0;
+        for (int i = 0; i < 64; i++) {
+            hs.pctq[NGW_PASS_ADDITEM][i] = (double)(spec->additem_pct_lo + i) / 100.0;
+            hs.pctq[NGW_PASS_REPLACE][i] = (double)(spec->replace_pct_lo + i) / 100.0;
+            hs.pctq[NGW_PASS_FENCE][i] = (double)(spec->fence_pct_lo + i) / 100.0;
+        }
         NgwStepU& u = hs.u;
         for (int i = 0; i < K; i++) {
             if (spec->breakable[i]) u.brk_mask |= 1u << i;

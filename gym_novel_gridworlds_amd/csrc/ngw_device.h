@@ -11,6 +11,8 @@ enum { NGW_MODE_STEP = 0, NGW_MODE_RESET = 1, NGW_MODE_ROLLOUT = 2,
        NGW_MODE_DBG_NOP = 8 /* exit at once: launch floor */, NGW_MODE_DBG_COPY = 9 /* stage in/out, no step logic */ };
 /* how a wave's map chunk is laid out in LDS: same image as HBM / odd-dword-padded rows / byte-granular (odd S) */
 enum { NGW_MAP_STRAIGHT = 0, NGW_MAP_DWORD = 1, NGW_MAP_BYTE = 2 };
+/* shuffled-subset reset passes: AddItem / Crate, ReplaceItem / FireWall, Fence / FenceRestriction */
+enum { NGW_PASS_ADDITEM = 0, NGW_PASS_REPLACE = 1, NGW_PASS_FENCE = 2 };
 
 /* Device buffers of one handle.  map/loc/facing/inv are the batched observation AND the state, updated IN PLACE:
  * a step writes through only the bytes it changes (a map cell, a few inventory slots, the agent pose); a reset
@@ -28,7 +30,7 @@ struct NgwBufs {
     uint8_t* done;        /* [n_pad] */
     uint32_t* info;       /* [n_pad] packed, see NGW_INFO_* */
     uint32_t* flags;      /* [1] sticky NGW_F_* */
-    uint16_t* perm;       /* [S*S][n_pad] AddItem shuffle scratch, or nullptr */
+    uint16_t* perm;       /* [S*S][n_pad] shuffle scratch of the subset reset passes, or nullptr */
 };
 
 struct NgwLaunch {
@@ -69,10 +71,16 @@ struct NgwStepU {
     uint8_t axe_required;                   /* AxetoBreak*: Break fails without the selected axe */
 };
 
+/* Uniform parameters of the step-time novelty predicates (kernel template flag EXT): FireWall, FenceRestriction, Crate */
+struct NgwExtU {
+    int32_t fire_item, fire_reward, fence_item, fence_mode, crate_item;
+    uint32_t crate_add[3];                  /* 4 bits per item id: how many of it a crate holds */
+};
+
 /* Per-action descriptor, NGW_ACT_DW dwords, copied to LDS (the only lane-varying LUT of the step):
  *   d0 = kind | arg<<8 | n_inputs<<16 | needs_table<<24      d1 = input item ids (4 bytes, dict order)
  *   d2 = input quantities (4 bytes)                          d3 = out_item | out_qty<<8 | cost_missing<<16 | cost_no_table<<24
- *   d4 = cost_ok                                             (d1..d4 are zero for non-craft actions) */
+ *   d4 = cost_ok | recipe_reward<<8                          (d1..d4 are zero for non-craft actions) */
 #define NGW_ACT_DW 5
 
 /* Blob kept in HBM (one per handle). */
@@ -85,13 +93,14 @@ struct NgwDevSpec {
     /* --- */
     int32_t n_place;
     ngw_spec sp;                 /* full spec: the (cold) reset path reads it with scalar loads */
-    double addq[32];             /* AddItem: pct / 100.0 for pct in [pct_lo, pct_hi) as the host's IEEE double */
+    NgwExtU x;
+    double pctq[3][64];          /* per reset pass (NGW_PASS_*): pct / 100.0 for pct in [pct_lo, pct_hi) as the host's IEEE double */
 };
 
 #ifdef __cplusplus
 extern "C"
 #endif
-hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int lidar, unsigned grid, size_t lds_bytes,
+hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int feat /* 1 = fused lidar, 2 = EXT */, unsigned grid, size_t lds_bytes,
                       hipStream_t stream);
 /* Device-side lidar tables, built by ngw_lidar_configure from ngw_lidar_cfg: flat cell offsets dr * S + dc. */
 struct NgwLidarDev {

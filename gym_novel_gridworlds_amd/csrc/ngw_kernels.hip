@@ -112,23 +112,49 @@ struct ResetArgs {
     uint32_t magicS;                // ceil(2^32 / S): cell / S for cell < S*S
 };
 
-// AddItem.reset (novelty_wrappers.py:1017-1028) on a shuffle array `perm` with element stride `ps`.
-template <typename P>
-__device__ __forceinline__ void additem_pass(P perm, int64_t ps, Philox& px, LDS_AS int8_t* mp, int S2, int agent, int item,
-                                             int pct_span, const GLOBAL_AS double* addq) {
-    int n_air = 0;
-    for (int i = 0; i < S2; i++)
-        if (mp[i] == 0) { perm[(int64_t)n_air * ps] = (uint16_t)i; n_air++; }       // np.where(map == 0), row-major
-    for (int i = n_air - 1; i >= 1; i--) {                                         // np.random.shuffle: Fisher-Yates from the top
+// The shuffled-subset reset passes - AddItem.reset (novelty_wrappers.py:1017-1028), ReplaceItem.reset (:1131-1144),
+// Fence.reset (:871-884) - on a shuffle array `perm` with element stride `ps`: np.where(<predicate>) in row-major order,
+// np.random.shuffle (Fisher-Yates from the top), percent = randint(lo, hi), edit the first ceil(len * (percent / 100)).
+template <int KIND, typename P>
+__device__ __forceinline__ void subset_pass(P perm, int64_t ps, Philox& px, LDS_AS int8_t* mp, int S, int S2, int agent, int match,
+                                            int item, int pct_span, const GLOBAL_AS double* pctq) {
+    int n = 0;
+    for (int i = 0; i < S2; i++) {
+        const int v = mp[i];
+        const bool hit = KIND == NGW_PASS_ADDITEM ? v == 0 : KIND == NGW_PASS_REPLACE ? v == match : (v != 0 && v != match);
+        if (hit) { perm[(int64_t)n * ps] = (uint16_t)i; n++; }
+    }
+    for (int i = n - 1; i >= 1; i--) {
         const int j = (int)bounded(px, (uint32_t)i);
         const uint16_t x = perm[(int64_t)i * ps], y = perm[(int64_t)j * ps];
         perm[(int64_t)i * ps] = y; perm[(int64_t)j * ps] = x;
     }
-    const int pct = (int)bounded(px, (uint32_t)(pct_span - 1));                    // randint(lo, hi)
-    const int cnt = (int)ceil((double)n_air * addq[pct]);                          // int(np.ceil(len * (pct / 100)))
+    const int pct = (int)bounded(px, (uint32_t)(pct_span - 1));                    // randint(lo, hi); a span of 1 draws nothing
+    const int cnt = (int)ceil((double)n * pctq[pct]);                              // int(np.ceil(len * (pct / 100)))
     for (int i = 0; i < cnt; i++) {
         const int cell = perm[(int64_t)i * ps];
-        if (cell != agent) mp[cell] = (int8_t)item;                                // :1027 skips the agent cell
+        if (KIND == NGW_PASS_FENCE) {                                              // add_fence_around, pogostick_v1_env.py:524-536
+            for (int dr = -S; dr <= S; dr += S)
+                for (int dc = -1; dc <= 1; dc++) {
+                    const int q = cell + dr + dc;
+                    if (mp[q] == 0 && q != agent) mp[q] = (int8_t)item;
+                }
+        } else if (cell != agent) mp[cell] = (int8_t)item;                         // :1027 / :1143 skip the agent cell
+    }
+}
+
+template <int KIND>
+__device__ __forceinline__ void run_pass(const ResetArgs& a, LDS_AS uint16_t* perm_lds, int64_t env_local, Philox& px, LDS_AS int8_t* mp,
+                                         int agent, int match, int item, int pct_span) {
+    const GLOBAL_AS double* pctq = (const GLOBAL_AS double*)a.dspec->pctq[KIND];
+    if (a.perm_lds) {
+        // shuffle array in LDS, [i][32 lanes] u16: the two halves of the wave take turns (a wave executes divergent
+        // halves one after the other and its LDS operations are in order, so they can share the region)
+        const int lane = threadIdx.x;
+        for (int half = 0; half < 2; half++)
+            if ((lane >> 5) == half) subset_pass<KIND>(perm_lds + (lane & 31), 32, px, mp, a.S, a.S2, agent, match, item, pct_span, pctq);
+    } else {
+        subset_pass<KIND>((GLOBAL_AS uint16_t*)(a.perm + env_local), a.n_pad, px, mp, a.S, a.S2, agent, match, item, pct_span, pctq);
     }
 }
 
@@ -138,7 +164,6 @@ __device__ __noinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t* mp
                                             const LDS_AS uint8_t* place_seq, LDS_AS uint16_t* perm_lds, uint64_t env_global,
                                             int64_t env_local, uint32_t episode) {
     const GLOBAL_AS ngw_spec& sp = *(const GLOBAL_AS ngw_spec*)&a.dspec->sp;
-    const GLOBAL_AS double* addq = (const GLOBAL_AS double*)a.dspec->addq;
     int r_out, c_out, f_out;
     const int S = a.S, K = a.K, W = S - 4, ncand = W * W;
     const uint32_t magicW = (uint32_t)((0x100000000ull + (uint32_t)W - 1) / (uint32_t)W);   // pos / W == umulhi(pos, magicW), pos < 2^12
@@ -199,18 +224,12 @@ __device__ __noinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t* mp
             }
         }
     }
-    if (sp.additem_item && !flags) {
-        const int span = sp.additem_pct_hi - sp.additem_pct_lo, item = sp.additem_item;
-        if (a.perm_lds) {
-            // shuffle array in LDS, [i][32 lanes] u16: the two halves of the wave take turns (a wave executes divergent
-            // halves one after the other and its LDS operations are in order, so they can share the region)
-            const int lane = threadIdx.x;
-            for (int half = 0; half < 2; half++)
-                if ((lane >> 5) == half) additem_pass(perm_lds + (lane & 31), 32, px, mp, a.S2, agent, item, span, addq);
-        } else {
-            additem_pass((GLOBAL_AS uint16_t*)(a.perm + env_local), a.n_pad, px, mp, a.S2, agent, item, span, addq);
-        }
-    }
+    if (sp.additem_item && !flags)                                                 // AddItem / Crate
+        run_pass<NGW_PASS_ADDITEM>(a, perm_lds, env_local, px, mp, agent, 0, sp.additem_item, sp.additem_pct_hi - sp.additem_pct_lo);
+    if (sp.replace_to && !flags)                                                   // ReplaceItem / FireWall
+        run_pass<NGW_PASS_REPLACE>(a, perm_lds, env_local, px, mp, agent, sp.replace_from, sp.replace_to, sp.replace_pct_hi - sp.replace_pct_lo);
+    if (sp.fence_item && !flags)                                                   // Fence / FenceRestriction
+        run_pass<NGW_PASS_FENCE>(a, perm_lds, env_local, px, mp, agent, sp.wall_item, sp.fence_item, sp.fence_pct_hi - sp.fence_pct_lo);
     if (!flags)
         for (int j = 0; j < sp.n_inv_start; j++) inv[sp.inv_start_item[j]] = sp.inv_start_qty[j];   // AxeEasy.reset :33, AxetoBreakHard.reset :667-670
     return flags | ((uint32_t)r_out << 8) | ((uint32_t)c_out << 16) | ((uint32_t)f_out << 24);
@@ -402,7 +421,7 @@ static_assert(offsetof(NgwLidarDev, chan_of_item) == 16 * LIDAR_TAB16 && offseto
 // LDS reads of the step are issued in TWO parallel levels (L0: action descriptor, block in front and its four
 // neighbours, the inventory slots whose item id is uniform; L1: the slots whose id comes out of L0) and the per-kind
 // bodies then work on registers only - the dependency chain of a step is two LDS latencies plus ALU, whatever the kind.
-template <int MAPMODE, int MODE, bool LIDAR>
+template <int MAPMODE, int MODE, bool LIDAR, bool EXT>
 __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restrict__ dspec, const NgwLaunch a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if (MODE == NGW_MODE_DBG_NOP) return;
@@ -525,6 +544,16 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     PIN_S(cost_extract); PIN_S(cost_select); PIN_S(table_item); PIN_S(goal_item); PIN_S(place_item); PIN_S(place_near);
     PIN_S(n_entities); PIN_S(ext_src); PIN_S(ext_near); PIN_S(ext_out); PIN_S(ext_qty); PIN_S(ext_consume);
     PIN_S(ext_cost_ok); PIN_S(axe_item); PIN_S(axe_cost); PIN_S(axe_qty); PIN_S(place_reward); PIN_S(ext_reward); PIN_S(axe_reward);
+    // step-time novelty predicates (FireWall / FenceRestriction / Crate): only the EXT instantiation carries them
+    int fire_item = 0, fire_reward = 0, fence_item = 0, fence_mode = 0, crate_item = 0;
+    uint32_t crate_a0 = 0, crate_a1 = 0, crate_a2 = 0;
+    if (EXT) {
+        const NgwExtU& X = dspec->x;
+        fire_item = X.fire_item; fire_reward = X.fire_reward; fence_item = X.fence_item; fence_mode = X.fence_mode;
+        crate_item = X.crate_item; crate_a0 = X.crate_add[0]; crate_a1 = X.crate_add[1]; crate_a2 = X.crate_add[2];
+        PIN_S(fire_item); PIN_S(fire_reward); PIN_S(fence_item); PIN_S(fence_mode); PIN_S(crate_item);
+        PIN_S(crate_a0); PIN_S(crate_a1); PIN_S(crate_a2);
+    }
 
     for (int t = 0; t < n_steps; t++, tt++) {
         bool do_reset = false;
@@ -577,6 +606,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                     PIN_V(nbW); PIN_V(nbE); PIN_V(inv_place); PIN_V(inv_ext); PIN_V(inv_axe);
                     // ---------------- register-only bodies
                     int rew = reward_step, result = 1, cost = 0, msg = NGW_MSG_NONE, arg = 0;   // :239-242
+                    bool fence_twice = false;
                     switch (kind) {
                     case NGW_ACT_FORWARD:                                          // :244-257
                         if (front == 0) { r = fr; c = fc; } else { result = 0; msg = NGW_MSG_BLOCK_IN_PATH; }
@@ -590,6 +620,27 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                         break;
                     case NGW_ACT_BREAK:                                            // :280-294, axe: novelty_wrappers.py:144-183
                         cost = cost_break;
+                        if (EXT && crate_item && front == crate_item) {            // Crate.step :1086-1089: the ingredients come first
+                            for (int i = 1; i < K; i++) {
+                                const uint32_t w = i < 8 ? crate_a0 : (i < 16 ? crate_a1 : crate_a2);
+                                const int q = (int)((w >> (4 * (i & 7))) & 15u);
+                                if (q) { const int nv = inv[i] + q; inv[i] = nv; gi[i] = nv; }
+                            }
+                        }
+                        if (EXT && fence_mode && ((brk_mask >> front) & 1u)) {     // FenceRestriction.step :924-946
+                            bool restricted = false;
+                            if (front != fence_item) {
+                                if (fence_mode == 1) {                             // medium: fence beside the AGENT, across its facing
+                                    const int side = f <= 1 ? 1 : S;
+                                    restricted = mp[r * S + c - side] == fence_item || mp[r * S + c + side] == fence_item;
+                                } else {                                           // hard: any fence in the 3x3 around the block in front
+                                    for (int dq = -S; dq <= S; dq += S)
+                                        for (int dc2 = -1; dc2 <= 1; dc2++) restricted |= mp[fcell + dq + dc2] == fence_item;
+                                }
+                            }
+                            if (restricted) { result = 0; msg = NGW_MSG_FENCE_RESTRICTION; break; }
+                            fence_twice = true;                                    // the wrapper runs env.step() AND its own epilogue
+                        }
                         if ((brk_mask >> front) & 1u) {
                             const bool axe_ok = axe_item && inv_axe >= 1 && sel == axe_item;
                             if (!axe_ok && axe_required) {                         // AxetoBreak*: novelty_wrappers.py:589-591
@@ -679,6 +730,18 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                     }
                     int done = 0;                                                  // :354-357 (LDS ops of a wave are in order)
                     if (inv[goal_item] >= 1) { rew = reward_done; done = 1; }
+                    if (EXT) {
+                        if (fence_twice) {                                         // FenceRestriction.step :949-972: its own info + a
+                            result = 1; cost = cost_break; msg = NGW_MSG_NONE; arg = 0;   // second step_count += 1 (:966)
+                            steps += 1;
+                        }
+                        if (fire_item) {                                           // FireWall.step :1168-1189, after the wrapped step
+                            const int ac = r * S + c;
+                            if (mp[ac - S] == fire_item || mp[ac + S] == fire_item || mp[ac - 1] == fire_item || mp[ac + 1] == fire_item) {
+                                rew = fire_reward; done = 1; msg = NGW_MSG_FIRE_WALL; arg = 0;
+                            }
+                        }
+                    }
                     steps += 1;                                                    // :362
                     reward = rew; ended = done;
                     info = (uint32_t)result | ((uint32_t)done << 1) | ((uint32_t)cost << 2) | ((uint32_t)msg << 8) |
@@ -887,7 +950,7 @@ extern "C" hipError_t ngw_lidar_launch(const NgwLidarDev* cfg, const NgwLaunch* 
 
 namespace {
 
-template <int MAPMODE, int MODE, bool LIDAR>
+template <int MAPMODE, int MODE, bool LIDAR, bool EXT>
 hipError_t launch_one(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     // CDNA4 has 160 KiB of LDS per CU; anything above the 64 KiB default needs an explicit opt-in per device.
     static size_t lds_opt_in[64] = {0};
@@ -895,31 +958,35 @@ hipError_t launch_one(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (lds_bytes > 64 * 1024 && dev < 64 && lds_bytes > lds_opt_in[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ngw_kernel<MAPMODE, MODE, LIDAR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ngw_kernel<MAPMODE, MODE, LIDAR, EXT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes);
         if (e != hipSuccess) return e;
         lds_opt_in[dev] = lds_bytes;
     }
-    hipLaunchKernelGGL((ngw_kernel<MAPMODE, MODE, LIDAR>), dim3(grid), dim3(NGW_EPB), lds_bytes, stream, dspec, *a);
+    hipLaunchKernelGGL((ngw_kernel<MAPMODE, MODE, LIDAR, EXT>), dim3(grid), dim3(NGW_EPB), lds_bytes, stream, dspec, *a);
     return hipGetLastError();
 }
 
-template <int MAPMODE>
-static hipError_t launch_mode(const NgwDevSpec* dspec, const NgwLaunch* a, int lidar, unsigned grid, size_t lds_bytes, hipStream_t stream) {
-    if (lidar) {
-        switch (a->mode) {
-        case NGW_MODE_STEP: return launch_one<MAPMODE, NGW_MODE_STEP, true>(dspec, a, grid, lds_bytes, stream);
-        case NGW_MODE_RESET: return launch_one<MAPMODE, NGW_MODE_RESET, true>(dspec, a, grid, lds_bytes, stream);
-        case NGW_MODE_ROLLOUT: return launch_one<MAPMODE, NGW_MODE_ROLLOUT, true>(dspec, a, grid, lds_bytes, stream);
-        default: return hipErrorInvalidValue;
-        }
-    }
+template <int MAPMODE, bool LIDAR, bool EXT>
+static hipError_t launch_mode(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     switch (a->mode) {
-    case NGW_MODE_STEP: return launch_one<MAPMODE, NGW_MODE_STEP, false>(dspec, a, grid, lds_bytes, stream);
-    case NGW_MODE_RESET: return launch_one<MAPMODE, NGW_MODE_RESET, false>(dspec, a, grid, lds_bytes, stream);
-    case NGW_MODE_ROLLOUT: return launch_one<MAPMODE, NGW_MODE_ROLLOUT, false>(dspec, a, grid, lds_bytes, stream);
-    case NGW_MODE_DBG_COPY: return launch_one<MAPMODE, NGW_MODE_DBG_COPY, false>(dspec, a, grid, lds_bytes, stream);
-    default: return launch_one<MAPMODE, NGW_MODE_DBG_NOP, false>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MODE_STEP: return launch_one<MAPMODE, NGW_MODE_STEP, LIDAR, EXT>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MODE_RESET: return launch_one<MAPMODE, NGW_MODE_RESET, LIDAR, EXT>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MODE_ROLLOUT: return launch_one<MAPMODE, NGW_MODE_ROLLOUT, LIDAR, EXT>(dspec, a, grid, lds_bytes, stream);
+    default: break;
+    }
+    if (LIDAR || EXT) return hipErrorInvalidValue;
+    if (a->mode == NGW_MODE_DBG_COPY) return launch_one<MAPMODE, NGW_MODE_DBG_COPY, false, false>(dspec, a, grid, lds_bytes, stream);
+    return launch_one<MAPMODE, NGW_MODE_DBG_NOP, false, false>(dspec, a, grid, lds_bytes, stream);
+}
+
+template <int MAPMODE>
+static hipError_t launch_feat(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream) {
+    switch (feat & 3) {
+    case 0: return launch_mode<MAPMODE, false, false>(dspec, a, grid, lds_bytes, stream);
+    case 1: return launch_mode<MAPMODE, true, false>(dspec, a, grid, lds_bytes, stream);
+    case 2: return launch_mode<MAPMODE, false, true>(dspec, a, grid, lds_bytes, stream);
+    default: return launch_mode<MAPMODE, true, true>(dspec, a, grid, lds_bytes, stream);
     }
 }
 
@@ -927,7 +994,7 @@ __global__ void ngw_nop_kernel(const NgwDevSpec* dspec, const NgwLaunch a) {}
 
 }  // namespace
 
-extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int lidar, unsigned grid,
+extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int feat, unsigned grid,
                                  size_t lds_bytes, hipStream_t stream) {
     if (a->mode >= 10 && a->mode <= 12) {       // diagnostics: empty kernels with other workgroup shapes over the same lanes
         const unsigned tpb = a->mode == 10 ? 256 : (a->mode == 11 ? 1024 : 128);
@@ -935,8 +1002,8 @@ extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, in
         return hipGetLastError();
     }
     switch (map_mode) {
-    case NGW_MAP_STRAIGHT: return launch_mode<NGW_MAP_STRAIGHT>(dspec, a, lidar, grid, lds_bytes, stream);
-    case NGW_MAP_DWORD: return launch_mode<NGW_MAP_DWORD>(dspec, a, lidar, grid, lds_bytes, stream);
-    default: return launch_mode<NGW_MAP_BYTE>(dspec, a, lidar, grid, lds_bytes, stream);
+    case NGW_MAP_STRAIGHT: return launch_feat<NGW_MAP_STRAIGHT>(dspec, a, feat, grid, lds_bytes, stream);
+    case NGW_MAP_DWORD: return launch_feat<NGW_MAP_DWORD>(dspec, a, feat, grid, lds_bytes, stream);
+    default: return launch_feat<NGW_MAP_BYTE>(dspec, a, feat, grid, lds_bytes, stream);
     }
 }

@@ -109,7 +109,8 @@ class _NovelGridworldEnv(_EnvBase):
         sp.reward_intermediate, sp.reward_done = self.reward_intermediate, self.reward_done
         key = (sp.map_size, tuple(sp.items_id.items()), tuple(sp.actions_id.items()), tuple(sp.items_quantity.items()),
                tuple(sorted(sp.entities)), repr(sp.axe), repr(sp.additem), repr(sp.start_inventory), sp.reward_done,
-               sp.reward_intermediate)
+               sp.reward_intermediate, repr(sp.replace), repr(sp.fence), repr(sp.fire_wall), repr(sp.crate),
+               tuple(sorted(sp.unbreakable_items)), repr(sp.recipes), repr(sp.break_increase))
         if self._vec is None or key != self._vec_key:
             self._close_backend()
             if self._seed is None:                          # reproducible under np.random.seed(), like the reference

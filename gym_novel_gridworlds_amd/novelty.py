@@ -7,9 +7,9 @@ AxeMedium.__init__ :125-134, AxeEasy.__init__ :16-27, AddItem.__init__ :996-1011
 `EnvSpec`, which is then recompiled into the kernel LUTs.
 
 In scope: SURVEY.md §8(a) 'axe' (easy / medium) and 'additem'; §8(f) row 2 (LUT-only novelties) 'breakincrease',
-'extractincdec', 'axetobreak', 'remapaction', 'addchop' and 'addjump'; 'axe' / 'axetobreak' hard (craftable axe).  The rest
-('crate', 'fence', 'fencerestriction', 'firewall', 'replaceitem') validate like the reference and then raise
-NotImplementedError.
+'extractincdec', 'axetobreak', 'remapaction', 'addchop' and 'addjump'; 'axe' / 'axetobreak' hard (craftable axe); §8(f) row 3
+(reset-time map edits + step predicates) 'fence', 'fencerestriction', 'replaceitem', 'firewall' and 'crate' - i.e. every
+name `inject_novelty` accepts.
 """
 
 NOVELTY_NAMES = ['addchop', 'additem', 'addjump', 'axe', 'axetobreak', 'breakincrease', 'crate', 'extractincdec',
@@ -73,9 +73,24 @@ def apply_novelty(spec, novelty_name, difficulty='hard', novelty_arg1='', novelt
         spec.manipulation_actions_id[name] = len(spec.actions_id)
         spec.actions_id.update(spec.manipulation_actions_id)
         spec.action_space_n = len(spec.actions_id)                 # these wrappers DO grow their action_space (:1278, :1350)
-    else:
-        raise NotImplementedError("novelty %r is outside this build's hot-path scope (SURVEY.md §8(f))"
-                                  % novelty_name)
+    elif novelty_name == 'crate':
+        _crate(spec, difficulty)
+    elif novelty_name == 'fence':
+        assert novelty_arg1, "For fence novelty, novelty_arg1 (attribute of fence, e.g. oak, jungle) is needed"   # :1660
+        _fence(spec, difficulty, novelty_arg1, mode=0)
+    elif novelty_name == 'fencerestriction':
+        assert novelty_arg1, \
+            "For fencerestriction novelty, novelty_arg1 (attribute of fence, e.g. oak, jungle) is needed"       # :1664
+        # FenceRestriction.__init__ :901: the fences are ALWAYS laid out by Fence(env, 'medium', ...); the difficulty
+        # only selects the Break predicate (:906, :927-941)
+        _fence(spec, 'medium', novelty_arg1, mode={'easy': 0, 'medium': 1, 'hard': 2}[difficulty])
+    elif novelty_name == 'firewall':
+        _replace_item(spec, difficulty, 'wall', 'fire_wall')       # FireWall.__init__ :1159
+        spec.fire_wall = 'fire_wall'
+    elif novelty_name == 'replaceitem':
+        assert novelty_arg1 and novelty_arg2, "For replaceitem novelty, novelty_arg1 (Item to replace) and novelty_arg2" \
+                                              "(Item to replace with) are needed"                       # :1672
+        _replace_item(spec, difficulty, novelty_arg1, novelty_arg2)
     spec.novelties.append((novelty_name, difficulty, novelty_arg1, novelty_arg2))
     return spec
 
@@ -162,6 +177,53 @@ def _axe_hard(spec, axe_material, breakincrease, required=False):
                                                                    # the wrapper keeps the copy it took before (action_space_n)
     spec.axe = dict(item=axe_name, cost=3600.0 * (0.5 if axe_material == 'wooden' else 0.25),
                     qty=2 if breakincrease == 'true' else 1, required=required)
+
+
+FENCE_PERCENT_RANGE = {'easy': (20, 50), 'medium': (50, 90), 'hard': (90, 100)}     # novelty_wrappers.py:861-866
+REPLACE_PERCENT_RANGE = {'easy': (5, 20), 'medium': (40, 90), 'hard': (99, 100)}    # :1121-1126
+CRATE_PERCENT_RANGE = {'easy': (99, 100), 'medium': (50, 90), 'hard': (10, 50)}     # :1047-1052
+
+
+def _fence(spec, difficulty, fence_material, mode):
+    """Fence.__init__ (novelty_wrappers.py:852-866): new item <material>_fence + its Select action; the fences appear in
+    the reset pass (:867-889).  `mode` is FenceRestriction's Break predicate (0 = none)."""
+    fence_name = fence_material + '_fence'
+    spec.add_new_item(fence_name)
+    spec.add_select_action(fence_name)
+    spec.fence = dict(item=fence_name, pct=FENCE_PERCENT_RANGE[difficulty], mode=mode)
+
+
+def _replace_item(spec, difficulty, item_to_replace, item_to_replace_with):
+    """ReplaceItem.__init__ (:1100-1126)."""
+    assert item_to_replace in spec.items_id, "Item to replace (" + item_to_replace + ") is not in the original map"
+    assert item_to_replace_with not in spec.items_id, "Item to replace with (" + item_to_replace_with + \
+                                                      ") should be a new item"
+    spec.add_new_item(item_to_replace_with)
+    spec.add_select_action(item_to_replace_with)
+    if item_to_replace == 'wall':
+        spec.unbreakable_items.add(item_to_replace_with)           # :1118-1119
+    spec.replace = dict(src=item_to_replace, dst=item_to_replace_with, pct=REPLACE_PERCENT_RANGE[difficulty])
+
+
+def _crate(spec, difficulty):
+    """Crate.__init__ (:1043-1068): AddItem(env, 'easy', 'crate') + the multiset of goal-recipe ingredients a crate holds,
+    drawn HERE from the global numpy stream with the reference's calls (randint, then choice until the quota is met), so
+    `np.random.seed(s); inject_novelty(env, 'crate', ...)` gives the reference's crate."""
+    import numpy as np
+    _add_item(spec, 'easy', 'crate')
+    lo, hi = CRATE_PERCENT_RANGE[difficulty]
+    item_percent = np.random.randint(low=lo, high=hi, size=1)[0]
+    goal_in = spec.recipes[spec.goal_item_to_craft]['input']
+    total_ingredients = sum(goal_in.values())
+    ingredients = list(goal_in)
+    crate_ingredients_num = int(np.ceil((item_percent / 100) * total_ingredients))
+    crate_ingredients = []
+    while crate_ingredients_num:
+        item = np.random.choice(ingredients, size=1)[0]
+        if crate_ingredients.count(item) < goal_in[item]:
+            crate_ingredients.append(str(item))
+            crate_ingredients_num -= 1
+    spec.crate = dict(item='crate', ingredients=crate_ingredients)
 
 
 def _add_item(spec, difficulty, item_to_add):

@@ -90,6 +90,26 @@ class AddItem(NoveltyWrapper):
         return self.env.reset()
 
 
+class Fence(AddItem):                                         # reset() without kwargs: :867
+    pass
+
+
+class FenceRestriction(AddItem):                              # :902
+    pass
+
+
+class Crate(AddItem):                                         # :1070
+    pass
+
+
+class ReplaceItem(AddItem):                                   # :1128
+    pass
+
+
+class FireWall(AddItem):                                      # :1161
+    pass
+
+
 def inject_novelty(env, novelty_name, difficulty='hard', novelty_arg1='', novelty_arg2=''):
     if isinstance(env, VecNovelGridworld):
         import copy
@@ -143,4 +163,5 @@ def inject_novelty(env, novelty_name, difficulty='hard', novelty_arg1='', novelt
         from . import spaces
         w.action_space = spaces.Discrete(len(base.actions_id))     # these two wrappers DO grow their action_space (:1278, :1350)
         return w
-    return AddItem(env)
+    return {'additem': AddItem, 'fence': Fence, 'fencerestriction': FenceRestriction, 'crate': Crate,
+            'replaceitem': ReplaceItem, 'firewall': FireWall}[novelty_name](env)

@@ -35,7 +35,7 @@ def cost_code(value):
 ACT_FORWARD, ACT_LEFT, ACT_RIGHT, ACT_BREAK, ACT_PLACE, ACT_EXTRACT, ACT_CRAFT, ACT_SELECT, ACT_CHOP, ACT_JUMP = range(10)
 (MSG_NONE, MSG_BLOCK_IN_PATH, MSG_CANNOT_BREAK, MSG_PLACED, MSG_ALREADY_EXISTS, MSG_NOT_IN_INVENTORY,
  MSG_EXTRACT_NO_SRC, MSG_EXTRACT_NOT_NEAR, MSG_MISSING_ITEMS, MSG_NEED_TABLE, MSG_CRAFTED, MSG_NEED_AXE,
- MSG_CANNOT_CHOP) = range(13)
+ MSG_CANNOT_CHOP, MSG_FENCE_RESTRICTION, MSG_FIRE_WALL) = range(15)
 
 F_INVALID_ACTION, F_PLACEMENT = 1, 2
 
@@ -71,7 +71,11 @@ class NgwSpec(C.Structure):
         ('tap_item', C.c_uint8), ('tap_near', C.c_uint8),
         ('additem_item', C.c_uint8), ('additem_pct_lo', C.c_uint8), ('additem_pct_hi', C.c_uint8),
         ('n_inv_start', C.c_uint8), ('inv_start_item', C.c_uint8 * MAX_INV_START), ('inv_start_qty', C.c_uint8 * MAX_INV_START),
-        ('_pad', C.c_uint8 * 2),
+        ('replace_from', C.c_uint8), ('replace_to', C.c_uint8), ('replace_pct_lo', C.c_uint8), ('replace_pct_hi', C.c_uint8),
+        ('fence_item', C.c_uint8), ('fence_pct_lo', C.c_uint8), ('fence_pct_hi', C.c_uint8), ('fence_mode', C.c_uint8),
+        ('fire_item', C.c_uint8), ('fire_reward', C.c_int8),
+        ('crate_item', C.c_uint8), ('crate_add', C.c_uint8 * MAX_ITEMS),
+        ('_pad', C.c_uint8 * 1),
     ]
 
 
@@ -174,6 +178,10 @@ class EnvSpec:
         self.break_increase = None # BreakIncrease: '' = every block gives 2, or the one item that does
         self.start_inventory = {}  # AxeEasy: item present in the inventory after every reset
         self.additem = None        # dict(item=name, pct=(lo, hi))
+        self.replace = None        # ReplaceItem / FireWall: dict(src=name, dst=name, pct=(lo, hi))
+        self.fence = None          # Fence / FenceRestriction: dict(item=name, pct=(lo, hi), mode=0|1|2)
+        self.fire_wall = None      # FireWall: item name whose 4-neighbourhood kills the agent
+        self.crate = None          # Crate: dict(item='crate', ingredients=[names drawn at injection])
         self.recipe_rewards = {}   # recipe -> reward of a successful craft when it differs from craft_reward (craftable axe)
         self.novelties = []
 
@@ -297,6 +305,18 @@ class EnvSpec:
         if self.additem:
             s.additem_item = ids[self.additem['item']]
             s.additem_pct_lo, s.additem_pct_hi = self.additem['pct']
+        if self.replace:
+            s.replace_from, s.replace_to = ids[self.replace['src']], ids[self.replace['dst']]
+            s.replace_pct_lo, s.replace_pct_hi = self.replace['pct']
+        if self.fence:
+            s.fence_item, s.fence_mode = ids[self.fence['item']], self.fence['mode']
+            s.fence_pct_lo, s.fence_pct_hi = self.fence['pct']
+        if self.fire_wall:
+            s.fire_item, s.fire_reward = ids[self.fire_wall], -self.reward_done // 2        # novelty_wrappers.py:1187
+        if self.crate:
+            s.crate_item = ids[self.crate['item']]
+            for name in self.crate['ingredients']:
+                s.crate_add[ids[name]] += 1
         return s
 
     # -- host-side decoding of kernel outputs --------------------------------------------------
@@ -329,6 +349,10 @@ class EnvSpec:
             return 'Crafted ' + names[arg]                                  # :472
         if code == MSG_CANNOT_CHOP:
             return "Cannot chop " + names[arg]                              # novelty_wrappers.py:1308
+        if code == MSG_FENCE_RESTRICTION:
+            return "Cannot break due to fence restriction"                  # novelty_wrappers.py:944
+        if code == MSG_FIRE_WALL:
+            return 'You died due to fire_wall'                              # novelty_wrappers.py:1189
         if code == MSG_NEED_AXE:
             return "Cannot break without " + names[arg] + " selected"         # novelty_wrappers.py:591
         raise ValueError("unknown message code %d" % code)

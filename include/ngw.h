@@ -57,7 +57,9 @@ enum { NGW_MSG_NONE = 0, NGW_MSG_BLOCK_IN_PATH = 1, NGW_MSG_CANNOT_BREAK = 2 /* 
        NGW_MSG_MISSING_ITEMS = 8 /* arg = recipe<<8 | mask over the recipe's inputs in dict order */,
        NGW_MSG_NEED_TABLE = 9, NGW_MSG_CRAFTED = 10 /* arg = crafted item */,
        NGW_MSG_NEED_AXE = 11 /* arg = axe item: "Cannot break without <axe> selected" */,
-       NGW_MSG_CANNOT_CHOP = 12 /* arg = item */ };
+       NGW_MSG_CANNOT_CHOP = 12 /* arg = item */,
+       NGW_MSG_FENCE_RESTRICTION = 13 /* "Cannot break due to fence restriction" */,
+       NGW_MSG_FIRE_WALL = 14 /* "You died due to fire_wall" */ };
 
 /* packed per-env info word produced by the step kernel:
  *   bit 0 result | bit 1 done | bits 2..7 cost code | bits 8..15 message code | bits 16..31 message arg */
@@ -126,7 +128,23 @@ typedef struct ngw_spec {
      * axe), AxetoBreakHard (:663-672: the axe's ingredients) */
     uint8_t n_inv_start;
     uint8_t inv_start_item[NGW_MAX_INV_START], inv_start_qty[NGW_MAX_INV_START];
-    uint8_t _pad[2];
+    /* ReplaceItem / FireWall reset pass (novelty_wrappers.py:1129-1148): a shuffled randint(lo, hi) percent of the cells
+     * holding replace_from become replace_to (never the agent cell); replace_to = 0 -> disabled */
+    uint8_t replace_from, replace_to, replace_pct_lo, replace_pct_hi;
+    /* Fence reset pass (:867-889): a shuffled percent of the non-air, non-wall cells get fence_item on every free
+     * 8-neighbour (add_fence_around, pogostick_v1_env.py:524-536); fence_item = 0 -> disabled.
+     * fence_mode: FenceRestriction Break predicate (:906-988) - 0 none (fence, fencerestriction easy), 1 medium (no
+     * fence beside the AGENT, across its facing), 2 hard (no fence in the 3x3 around the block in front) */
+    uint8_t fence_item, fence_pct_lo, fence_pct_hi, fence_mode;
+    /* FireWall.step (:1164-1200): after the step, a fire_item 4-neighbour of the agent -> reward fire_reward, done,
+     * message 'You died due to fire_wall'; fire_item = 0 -> disabled */
+    uint8_t fire_item;
+    int8_t fire_reward;
+    /* Crate.step (:1078-1092): Break with crate_item in front first adds crate_add[item] of every item to the
+     * inventory (the ingredient multiset drawn at injection, :1055-1068); crate_item = 0 -> disabled */
+    uint8_t crate_item;
+    uint8_t crate_add[NGW_MAX_ITEMS];
+    uint8_t _pad[1];
 } ngw_spec;
 
 /* LidarInFront observation (reference gym_novel_gridworlds/observation_wrappers.py:10-80): `num_beams` rays at equally

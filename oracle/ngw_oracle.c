@@ -112,6 +112,39 @@ uint32_t ngwo_mt_bounded(ngwo_mt* s, uint32_t max) { ngwo_rng r = {s, 0}; return
 static const int DR[4] = {-1, 1, 0, 0}, DC[4] = {0, 0, -1, 1};          /* NORTH SOUTH WEST EAST (:245-252) */
 static const int TURN_LEFT[4] = {2, 3, 1, 0}, TURN_RIGHT[4] = {3, 2, 0, 1}; /* (:258-279) */
 
+/* The reset passes of AddItem (novelty_wrappers.py:1017-1028), ReplaceItem (:1131-1144) and Fence (:871-884) share one
+ * shape: np.where(<predicate>) in row-major order, np.random.shuffle of the index array (Fisher-Yates from the top),
+ * percent = np.random.randint(lo, hi), then the first int(np.ceil(len * (percent / 100))) cells are edited. */
+enum { PASS_ADDITEM = 0, PASS_REPLACE = 1, PASS_FENCE = 2 };
+static void subset_pass(const ngw_spec* sp, ngwo_rng* rng, int8_t* map, int agent, int kind, int pct_lo, int pct_hi) {
+    const int S = sp->map_size;
+    int n = 0;
+    int16_t* cells = (int16_t*)malloc(sizeof(int16_t) * (size_t)(S * S));
+    for (int i = 0; i < S * S; i++) {
+        const int v = map[i];
+        const int hit = kind == PASS_ADDITEM ? v == 0 : kind == PASS_REPLACE ? v == sp->replace_from
+                                                                             : (v != 0 && v != sp->wall_item);
+        if (hit) cells[n++] = (int16_t)i;
+    }
+    for (int i = n - 1; i >= 1; i--) {
+        int j = (int)rng_bounded(rng, (uint32_t)i);
+        int16_t t = cells[i]; cells[i] = cells[j]; cells[j] = t;
+    }
+    int pct = pct_lo + (int)rng_bounded(rng, (uint32_t)(pct_hi - pct_lo - 1));
+    int cnt = (int)ceil((double)n * ((double)pct / 100.0));
+    for (int i = 0; i < cnt; i++) {
+        const int cell = cells[i];
+        if (kind == PASS_FENCE) {                                 /* add_fence_around, pogostick_v1_env.py:524-536 */
+            for (int rr = cell / S - 1; rr <= cell / S + 1; rr++)
+                for (int cc = cell % S - 1; cc <= cell % S + 1; cc++)
+                    if (map[rr * S + cc] == 0 && rr * S + cc != agent) map[rr * S + cc] = (int8_t)sp->fence_item;
+        } else if (cell != agent) {                               /* :1027 / :1143 skip the agent cell */
+            map[cell] = (int8_t)(kind == PASS_ADDITEM ? sp->additem_item : sp->replace_to);
+        }
+    }
+    free(cells);
+}
+
 /* pogostick_v1_env.py:86-157 (+ AddItem.reset novelty_wrappers.py:1013-1034, AxeEasy.reset :29-35).
  * Returns 0, or NGW_E_PLACEMENT when the candidate list runs out ("Cannot place items, increase map size!"). */
 static int reset_env(const ngw_spec* sp, ngwo_rng* rng, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv,
@@ -164,20 +197,12 @@ static int reset_env(const ngw_spec* sp, ngwo_rng* rng, int8_t* map, int32_t* lo
         }
         free(logs);
     }
-    if (sp->additem_item) {                                       /* AddItem.reset, novelty_wrappers.py:1017-1028 */
-        int n_air = 0;
-        int16_t* air = (int16_t*)malloc(sizeof(int16_t) * (size_t)(S * S));
-        for (int i = 0; i < S * S; i++) if (map[i] == 0) air[n_air++] = (int16_t)i;   /* np.where(map == 0), row-major */
-        for (int i = n_air - 1; i >= 1; i--) {                    /* np.random.shuffle: Fisher-Yates from the top */
-            int j = (int)rng_bounded(rng, (uint32_t)i);
-            int16_t t = air[i]; air[i] = air[j]; air[j] = t;
-        }
-        int pct = sp->additem_pct_lo + (int)rng_bounded(rng, (uint32_t)(sp->additem_pct_hi - sp->additem_pct_lo - 1));
-        int cnt = (int)ceil((double)n_air * ((double)pct / 100.0));   /* int(np.ceil(len * (pct / 100))) :1025 */
-        for (int i = 0; i < cnt; i++)
-            if (air[i] != agent) map[air[i]] = (int8_t)sp->additem_item;  /* :1027 skips the agent cell */
-        free(air);
-    }
+    if (sp->additem_item)                                         /* AddItem.reset, novelty_wrappers.py:1017-1028 (also Crate.reset :1071) */
+        subset_pass(sp, rng, map, agent, PASS_ADDITEM, sp->additem_pct_lo, sp->additem_pct_hi);
+    if (sp->replace_to)                                           /* ReplaceItem.reset :1129-1148 (also FireWall.reset :1160) */
+        subset_pass(sp, rng, map, agent, PASS_REPLACE, sp->replace_pct_lo, sp->replace_pct_hi);
+    if (sp->fence_item)                                           /* Fence.reset :867-889 (also FenceRestriction.reset :904) */
+        subset_pass(sp, rng, map, agent, PASS_FENCE, sp->fence_pct_lo, sp->fence_pct_hi);
     for (int j = 0; j < sp->n_inv_start; j++) inv[sp->inv_start_item[j]] = sp->inv_start_qty[j];   /* AxeEasy.reset :33, AxetoBreakHard.reset :667-670 */
     return 0;
 }
@@ -214,6 +239,7 @@ void ngwo_step(const ngw_spec* sp, int8_t* map, int32_t* loc, int32_t* facing, i
     const int S = sp->map_size;
     int r = loc[0], c = loc[1], f = *facing;
     int reward = sp->reward_step, result = 1, cost = 0, msg = NGW_MSG_NONE, arg = 0;   /* :239-242 */
+    int fence_twice = 0;
     const int kind = sp->act_kind[action], aarg = sp->act_arg[action];
     /* block in front: cached by the reference but coherent at every read */
     const int fr = r + DR[f], fc = c + DC[f];
@@ -229,6 +255,20 @@ void ngwo_step(const ngw_spec* sp, int8_t* map, int32_t* loc, int32_t* facing, i
     case NGW_ACT_RIGHT: f = TURN_RIGHT[f]; cost = sp->cost_turn; break;    /* :269-279 */
     case NGW_ACT_BREAK:                                           /* :280-294; axe: novelty_wrappers.py:144-183 */
         cost = sp->cost_break;
+        if (sp->crate_item && front == sp->crate_item)            /* Crate.step :1086-1089: the ingredients come first */
+            for (int i = 0; i < sp->n_items; i++) inv[i] += sp->crate_add[i];
+        if (sp->fence_mode && sp->breakable[front] && front != sp->fence_item) {   /* FenceRestriction.step :924-946 */
+            int restricted = 0;
+            if (sp->fence_mode == 1) {                            /* medium: fence beside the AGENT, across its facing */
+                if (f <= 1) restricted = map[r * S + c - 1] == sp->fence_item || map[r * S + c + 1] == sp->fence_item;
+                else restricted = map[(r - 1) * S + c] == sp->fence_item || map[(r + 1) * S + c] == sp->fence_item;
+            } else {                                              /* hard: any fence in the 3x3 around the block in front */
+                for (int rr = fr - 1; rr <= fr + 1; rr++)
+                    for (int cc = fc - 1; cc <= fc + 1; cc++) restricted |= map[rr * S + cc] == sp->fence_item;
+            }
+            if (restricted) { result = 0; msg = NGW_MSG_FENCE_RESTRICTION; break; }
+        }
+        if (sp->fence_mode && sp->breakable[front]) fence_twice = 1;  /* the wrapper runs env.step() AND its own epilogue */
         if (sp->breakable[front]) {
             const int axe_ok = sp->axe_item && inv[sp->axe_item] >= 1 && *selected == sp->axe_item;
             if (axe_ok) {                                         /* axe held AND selected */
@@ -321,6 +361,16 @@ void ngwo_step(const ngw_spec* sp, int8_t* map, int32_t* loc, int32_t* facing, i
             }
     int done = 0;                                                 /* :354-357 sticky via the inventory */
     if (inv[sp->goal_item] >= 1) { reward = sp->reward_done; done = 1; }
+    if (fence_twice) {                                            /* FenceRestriction.step :949-972 after env.step(): its own info */
+        result = 1; cost = sp->cost_break; msg = NGW_MSG_NONE; arg = 0;   /* ... and a second step_count += 1 (:966) */
+        *step_count += 1;
+    }
+    if (sp->fire_item) {                                          /* FireWall.step :1168-1187, after the wrapped step */
+        if (map[(r - 1) * S + c] == sp->fire_item || map[(r + 1) * S + c] == sp->fire_item ||
+            map[r * S + c - 1] == sp->fire_item || map[r * S + c + 1] == sp->fire_item) {
+            reward = sp->fire_reward; done = 1; msg = NGW_MSG_FIRE_WALL; arg = 0;
+        }
+    }
     loc[0] = r; loc[1] = c; *facing = f;
     *step_count += 1;                                             /* :362 */
     *reward_out = reward;

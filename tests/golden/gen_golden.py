@@ -66,12 +66,26 @@ CFGS = {
     'axehardi12':  (BOW, 12, ('axe', 'hard', 'iron', 'true')),      # new item 'iron' (add_new_items -> reset at injection)
     'atbhard10':   (POGO, 10, ('axetobreak', 'hard', 'wooden', '')),   # ingredients start in the inventory
     'atbhardi11':  (BOW, 11, ('axetobreak', 'hard', 'iron', '')),
+    # reset-time map edits + step predicates
+    'fence10e':    (POGO, 10, ('fence', 'easy', 'oak', '')),
+    'fence12h':    (BOW, 12, ('fence', 'hard', 'jungle', '')),
+    'fencer10e':   (POGO, 10, ('fencerestriction', 'easy', 'oak', '')),
+    'fencer10m':   (POGO, 10, ('fencerestriction', 'medium', 'oak', '')),
+    'fencer12h':   (BOW, 12, ('fencerestriction', 'hard', 'jungle', '')),
+    'repl10m':     (POGO, 10, ('replaceitem', 'medium', 'tree_log', 'brick')),
+    'replwall12e': (BOW, 12, ('replaceitem', 'easy', 'wall', 'brick')),
+    'fire10h':     (POGO, 10, ('firewall', 'hard', '', '')),
+    'fire14m':     (BOW, 14, ('firewall', 'medium', '', '')),
+    'crate10m':    (POGO, 10, ('crate', 'medium', '', '')),
+    'crate12h':    (BOW, 12, ('crate', 'hard', '', '')),
+    'crate11e':    (POGO, 11, ('crate', 'easy', '', '')),
     # the v0 variants
     'pogov0_10':   (POGO0, 10, None),
     'pogov0_14':   (POGO0, 14, ('axe', 'medium', 'wooden', '')),
     'bowv0_12':    (BOW0, 12, None),
 }
-REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13}      # np.random.seed right before inject_novelty
+REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13,      # np.random.seed right before inject_novelty
+              'crate10m': 31, 'crate12h': 32, 'crate11e': 33}      # (remapaction shuffles / Crate draws its ingredients there)
 DIRS = ['NORTH', 'SOUTH', 'WEST', 'EAST']
 
 
@@ -138,6 +152,11 @@ def spec_of(cfg):
         'reward_intermediate': base.reward_intermediate, 'reward_done': base.reward_done,
         'novelty': CFGS[cfg][2],
     }
+    w = env
+    while hasattr(w, 'env'):
+        if 'crate_ingredients' in vars(w):
+            d['crate_ingredients'] = [str(x) for x in w.crate_ingredients]
+        w = w.env
     A = len(base.actions_id)
     errs = []
     for a in (A, A + 5, -1):
@@ -612,6 +631,10 @@ PLAN = {  # cfg: (reset seeds, traces, steps per trace, single-step cases, solve
     'bowv0_12': (16, 2, 1000, 3000, 0),
     'axehard10': (12, 2, 1200, 4000, 2), 'axehardi12': (8, 2, 1000, 3000, 1), 'atbhard10': (12, 2, 1200, 4000, 0),
     'atbhardi11': (8, 2, 1000, 3000, 0),
+    'fence10e': (16, 2, 1000, 2500, 0), 'fence12h': (12, 2, 800, 2000, 0), 'fencer10e': (8, 1, 800, 2000, 0),
+    'fencer10m': (16, 3, 1200, 5000, 0), 'fencer12h': (16, 3, 1200, 5000, 0), 'repl10m': (16, 2, 1000, 2500, 0),
+    'replwall12e': (16, 2, 1000, 2500, 1), 'fire10h': (16, 3, 1200, 4000, 1), 'fire14m': (16, 3, 1200, 4000, 1),
+    'crate10m': (12, 3, 1200, 4000, 2), 'crate12h': (12, 2, 1000, 3000, 1), 'crate11e': (8, 2, 1000, 2500, 1),
 }
 
 

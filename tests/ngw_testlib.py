@@ -29,8 +29,18 @@ CFGS = {
     'bowv0_12': ('NovelGridworld-Bow-v0', 12, None),
     'axehard10': (POGO, 10, ('axe', 'hard', 'wooden', '')), 'axehardi12': (BOW, 12, ('axe', 'hard', 'iron', 'true')),
     'atbhard10': (POGO, 10, ('axetobreak', 'hard', 'wooden', '')), 'atbhardi11': (BOW, 11, ('axetobreak', 'hard', 'iron', '')),
+    'fence10e': (POGO, 10, ('fence', 'easy', 'oak', '')), 'fence12h': (BOW, 12, ('fence', 'hard', 'jungle', '')),
+    'fencer10e': (POGO, 10, ('fencerestriction', 'easy', 'oak', '')), 'fencer10m': (POGO, 10, ('fencerestriction', 'medium', 'oak', '')),
+    'fencer12h': (BOW, 12, ('fencerestriction', 'hard', 'jungle', '')), 'repl10m': (POGO, 10, ('replaceitem', 'medium', 'tree_log', 'brick')),
+    'replwall12e': (BOW, 12, ('replaceitem', 'easy', 'wall', 'brick')), 'fire10h': (POGO, 10, ('firewall', 'hard', '', '')),
+    'fire14m': (BOW, 14, ('firewall', 'medium', '', '')), 'crate10m': (POGO, 10, ('crate', 'medium', '', '')),
+    'crate12h': (BOW, 12, ('crate', 'hard', '', '')), 'crate11e': (POGO, 11, ('crate', 'easy', '', '')),
 }
-REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13}
+# configurations WITHOUT reference fixtures (larger maps of pinned components: the oracle is the checker there)
+CFGS.update({'fire32m': (POGO, 32, ('firewall', 'medium', '', '')), 'fencer24h': (BOW, 24, ('fencerestriction', 'hard', 'oak', '')),
+             'repl40e': (POGO, 40, ('replaceitem', 'easy', 'wall', 'brick'))})
+NO_FIXTURES = ('fire32m', 'fencer24h', 'repl40e')
+REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13, 'crate10m': 31, 'crate12h': 32, 'crate11e': 33}
 HEADLINE = ['pogo10', 'bow20', 'axe10', 'add32']       # BASELINE.json configs 2-5
 
 _spec_json = None

@@ -57,8 +57,12 @@ def test_inject_novelty_argument_errors_match_reference():
         with pytest.raises(AssertionError) as ei:
             G.inject_novelty(env, *args)
         assert exc == 'AssertionError' and str(ei.value) == text
-    with pytest.raises(NotImplementedError):
-        apply_novelty(make_spec(T.POGO), 'firewall', 'hard')
+    from gym_novel_gridworlds_amd.novelty import NOVELTY_NAMES
+    for name in NOVELTY_NAMES:                 # every name inject_novelty accepts compiles to kernel tables
+        env_id = T.BOW if name == 'extractincdec' else T.POGO
+        arg1 = {'additem': 'arrow', 'axe': 'wooden', 'axetobreak': 'iron', 'extractincdec': 'decrease', 'fence': 'oak',
+                'fencerestriction': 'oak', 'replaceitem': 'tree_log'}.get(name, '')
+        apply_novelty(make_spec(env_id), name, 'hard', arg1, 'brick' if name == 'replaceitem' else '').compile()
 
 
 def test_placement_exhaustion_raises_assertion():

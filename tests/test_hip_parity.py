@@ -8,7 +8,7 @@ from gym_novel_gridworlds_amd.spec import make_spec
 from oracle.ngw_oracle import Oracle
 
 pytestmark = pytest.mark.gpu
-ALL = list(T.CFGS)
+ALL = [c for c in T.CFGS if c not in T.NO_FIXTURES]
 STATE_KEYS = ('map', 'loc', 'facing', 'inv', 'selected', 'step_count', 'episode')
 
 
@@ -45,7 +45,10 @@ def test_solved_episodes_match_reference(cfg):
 @pytest.mark.parametrize('cfg,n', [('pogo10', 5000), ('bow20', 1500), ('axe10', 4096), ('add32', 300), ('pogo13', 777),
                                    ('bow10', 1000), ('axe12bi', 1000), ('add12m', 640), ('add11e', 500), ('bowaxe16', 900),
                                    ('axeeasy10', 700), ('pogov0_10', 2000), ('pogov0_14', 600), ('bowv0_12', 600), ('axetbm12', 500),
-                                   ('chop10', 300)])
+                                   ('chop10', 300), ('axehard10', 800), ('axehardi12', 500), ('atbhard10', 500), ('fence10e', 1500),
+                                   ('fence12h', 700), ('fencer10m', 1000), ('fencer12h', 600), ('repl10m', 1000), ('replwall12e', 800),
+                                   ('fire10h', 1500), ('fire14m', 600), ('crate10m', 1000), ('crate12h', 600), ('fire32m', 200),
+                                   ('fencer24h', 333), ('repl40e', 130)])
 def test_reset_matches_oracle(cfg, n):
     """reset(): template + per-env Philox item scatter (+ AddItem pass), three episodes, ragged N, masked reset."""
     spec = T.build_spec(cfg)
@@ -65,7 +68,11 @@ def test_reset_matches_oracle(cfg, n):
 
 
 @pytest.mark.parametrize('cfg,n,steps,horizon', [('pogo10', 4096, 260, 50), ('bow20', 1024, 150, 40), ('axe10', 4096, 260, 50),
-                                                 ('add32', 256, 60, 25), ('axe12bi', 1000, 120, 30), ('bow10', 999, 150, 0)])
+                                                 ('add32', 256, 60, 25), ('axe12bi', 1000, 120, 30), ('bow10', 999, 150, 0),
+                                                 ('fencer10m', 2048, 200, 40), ('fencer12h', 777, 120, 30), ('fire10h', 4096, 200, 50),
+                                                 ('fire14m', 500, 100, 0), ('crate10m', 2048, 200, 40), ('repl10m', 1000, 120, 30),
+                                                 ('atbhard10', 1000, 150, 35), ('axehardi12', 640, 100, 30), ('fence12h', 500, 80, 25),
+                                                 ('fire32m', 128, 60, 20), ('fencer24h', 256, 60, 20)])
 def test_autoreset_steps_match_oracle(cfg, n, steps, horizon):
     """Random actions with same-step autoreset (done or horizon): outputs every step, full state at checkpoints."""
     spec = T.build_spec(cfg)
@@ -96,7 +103,8 @@ def test_autoreset_steps_match_oracle(cfg, n, steps, horizon):
     assert o.st.episode.max() >= 2
 
 
-@pytest.mark.parametrize('cfg,n,steps', [('pogo10', 8192, 330), ('axe10', 4096, 250), ('bow20', 1024, 120), ('add32', 128, 70)])
+@pytest.mark.parametrize('cfg,n,steps', [('pogo10', 8192, 330), ('axe10', 4096, 250), ('bow20', 1024, 120), ('add32', 128, 70),
+                                         ('fencer10m', 2048, 250), ('fire10h', 2048, 250), ('crate12h', 1024, 150)])
 def test_fused_rollout_matches_oracle(cfg, n, steps):
     """ngw_rollout: T steps in one launch with in-kernel uniform actions == oracle stepping the same action stream."""
     spec = T.build_spec(cfg)

@@ -9,7 +9,7 @@ import ngw_testlib as T
 from gym_novel_gridworlds_amd.spec import make_spec
 from oracle.ngw_oracle import MT19937, Oracle
 
-ALL = list(T.CFGS)
+ALL = [c for c in T.CFGS if c not in T.NO_FIXTURES]
 
 
 @pytest.mark.parametrize('cfg', ALL)
@@ -32,6 +32,8 @@ def test_spec_tables_match_reference(cfg):
         assert [[k, v] for k, v in spec.recipes[name]['input'].items()] == rec['input']
         assert [[k, v] for k, v in spec.recipes[name]['output'].items()] == rec['output']
     assert set(spec.recipes) == set(ref['recipes'])
+    if 'crate_ingredients' in ref:             # Crate.__init__ draws them from the global numpy stream at injection (:1055-1068)
+        assert spec.crate['ingredients'] == ref['crate_ingredients']
     spec.compile()
 
 

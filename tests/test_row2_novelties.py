@@ -10,6 +10,8 @@ from gym_novel_gridworlds_amd.novelty import apply_novelty
 
 ROW2 = ['brkinc10', 'brkinclog12', 'extdec10', 'axetbe10', 'axetbm12', 'remape10', 'remapm10', 'remaph10', 'chop10', 'jump12',
         'axehard10', 'axehardi12', 'atbhard10', 'atbhardi11']
+ROW3 = ['fence10e', 'fence12h', 'fencer10e', 'fencer10m', 'fencer12h', 'repl10m', 'replwall12e', 'fire10h', 'fire14m', 'crate10m',
+        'crate12h', 'crate11e']
 LIM = dict(np.load(T.GOLDEN + '/limit.npz'))
 LIMITED = {'Forward', 'Left', 'Right', 'Break', 'Craft_plank', 'Craft_stick', 'Select_tree_log'}
 
@@ -19,12 +21,18 @@ def test_argument_errors_match_reference():
         with pytest.raises(Exception) as ei:
             apply_novelty(make_spec(env_id), *args)
         assert type(ei.value).__name__ == exc and str(ei.value) == text, (args, ei.value)
-    for name in ('crate', 'firewall', 'fence', 'replaceitem'):
-        with pytest.raises(NotImplementedError):
-            apply_novelty(make_spec(T.POGO), name, 'hard', 'oak', 'brick')
+    for args, text in ((('fence', 'hard', '', ''), "For fence novelty, novelty_arg1 (attribute of fence, e.g. oak, jungle) is needed"),
+                       (('fencerestriction', 'easy', '', ''), "For fencerestriction novelty, novelty_arg1 (attribute of fence, e.g. oak, jungle) is needed"),
+                       (('replaceitem', 'easy', 'wall', ''), "For replaceitem novelty, novelty_arg1 (Item to replace) and novelty_arg2(Item to replace with) are needed"),
+                       (('replaceitem', 'easy', 'granite', 'brick'), "Item to replace (granite) is not in the original map"),
+                       (('replaceitem', 'easy', 'wall', 'plank'), "Item to replace with (plank) should be a new item"),
+                       (('crate', 'tiny', '', ''), "difficulty must be one of 'easy', 'medium', 'hard'")):
+        with pytest.raises(AssertionError) as ei:
+            apply_novelty(make_spec(T.POGO), *args)
+        assert str(ei.value) == text
 
 
-@pytest.mark.parametrize('cfg', ROW2)
+@pytest.mark.parametrize('cfg', ROW2 + ROW3)
 def test_adapter_replays_row2_traces(cfg):
     """inject_novelty on the reference-shaped single env (incl. remapaction reproducing the reference's permutation)."""
     np.random.seed(T.REMAP_SEED.get(cfg, 0))
@@ -122,7 +130,7 @@ def test_limit_actions_wrapper_on_hip_backend(kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('cfg', ['brkinc10', 'axetbm12', 'remaph10', 'axehardi12', 'atbhard10'])
+@pytest.mark.parametrize('cfg', ['brkinc10', 'axetbm12', 'remaph10', 'axehardi12', 'atbhard10', 'fencer10m', 'fire10h', 'crate10m'])
 def test_adapter_row2_on_hip_backend(cfg):
     np.random.seed(T.REMAP_SEED.get(cfg, 0))
     assert T.replay_adapter(cfg, 'hip', max_steps=150, n_single=100) > 200
