@@ -78,6 +78,7 @@ def main():
     ap.add_argument('--launch', default='graph', choices=['graph', 'eager'],
                     help='step mode: replay the K step launches from one hipGraph (default) or launch them one by one')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-stagger', action='store_true', help='skip the staggered-episode-ends side measurement')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo + --single-device: rehearse the N > 1 code path on a one-GPU box (every rank on cuda:0)')
     ap.add_argument('--single-device', action='store_true')
@@ -215,6 +216,28 @@ def main():
         add_traffic(fused['roofline'], 'rollout', n * steps)
         assert v.error_flags() == 0
 
+    # side measurement: the SAME workload with episode ends spread over the batch (step_count offset e * 7919 % H: about
+    # n / H envs reset in every batched step, a few per wavefront) - the regime of a training loop; inline placement
+    # loops vs prepared next episodes (ngw_set_reset_prefetch).  Not the headline: BASELINE's loop resets all envs together.
+    stag = None
+    if args.mode == 'step' and world == 1 and use_graph and not args.no_stagger:
+        import numpy as np
+        stag = {'what': 'episode ends staggered over the batch (~%d of %d envs reset per batched step), hipGraph replay' % (n // HORIZON, n)}
+        for key, every in (('inline_resets', 0), ('prepared_next_episodes_every_32', 32)):
+            v.set_reset_prefetch(every)
+            v.reset()
+            v.set_state(0, step_count=(np.arange(n) * 7919 % HORIZON).astype(np.int32))
+            v.graph_build(ptrs[warmup], n, 64)
+            v.graph_launch(4)
+            fence()
+            v.timing_begin()
+            v.graph_launch(8)
+            s_ms = v.timing_end() / 512
+            fence()
+            stag[key] = {'ms_per_step': round(s_ms, 6), 'value': round(n / (s_ms * 1e-3), 1), 'unit': 'env-steps/s'}
+        v.set_reset_prefetch(0)
+        assert v.error_flags() == 0
+
     if rank == 0:
         total = n * world * steps
         line = {
@@ -230,6 +253,8 @@ def main():
         }
         if fused:
             line['fused_rollout'] = fused
+        if stag:
+            line['staggered_resets'] = stag
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(spec)
             line['cpu_baseline'] = {'value': round(cb['allcores']['value'], 1), 'unit': 'env-steps/s',

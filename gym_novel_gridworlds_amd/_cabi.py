@@ -21,7 +21,7 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_out_device_ptrs', 'ngw_sync', 'ngw_error_flags', 'ngw_timing_begin', 'ngw_timing_end',
            'ngw_graph_build', 'ngw_graph_launch', 'ngw_lidar_configure', 'ngw_lidar', 'ngw_lidar_fuse',
            'ngw_get_lidar', 'ngw_lidar_device_ptr', 'ngw_host_alloc', 'ngw_host_free', 'ngw_agent_view',
-           'ngw_get_agent_view', 'ngw_agent_view_device_ptr']
+           'ngw_get_agent_view', 'ngw_agent_view_device_ptr', 'ngw_set_reset_prefetch']
 
 _lib = None
 
@@ -76,6 +76,8 @@ def lib():
     L.ngw_destroy.argtypes = [vp]
     L.ngw_set_autoreset.argtypes = [vp, C.c_int, C.c_int]
     L.ngw_set_stream.argtypes = [vp, vp]
+    if hasattr(L, 'ngw_set_reset_prefetch'):           # absent only in older builds loaded through NGW_LIB (A/B runs)
+        L.ngw_set_reset_prefetch.argtypes = [vp, i32]
     L.ngw_reset.argtypes = [vp, vp]
     L.ngw_step.argtypes = [vp, vp]
     L.ngw_step_device.argtypes = [vp, vp]

@@ -58,6 +58,8 @@ struct ngw_handle {
     uint32_t lidar_magic = 0, lidar_off_tab = 0, lidar_off_tile = 0, lidar_off_map = 0;
     int lidar_fused = 0, lidar_range = 0, lidar_beams = 0, lidar_chan = 0, lidar_ninv = 0;
     size_t lidar_lds = 0;
+    NgwNx nx = {};                        // prepared next episodes (ngw_set_reset_prefetch); all null = off
+    int prefetch_every = 0, since_refill = 0;
     int ext = 0;                          // spec uses FireWall / FenceRestriction / Crate step predicates -> EXT kernels
     int8_t* view_out = nullptr;           // AgentMap windows
     int view_size = 0;
@@ -176,6 +178,17 @@ int layout_lds(ngw_handle* h) {
     return NGW_OK;
 }
 
+// the cold reset path reads its uniform arguments from the blob: keep them in step with the launch prototype
+int upload_reset_u(ngw_handle* h) {
+    const NgwLaunch& p = h->proto;
+    NgwResetU ru = {};
+    ru.perm = h->b.perm; ru.map = h->b.map; ru.inv = h->b.inv; ru.n_pad = h->n_pad; ru.seed = p.seed;
+    ru.S = p.S; ru.S2 = p.S2; ru.K = p.K; ru.CW = p.CW; ru.perm_lds = p.perm_lds; ru.magicS = p.magicS;
+    HIP_TRY(hipMemcpyAsync(&h->dspec->ru, &ru, sizeof(ru), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NGW_OK;
+}
+
 int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, const uint8_t* mask_dev, uint64_t action_seed, int64_t t0) {
     NgwLaunch a = h->proto;
     a.b = h->b;
@@ -189,6 +202,22 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     a.t0 = t0;
     const unsigned grid = (unsigned)(h->n_pad / NGW_EPB);
     HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, (h->lidar_fused ? 1 : 0) | (h->ext ? 2 : 0), grid, h->lds_bytes, h->stream));
+    if (h->prefetch_every > 0 && (mode == NGW_MODE_STEP || mode == NGW_MODE_RESET || mode == NGW_MODE_ROLLOUT)) {
+        // Prepared next episodes: every `prefetch_every` batched steps (and right after an explicit reset) one more launch
+        // refills the shadow rows that resets have consumed since.  Same stream, so it is ordered between the steps.
+        h->since_refill += mode == NGW_MODE_RESET ? h->prefetch_every : n_steps;
+        if (h->since_refill >= h->prefetch_every) {
+            h->since_refill = 0;
+            NgwLaunch rf = h->proto;
+            rf.b = NgwBufs{};
+            rf.b.map = h->nx.map; rf.b.loc = h->nx.loc; rf.b.facing = h->nx.facing; rf.b.inv = h->nx.inv; rf.b.episode = h->nx.episode;
+            rf.b.flags = h->b.flags; rf.b.perm = h->b.perm;
+            rf.mode = NGW_MODE_REFILL; rf.n_steps = 1;
+            rf.actions = reinterpret_cast<const int32_t*>(h->b.episode);
+            rf.reset_mask = nullptr; rf.autoreset = 0; rf.horizon = 0; rf.action_seed = 0; rf.t0 = 0;
+            HIP_TRY(ngw_launch(h->dspec, &rf, h->map_mode, 0, grid, h->lds_bytes, h->stream));
+        }
+    }
     return NGW_OK;
 }
 
@@ -324,6 +353,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     p.magic = (uint32_t)((0x100000000ull + div - 1) / div);
     p.CW = ((S - 4) * (S - 4) + 31) / 32;
     if (int rc = layout_lds(h)) return bail(rc);
+    if (int rc = upload_reset_u(h)) return bail(rc);
     if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(NGW_E_HIP, "stream sync failed after allocation"));
     *out = h;
     return NGW_OK;
@@ -347,6 +377,29 @@ int ngw_set_autoreset(ngw_handle* h, int autoreset, int horizon) {
     if (horizon < 0) return fail(NGW_E_INVALID_ARG, "horizon must be >= 0");
     h->autoreset = autoreset ? 1 : 0;
     h->horizon = horizon;
+    return NGW_OK;
+}
+
+int ngw_set_reset_prefetch(ngw_handle* h, int32_t every_n_steps) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (every_n_steps < 0) return fail(NGW_E_INVALID_ARG, "every_n_steps must be >= 0");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    drop_graph(h);                                   // captured launches bake the cadence in
+    if (every_n_steps > 0 && !h->nx.episode) {
+        const size_t np = (size_t)h->n_pad, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
+        int rc = dev_alloc(h, &h->nx.map, np * S2);
+        if (!rc) rc = dev_alloc(h, &h->nx.loc, np * 2);
+        if (!rc) rc = dev_alloc(h, &h->nx.facing, np);
+        if (!rc) rc = dev_alloc(h, &h->nx.inv, np * K);
+        if (!rc) rc = dev_alloc(h, &h->nx.episode, np);
+        if (rc) { h->nx = NgwNx{}; return rc; }
+    }
+    const NgwNx on_device = every_n_steps > 0 ? h->nx : NgwNx{};      // null pointers switch the consume path off
+    HIP_TRY(hipMemcpyAsync(&h->dspec->nx, &on_device, sizeof(NgwNx), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->prefetch_every = every_n_steps;
+    h->since_refill = every_n_steps;                 // the next launch is followed by a refill
     return NGW_OK;
 }
 
@@ -604,7 +657,8 @@ int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg) {
     }
     h->lidar_len = L;
     h->lidar_range = cfg->max_range; h->lidar_beams = cfg->num_beams; h->lidar_chan = cfg->n_chan; h->lidar_ninv = cfg->n_inv;
-    if (h->lidar_fused) { drop_graph(h); if (int rc = layout_lds(h)) { h->lidar_fused = 0; layout_lds(h); return rc; } }
+    if (h->lidar_fused) { drop_graph(h); if (int rc = layout_lds(h)) { h->lidar_fused = 0; layout_lds(h); upload_reset_u(h); return rc; } }
+    if (int rc = upload_reset_u(h)) return rc;
     h->lidar_magic = (uint32_t)((0x100000000ull + (uint32_t)L - 1) / (uint32_t)L);
     h->lidar_off_tab = off_tab; h->lidar_off_tile = off_tile; h->lidar_off_map = off_map; h->lidar_lds = (size_t)off * 4;
     return NGW_OK;
@@ -618,7 +672,8 @@ int ngw_lidar_fuse(ngw_handle* h, int enable) {
     drop_graph(h);                                   // captured launches bake the LDS layout in
     const int before = h->lidar_fused;
     h->lidar_fused = enable ? 1 : 0;
-    if (int rc = layout_lds(h)) { h->lidar_fused = before; layout_lds(h); return rc; }
+    if (int rc = layout_lds(h)) { h->lidar_fused = before; layout_lds(h); upload_reset_u(h); return rc; }
+    if (int rc = upload_reset_u(h)) return rc;
     return NGW_OK;
 }
 
@@ -707,6 +762,7 @@ int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stri
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     drop_graph(h);
+    h->since_refill = 0;                              // the captured refill cadence starts from a known phase
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     int rc = NGW_OK;
     for (int i = 0; i < n_steps && !rc; i++) rc = launch(h, NGW_MODE_STEP, 1, actions_dev + (int64_t)i * step_stride, nullptr, 0, 0);

@@ -8,6 +8,7 @@
 #define NGW_EPB 64            /* envs per workgroup = one CDNA wavefront, one lane per env */
 
 enum { NGW_MODE_STEP = 0, NGW_MODE_RESET = 1, NGW_MODE_ROLLOUT = 2,
+       NGW_MODE_REFILL = 3 /* prepare next episodes in the shadow buffers: a.b = shadow set, a.actions = the main episode[] */,
        NGW_MODE_DBG_NOP = 8 /* exit at once: launch floor */, NGW_MODE_DBG_COPY = 9 /* stage in/out, no step logic */ };
 /* how a wave's map chunk is laid out in LDS: same image as HBM / odd-dword-padded rows / byte-granular (odd S) */
 enum { NGW_MAP_STRAIGHT = 0, NGW_MAP_DWORD = 1, NGW_MAP_BYTE = 2 };
@@ -71,6 +72,29 @@ struct NgwStepU {
     uint8_t axe_required;                   /* AxetoBreak*: Break fails without the selected axe */
 };
 
+/* Prepared next episodes (ngw_set_reset_prefetch): shadow buffers holding, for env e, the first state of episode
+ * nx.episode[e]; a reset whose new episode number matches copies it instead of running the placement loop.  All null
+ * when the feature is off.  Read only on the cold reset path, with scalar loads from the HBM blob. */
+struct NgwNx {
+    int8_t* map;          /* [n_pad][S*S] */
+    int32_t* loc;         /* [n_pad][2]   */
+    int32_t* facing;      /* [n_pad]      */
+    int32_t* inv;         /* [n_pad][K]   */
+    uint32_t* episode;    /* [n_pad] episode the row was prepared for (0 = nothing prepared) */
+};
+
+/* What the cold reset path needs besides the spec: static per handle, read there with scalar loads from the HBM blob
+ * (passing them as arguments of the out-of-line reset would spill the call's argument list to scratch). */
+struct NgwResetU {
+    uint16_t* perm;       /* = NgwBufs.perm */
+    int8_t* map;          /* = NgwBufs.map / .inv of the MAIN buffer set: rows a consumed prepared episode is stored to */
+    int32_t* inv;
+    int64_t n_pad;
+    uint64_t seed;
+    int32_t S, S2, K, CW, perm_lds;
+    uint32_t magicS;
+};
+
 /* Uniform parameters of the step-time novelty predicates (kernel template flag EXT): FireWall, FenceRestriction, Crate */
 struct NgwExtU {
     int32_t fire_item, fire_reward, fence_item, fence_mode, crate_item;
@@ -94,6 +118,8 @@ struct NgwDevSpec {
     int32_t n_place;
     ngw_spec sp;                 /* full spec: the (cold) reset path reads it with scalar loads */
     NgwExtU x;
+    NgwNx nx;
+    NgwResetU ru;
     double pctq[3][64];          /* per reset pass (NGW_PASS_*): pct / 100.0 for pct in [pct_lo, pct_hi) as the host's IEEE double */
 };
 

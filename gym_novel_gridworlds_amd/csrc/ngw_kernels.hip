@@ -103,6 +103,8 @@ __device__ __forceinline__ int nth_set_bit(uint32_t x, int n) {
 // in LDS, `inv` = this lane's inventory row, `cand` = candidate bitmask column (stride EPB).
 // Out of line ON PURPOSE: this is the cold path (1 % of env-steps at H = 100); inlined, its register needs spill the
 // scalars of the hot step loop.  Returns flags | r<<8 | c<<16 | facing<<24.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));                     // native vector type (VGPR quad)
+
 struct ResetArgs {
     const NgwDevSpec* dspec;
     uint16_t* perm;                 // HBM scratch [S2][n_pad] (used when the shuffle array does not fit in LDS)
@@ -160,7 +162,7 @@ __device__ __forceinline__ void run_pass(const ResetArgs& a, LDS_AS uint16_t* pe
 
 // (LDS / global pointers carry their address space: across a real call generic pointers would turn every access
 //  into a flat_* instruction)
-__device__ __noinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t* mp, LDS_AS int32_t* inv, LDS_AS uint32_t* cand,
+__device__ __forceinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t* mp, LDS_AS int32_t* inv, LDS_AS uint32_t* cand,
                                             const LDS_AS uint8_t* place_seq, LDS_AS uint16_t* perm_lds, uint64_t env_global,
                                             int64_t env_local, uint32_t episode) {
     const GLOBAL_AS ngw_spec& sp = *(const GLOBAL_AS ngw_spec*)&a.dspec->sp;
@@ -233,6 +235,80 @@ __device__ __noinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t* mp
     if (!flags)
         for (int j = 0; j < sp.n_inv_start; j++) inv[sp.inv_start_item[j]] = sp.inv_start_qty[j];   // AxeEasy.reset :33, AxetoBreakHard.reset :667-670
     return flags | ((uint32_t)r_out << 8) | ((uint32_t)c_out << 16) | ((uint32_t)f_out << 24);
+}
+
+// Prepared-next-episode fast path of a reset: if the shadow buffers hold the first state of `episode` for this env, copy
+// it into the lane's LDS map / inventory row AND straight into the env's observation rows in HBM (so the wave does not
+// have to store its whole 64-env chunk for this lane).  One HBM round trip instead of the placement loop's ~40
+// dependent draws.  A lone lane runs this, so the INSTRUCTION COUNT is what costs: rows move as 16-byte chunks whose
+// start is clamped to (row end - 16) - the last chunk overlaps its predecessor instead of being predicated per element.
+// The rows were written by an earlier launch on the same stream (NGW_MODE_REFILL): plain visible global memory.
+typedef GLOBAL_AS u32x4_t g_u32x4_t;
+__device__ __forceinline__ uint32_t consume_lane(const NgwNx nx, LDS_AS int8_t* mp, LDS_AS int32_t* inv, GLOBAL_AS int8_t* gm,
+                                                 GLOBAL_AS int32_t* gi, int64_t e, int S2, int K) {
+    const GLOBAL_AS int8_t* src = (const GLOBAL_AS int8_t*)nx.map + e * S2;
+    const GLOBAL_AS int32_t* sinv = (const GLOBAL_AS int32_t*)nx.inv + e * K;
+    const int pr = ((const GLOBAL_AS int32_t*)nx.loc)[2 * e], pc = ((const GLOBAL_AS int32_t*)nx.loc)[2 * e + 1];
+    const int f = ((const GLOBAL_AS int32_t*)nx.facing)[e];
+    constexpr int R = 8;                                                           // 16-byte chunks per round trip
+    u32x4_t q[(NGW_MAX_ITEMS + 3) / 4];
+    const int nqi = (K + 3) >> 2;                                                  // K >= 4 always (air, wall, table, goal, ...)
+#pragma unroll
+    for (int j = 0; j < (NGW_MAX_ITEMS + 3) / 4; j++) q[j] = *(const g_u32x4_t*)(sinv + min(4 * j, K - 4));
+    if ((S2 & 3) == 0) {                                                           // even S: rows are dword-aligned on both sides
+        const GLOBAL_AS uint32_t* s4 = (const GLOBAL_AS uint32_t*)src;
+        LDS_AS uint32_t* d4 = (LDS_AS uint32_t*)mp;
+        GLOBAL_AS uint32_t* g4 = (GLOBAL_AS uint32_t*)gm;
+        const int nd = S2 >> 2, nq = (nd + 3) >> 2;                                // nd >= 6 (S >= 5)
+        for (int base = 0; base < nq; base += R) {
+            u32x4_t v[R];
+#pragma unroll
+            for (int j = 0; j < R; j++) v[j] = *(const g_u32x4_t*)(s4 + min(4 * (base + j), nd - 4));
+#pragma unroll
+            for (int j = 0; j < R; j++)
+                if (base + j < nq) {
+                    const int o = min(4 * (base + j), nd - 4);
+                    *(g_u32x4_t*)(g4 + o) = v[j];
+                    d4[o] = v[j].x; d4[o + 1] = v[j].y; d4[o + 2] = v[j].z; d4[o + 3] = v[j].w;
+                }
+        }
+    } else {                                                                       // odd S: byte rows
+        for (int base = 0; base < S2; base += 16) {
+            const int o = min(base, S2 - 16);
+            int8_t v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = src[o + j];
+#pragma unroll
+            for (int j = 0; j < 16; j++) { mp[o + j] = v[j]; gm[o + j] = v[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < (NGW_MAX_ITEMS + 3) / 4; j++)
+        if (j < nqi) {
+            const int o = min(4 * j, K - 4);
+            *(g_u32x4_t*)(gi + o) = q[j];
+            inv[o] = (int)q[j].x; inv[o + 1] = (int)q[j].y; inv[o + 2] = (int)q[j].z; inv[o + 3] = (int)q[j].w;
+        }
+    return ((uint32_t)pr << 8) | ((uint32_t)pc << 16) | ((uint32_t)f << 24);
+}
+
+// The one out-of-line entry of the cold path: a prepared row if there is one, else the placement loop.  Bit
+// NGW_F_ROWS_STORED of the result says the env's rows are already in HBM (the wave need not store its chunk for it).
+constexpr uint32_t NGW_F_ROWS_STORED = 0x80u;
+__device__ __noinline__ uint32_t new_episode(const NgwDevSpec* dspec, LDS_AS int8_t* mp, LDS_AS int32_t* inv, LDS_AS uint32_t* cand,
+                                             const LDS_AS uint8_t* place_seq, LDS_AS uint16_t* perm_lds, uint64_t env_global,
+                                             int64_t env_local, uint32_t episode, bool may_consume) {
+    const GLOBAL_AS NgwResetU* rp = (const GLOBAL_AS NgwResetU*)&dspec->ru;        // both blobs requested together
+    const GLOBAL_AS NgwNx* np = (const GLOBAL_AS NgwNx*)&dspec->nx;
+    NgwResetU ru; NgwNx nx;
+    ru.perm = rp->perm; ru.map = rp->map; ru.inv = rp->inv; ru.n_pad = rp->n_pad; ru.seed = rp->seed; ru.S = rp->S;
+    ru.S2 = rp->S2; ru.K = rp->K; ru.CW = rp->CW; ru.perm_lds = rp->perm_lds; ru.magicS = rp->magicS;
+    nx.map = np->map; nx.loc = np->loc; nx.facing = np->facing; nx.inv = np->inv; nx.episode = np->episode;
+    if (may_consume && nx.episode && ((const GLOBAL_AS uint32_t*)nx.episode)[env_local] == episode)
+        return consume_lane(nx, mp, inv, (GLOBAL_AS int8_t*)ru.map + env_local * ru.S2, (GLOBAL_AS int32_t*)ru.inv + env_local * ru.K,
+                            env_local, ru.S2, ru.K) | NGW_F_ROWS_STORED;
+    const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS};
+    return reset_lane(a, mp, inv, cand, place_seq, perm_lds, env_global, env_local, episode);
 }
 
 // ---------------------------------------------------------------- map staging HBM <-> LDS (coalesced 16-B pieces)
@@ -457,18 +533,30 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
         for (int j = 0; j < 8; j++) ltb[j] = src[tid + EPB * j];
         if (tid < 2 * NGW_MAX_ITEMS / 4) lit = reinterpret_cast<const uint32_t*>(a.lcfg->chan_of_item)[tid];
     }
+    int r = 1, c = 1, f = 0, sel = 0, steps = 0, action = 0;
+    uint32_t episode = 0, nx_old = 0;
+    if (MODE == NGW_MODE_REFILL) {
+        // a.b is the SHADOW set; a.actions carries the main episode[].  A row is stale unless it was prepared for the
+        // env's NEXT episode.  Waves without a stale row leave before touching anything else.
+        if (live) {
+            nx_old = a.b.episode[e];
+            const uint32_t main_ep = reinterpret_cast<const uint32_t*>(a.actions)[e];
+            if (nx_old != main_ep + 1u) { action = 1; episode = main_ep; } else episode = nx_old;
+        }
+        if (!__any(action)) return;
+    }
     u32x4 buf[PB];
     const u32x4* gin = reinterpret_cast<const u32x4*>(a.b.map + env0 * a.S2);
     pieces_load(buf, gin, 0, npieces, tid);
-    int r = 1, c = 1, f = 0, sel = 0, steps = 0, action = 0;
-    uint32_t episode = 0;
     if (live) {
         const int2 rc = reinterpret_cast<const int2*>(a.b.loc)[e];
         r = rc.x; c = rc.y;
         f = a.b.facing[e];
-        sel = a.b.selected[e];
-        steps = a.b.step_count[e];
-        episode = a.b.episode[e];
+        if (MODE != NGW_MODE_REFILL) {
+            sel = a.b.selected[e];
+            steps = a.b.step_count[e];
+            episode = a.b.episode[e];
+        }
         if (MODE == NGW_MODE_STEP) action = a.actions[e];
         else if (MODE == NGW_MODE_RESET) action = a.reset_mask ? (int)a.reset_mask[e] : 1;
     }
@@ -558,7 +646,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     for (int t = 0; t < n_steps; t++, tt++) {
         bool do_reset = false;
         if (live && mode != NGW_MODE_DBG_COPY) {
-            if (mode == NGW_MODE_RESET) {
+            if (mode == NGW_MODE_RESET || mode == NGW_MODE_REFILL) {
                 do_reset = action != 0;
             } else {
                 if (mode == NGW_MODE_ROLLOUT) {
@@ -753,10 +841,13 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
             }
             if (do_reset) {                                                        // cold path, out of line
                 episode++;
-                const ResetArgs ra = {dspec, a.b.perm, a.n_pad, a.seed, S, a.S2, K, a.CW, a.perm_lds, a.magicS};
-                const uint32_t rr = reset_lane(ra, (LDS_AS int8_t*)mp, (LDS_AS int32_t*)inv, (LDS_AS uint32_t*)cand,
-                                               (const LDS_AS uint8_t*)(lds_act + NGW_MAX_ACTIONS * NGW_ACT_DW),
-                                               (LDS_AS uint16_t*)(lds + a.off_perm), env_global, e, episode);
+                uint32_t rr = new_episode(dspec, (LDS_AS int8_t*)mp, (LDS_AS int32_t*)inv, (LDS_AS uint32_t*)cand,
+                                          (const LDS_AS uint8_t*)(lds_act + NGW_MAX_ACTIONS * NGW_ACT_DW),
+                                          (LDS_AS uint16_t*)(lds + a.off_perm), env_global, e, episode, mode != NGW_MODE_REFILL);
+                do_reset = !(rr & NGW_F_ROWS_STORED);                              // from here on: "the wave must store its chunk"
+                rr &= ~(uint32_t)NGW_F_ROWS_STORED;
+                if (mode == NGW_MODE_REFILL && (rr & 0xFFu)) { rr &= ~0xFFu; episode = nx_old; }   // failed placement: leave the row
+                                                                                   // stale, the real reset raises the flag
                 flags |= rr & 0xFFu;
                 r = (int)((rr >> 8) & 0xFFu); c = (int)((rr >> 16) & 0xFFu); f = (int)(rr >> 24);
                 sel = 0; steps = 0;
@@ -780,7 +871,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
         if (live) {
             gloc->x = r; gloc->y = c;
             *gfac = f;
-            if (mode != NGW_MODE_RESET) {
+            if (mode != NGW_MODE_RESET && mode != NGW_MODE_REFILL) {
                 *grew = reward;
                 *gdone = (uint8_t)ended;
                 *ginfo = info;
@@ -806,8 +897,10 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
         }
     }
     if (live) {
-        a.b.selected[e] = (uint8_t)sel;
-        a.b.step_count[e] = steps;
+        if (MODE != NGW_MODE_REFILL) {
+            a.b.selected[e] = (uint8_t)sel;
+            a.b.step_count[e] = steps;
+        }
         a.b.episode[e] = episode;
     }
     if (flags) atomicOr(a.b.flags, flags);
@@ -975,6 +1068,7 @@ static hipError_t launch_mode(const NgwDevSpec* dspec, const NgwLaunch* a, unsig
     case NGW_MODE_ROLLOUT: return launch_one<MAPMODE, NGW_MODE_ROLLOUT, LIDAR, EXT>(dspec, a, grid, lds_bytes, stream);
     default: break;
     }
+    if (a->mode == NGW_MODE_REFILL) return launch_one<MAPMODE, NGW_MODE_REFILL, false, false>(dspec, a, grid, lds_bytes, stream);
     if (LIDAR || EXT) return hipErrorInvalidValue;
     if (a->mode == NGW_MODE_DBG_COPY) return launch_one<MAPMODE, NGW_MODE_DBG_COPY, false, false>(dspec, a, grid, lds_bytes, stream);
     return launch_one<MAPMODE, NGW_MODE_DBG_NOP, false, false>(dspec, a, grid, lds_bytes, stream);

@@ -26,7 +26,7 @@ class _DevArray:
 
 class VecNovelGridworld:
     def __init__(self, env_id='NovelGridworld-Pogostick-v1', num_envs=1, map_size=None, novelty=None, device=0,
-                 seed=0, autoreset=False, horizon=0, env_index_base=0, spec=None):
+                 seed=0, autoreset=False, horizon=0, env_index_base=0, spec=None, reset_prefetch=0):
         if spec is None:
             spec = make_spec(env_id, map_size)
             if novelty:
@@ -53,6 +53,9 @@ class VecNovelGridworld:
                                  C.byref(self._h)))
         self.autoreset, self.horizon = bool(autoreset), int(horizon)
         _cabi.check(L.ngw_set_autoreset(self._h, int(self.autoreset), self.horizon))
+        self.reset_prefetch = 0
+        if reset_prefetch:
+            self.set_reset_prefetch(reset_prefetch)
         N, S, K = self.num_envs, self.map_size, self.n_items
         pin = _cabi.pinned_array                              # page-locked: D2H / H2D at full PCIe rate (API mode)
         self._obs = {'map': pin((N, S, S), np.int8), 'agent_location': pin((N, 2), np.int32),
@@ -141,6 +144,13 @@ class VecNovelGridworld:
     def step_device(self, actions_ptr):
         """One batched step with int32 actions already in HBM (`actions_ptr` = device address, e.g. tensor.data_ptr())."""
         _cabi.check(_cabi.lib().ngw_step_device(self._h, C.c_void_p(int(actions_ptr))))
+
+    def set_reset_prefetch(self, every_n_steps):
+        """Keep every env's NEXT episode prepared in shadow buffers and re-prepare consumed ones every `every_n_steps`
+        batched steps (include/ngw.h ngw_set_reset_prefetch): resets become a row copy, which matters when episode ends
+        are spread over the batch (a few envs per step).  Bit-identical results; 0 switches it off."""
+        _cabi.check(_cabi.lib().ngw_set_reset_prefetch(self._h, int(every_n_steps)))
+        self.reset_prefetch = int(every_n_steps)
 
     def rollout(self, n_steps, action_seed=1234, t0=0):
         """Fused mode: n_steps steps in one launch with on-device uniform actions."""

@@ -188,6 +188,13 @@ int ngw_destroy(ngw_handle* h);
  * one; reward/info are the terminal step's, done = 1 for both endings (info bit 1 set only for goal-done). */
 int ngw_set_autoreset(ngw_handle* h, int autoreset, int horizon);
 /* Run the handle's kernels on an external hipStream_t (e.g. torch's current stream); NULL = own stream. */
+/* Prepared next episodes.  A reset (explicit, or the same-step autoreset) normally runs the reference's placement loop
+ * (~40 dependent random draws per env) inside the step launch; when only a few envs of a batch end in a given step, the
+ * whole launch waits for them.  With every_n_steps > 0 the library keeps, per env, the first state of its NEXT episode
+ * in shadow buffers: a reset then copies that row (one memory round trip), and one extra launch every `every_n_steps`
+ * batched steps (and after every ngw_reset) re-prepares the rows consumed since.  Results are bit-identical with the
+ * feature on or off (the shadow row is the output of the same per-(env, episode) Philox stream).  0 = off (default). */
+int ngw_set_reset_prefetch(ngw_handle* h, int32_t every_n_steps);
 int ngw_set_stream(ngw_handle* h, void* hip_stream);
 
 /* reset(): pogostick_v1_env.py:86-157 (+ AddItem.reset).  mask = NULL resets all envs, else mask[i] != 0. */

@@ -124,6 +124,54 @@ def test_fused_rollout_matches_oracle(cfg, n, steps):
     assert v.error_flags() == 0
 
 
+@pytest.mark.parametrize('cfg,n,steps,horizon,every', [('pogo10', 4096, 260, 50, 8), ('pogo10', 3000, 120, 7, 1), ('fire10h', 4096, 200, 50, 4),
+                                                       ('add32', 256, 60, 25, 16), ('bow20', 1000, 120, 30, 64), ('pogo13', 777, 100, 20, 3),
+                                                       ('fencer10m', 1500, 120, 30, 5)])
+def test_prepared_next_episodes_are_bit_identical(cfg, n, steps, horizon, every):
+    """ngw_set_reset_prefetch: resets served from the shadow rows (staggered episode ends, instant deaths, explicit masked
+    resets, a stale row after set_state(episode=...), fused rollout, graph replay) give exactly the oracle's states."""
+    import torch
+    spec = T.build_spec(cfg)
+    A = len(spec.actions_id)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=21, autoreset=True, horizon=horizon, reset_prefetch=every)
+    o = Oracle(spec.compile(), n, seed=21, autoreset=True, horizon=horizon)
+    v.reset(); o.reset()
+    stag = (np.arange(n) * 7919 % horizon).astype(np.int32)            # episode ends spread over the batch
+    v.set_state(0, step_count=stag); o.st.step_count[:] = stag
+    rs = np.random.RandomState(4)
+    for t in range(steps):
+        if t == steps // 3:                                             # explicit masked reset in between
+            mask = (np.arange(n) % 5 == 1).astype(np.uint8)
+            v.reset(mask); o.reset(mask)
+        if t == steps // 2:                                             # make every prepared row stale for a third of the envs
+            ep = o.st.episode.copy(); ep[::3] += 1000
+            v.set_state(0, episode=ep); o.st.episode[:] = ep
+        a = rs.randint(0, A, size=n).astype(np.int32)
+        _, reward, done, info = v.step(a)
+        assert o.step(a) == 0
+        where = '%s step %d' % (cfg, t)
+        assert (reward == o.reward).all() and (done == o.done.astype(bool)).all(), where
+        assert (info['message_code'] == o.msg_code).all(), where
+        if t % 20 == 19 or t == steps - 1:
+            assert_state_equal(v, o, where)
+    v.rollout(2 * horizon + 3, action_seed=77, t0=9); assert o.rollout(2 * horizon + 3, 77, 9) == 0
+    assert_state_equal(v, o, cfg + ' rollout')
+    acts = torch.randint(0, A, (6, n), dtype=torch.int32, device='cuda')
+    torch.cuda.synchronize()
+    v.graph_build(acts.data_ptr(), n, 6); v.graph_launch(horizon // 6 + 3)
+    an = acts.cpu().numpy()
+    for rep in range(horizon // 6 + 3):
+        for t in range(6):
+            o.step(an[t])
+    assert_state_equal(v, o, cfg + ' graph')
+    v.set_reset_prefetch(0)                                             # off again: inline resets
+    for t in range(horizon + 2):
+        a = rs.randint(0, A, size=n).astype(np.int32)
+        v.step(a); o.step(a)
+    assert_state_equal(v, o, cfg + ' prefetch off')
+    assert o.st.episode.min() >= 3 and v.error_flags() == 0
+
+
 # ------------------------------------------------------------------ BASELINE sizes: size-independent properties
 def test_full_size_properties_pogostick_65536():
     """BASELINE config 2 at full size: determinism, shard independence, structural invariants, oracle on a sample."""

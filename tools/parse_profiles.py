@@ -24,12 +24,19 @@ def one(pattern):
     return f[-1] if f else None
 
 
-def kernel_rows(path):
-    return [r for r in csv.DictReader(open(path)) if 'ngw_kernel' in r['Kernel_Name']]
+def kernel_mode(name):
+    """MODE template argument of ngw_kernel<MAPMODE, MODE, LIDAR, EXT>: 0 step, 1 reset, 2 rollout, 3 refill"""
+    import re
+    m = re.search(r'ngw_kernel<\d+, (\d+),', name)
+    return int(m.group(1)) if m else -1
+
+
+def kernel_rows(path, modes):
+    return [r for r in csv.DictReader(open(path)) if kernel_mode(r['Kernel_Name']) in modes]
 
 
 out = ['# rocprofv3 --kernel-trace --stats summaries (%s)\n' % tag,
-       'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --steps 400 --warmup 100 [--mode rollout]`',
+       'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-stagger --steps 400 --warmup 100 [--mode rollout]`',
        '(workload C2: NovelGridworld-Pogostick-v1, 65 536 envs, 10x10, autoreset H=100).\n']
 for mode in ('step', 'rollout'):
     f = one('stats_%s/**/*kernel_stats.csv' % mode)
@@ -42,7 +49,7 @@ for mode in ('step', 'rollout'):
         name = r['Name'] if len(r['Name']) < 90 else r['Name'][:87] + '...'
         out.append('| `%s` | %s | %s | %.1f | %s | %s | %s |' % (name, r['Calls'], r['TotalDurationNs'], float(r['AverageNs']),
                                                               r['Percentage'], r['MinNs'], r['MaxNs']))
-    rows = kernel_rows(one('stats_%s/**/*kernel_trace.csv' % mode))
+    rows = kernel_rows(one('stats_%s/**/*kernel_trace.csv' % mode), (0, 1) if mode == 'step' else (1, 2))
     d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows]
     out.append('')
     if mode == 'step':
@@ -64,12 +71,30 @@ for mode in ('step', 'rollout'):
         out.append('Per-dispatch: reset-all %.1f us; warm-up rollout (100 steps) %.1f us; timed rollout (400 steps) %.1f us = %.3f us per batched step.'
                    % (d[0], d[1], d[2], d[2] / 400))
     out.append('')
+for run, title in (('stagger_inline', 'inline resets'), ('stagger_prefetch', 'prepared next episodes, refill every 32 steps (NGW_PREFETCH=32)')):
+    f = one('stats_%s/**/*kernel_stats.csv' % run)
+    if not f:
+        continue
+    out.append('## staggered episode ends - %s\n' % title)
+    out.append('Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/stagger_rate.py` (C2; first a synchronized '
+               'run, then step_count offsets e * 7919 % 100: ~655 of 65 536 envs reset in every batched step).\n')
+    log = os.path.join(src, 'stats_%s.log' % run)
+    if os.path.exists(log):
+        out += ['```'] + [l.rstrip() for l in open(log) if 'horizon' in l] + ['```', '']
+    out.append('| kernel | calls | total ns | average ns | % | min ns | max ns |')
+    out.append('|---|---|---|---|---|---|---|')
+    for r in csv.DictReader(open(f)):
+        name = r['Name'] if len(r['Name']) < 90 else r['Name'][:87] + '...'
+        out.append('| `%s` | %s | %s | %.1f | %s | %s | %s |' % (name, r['Calls'], r['TotalDurationNs'], float(r['AverageNs']),
+                                                              r['Percentage'], r['MinNs'], r['MaxNs']))
+    out.append('')
 open(os.path.join(dst, tag + '_kernel_stats.md'), 'w').write('\n'.join(out) + '\n')
 
 
 def counter(run, name):
     f = one('pmc_%s_%s/**/*counter_collection.csv' % (run, name))
-    rows = [r for r in csv.DictReader(open(f)) if 'ngw_kernel' in r['Kernel_Name'] and r['Counter_Name'] == name]
+    modes = {'step': (0, 1), 'rollout': (1, 2), 'calib': (1, 9)}[run]      # the reset launch stays in as element [0]
+    rows = [r for r in csv.DictReader(open(f)) if kernel_mode(r['Kernel_Name']) in modes and r['Counter_Name'] == name]
     return [float(r['Counter_Value']) for r in rows]
 
 
