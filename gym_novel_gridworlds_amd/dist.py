@@ -24,7 +24,7 @@ class ShardedVecNovelGridworld:
     """Rank-local view of `global_num_envs` environments sharded over the ranks of a torch.distributed group."""
 
     def __init__(self, env_id='NovelGridworld-Pogostick-v1', global_num_envs=65536, map_size=None, novelty=None, seed=0,
-                 autoreset=False, horizon=0, spec=None, device=None, group=None, local_factory=None):
+                 autoreset=False, horizon=0, spec=None, device=None, group=None, local_factory=None, reset_prefetch=0):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -38,7 +38,8 @@ class ShardedVecNovelGridworld:
         else:
             import torch
             dev = torch.cuda.current_device() if device is None else device
-            self.local = VecNovelGridworld(env_id=env_id, map_size=map_size, novelty=novelty, spec=spec, device=dev, **kw)
+            self.local = VecNovelGridworld(env_id=env_id, map_size=map_size, novelty=novelty, spec=spec, device=dev,
+                                           reset_prefetch=reset_prefetch, **kw)
         self.spec = self.local.spec
 
     # step / reset are purely local

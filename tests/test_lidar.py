@@ -140,8 +140,9 @@ def test_lidar_wrapper_on_vec_env_follows_steps():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('cfg,n,steps', [('pogo10', 4000, 60), ('bow20', 700, 40), ('axe10', 2048, 60), ('add32', 128, 30)])
-def test_fused_lidar_epilogue_matches_oracle(cfg, n, steps):
+@pytest.mark.parametrize('cfg,n,steps,prefetch', [('pogo10', 4000, 60, 0), ('bow20', 700, 40, 0), ('axe10', 2048, 60, 0), ('add32', 128, 30, 0),
+                                                  ('pogo10', 3000, 60, 5), ('bow20', 500, 40, 3)])
+def test_fused_lidar_epilogue_matches_oracle(cfg, n, steps, prefetch):
     """ngw_lidar_fuse: reset / step / rollout launches refresh the lidar observation themselves; it equals the oracle's
     lidar of the oracle's state after every launch, and the plain state stays bit-exact too."""
     import torch
@@ -149,7 +150,7 @@ def test_fused_lidar_epilogue_matches_oracle(cfg, n, steps):
     from oracle.ngw_oracle import Oracle, lidar
     spec, lc = lidar_setup(cfg)
     A, S, K = len(spec.actions_id), spec.map_size, len(spec.items_id)
-    v = G.VecNovelGridworld(spec=spec, num_envs=n, seed=13, autoreset=True, horizon=17)
+    v = G.VecNovelGridworld(spec=spec, num_envs=n, seed=13, autoreset=True, horizon=17, reset_prefetch=prefetch)
     v.lidar_configure(lc, fused=True)
     o = Oracle(spec.compile(), n, seed=13, autoreset=True, horizon=17)
     cc = lc.compile(spec)
