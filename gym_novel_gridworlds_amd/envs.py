@@ -264,6 +264,41 @@ class _NovelGridworldEnv(_EnvBase):
             self.items_quantity.update({item: new_items_quantity[item]})
         self.reset()
 
+    # ---- public map / table editing helpers of the reference env (host attributes are the truth between calls; the next
+    #      step() pushes them to the device).  The placement and craft internals (add_item_to_map, craft) live in the kernels.
+    def remap_action(self, actions_id, start_action_id):
+        """Shuffle action names with the global numpy stream until the table changes (:476-493)."""
+        from .novelty import _remap_action
+        return _remap_action(actions_id, start_action_id)
+
+    def add_fence_around(self, item_location, fence_name):
+        """Every free 8-neighbour of `item_location` except the agent cell becomes `fence_name` (:524-536)."""
+        r, c = item_location
+        for rr in (r - 1, r, r + 1):
+            for cc in (c - 1, c, c + 1):
+                if self.map[rr][cc] == 0 and (rr, cc) != self.agent_location:
+                    self.map[rr][cc] = self.items_id[fence_name]
+
+    def block_items(self, item_to_block, item_to_block_from):
+        """Put `item_to_block_from` on the free in-bounds 4-neighbours of every `item_to_block` (:503-522)."""
+        rows, cols = np.where(self.map == self.items_id[item_to_block])
+        for r, c in zip(rows, cols):
+            for rr, cc in ((r - 1, c), (r + 1, c), (r, c - 1), (r, c + 1)):
+                if 0 <= rr <= self.map_size - 1 and 0 <= cc <= self.map_size - 1 and self.map[rr][cc] == 0 \
+                        and (rr, cc) != self.agent_location:
+                    self.map[rr][cc] = self.items_id[item_to_block_from]
+
+    def grab_entities(self, location=None):
+        """Entities in the 3x3 around `location` (default: the agent) go to the inventory (:538-554)."""
+        r, c = self.agent_location if location is None else location
+        names = {v: k for k, v in self.items_id.items()}
+        for rr in (r - 1, r, r + 1):
+            for cc in (c - 1, c, c + 1):
+                ent = int(self.map[rr][cc])
+                if ent != 0 and names[ent] in self.entities:
+                    self.map[rr][cc] = 0
+                    self.inventory_items_quantity[names[ent]] += 1
+
     def render(self, mode='human', title=None):
         raise NotImplementedError("rendering is outside the batched hot path (SURVEY.md §2 row 12)")
 

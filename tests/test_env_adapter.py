@@ -100,3 +100,31 @@ def test_gym_registration_with_classic_gym_standin():
         sys.path.remove(shim)
         for m in [m for m in sys.modules if m == 'gym' or m.startswith('gym.')]:
             del sys.modules[m]
+
+
+def test_public_map_editing_helpers():
+    """add_fence_around / block_items / grab_entities / remap_action edit the host attributes like the reference's
+    (pogostick_v1_env.py:476-554) and the next step sees the edited state."""
+    env = T.make_adapter_env('axe10', 'oracle')
+    base = env.env
+    env.reset()
+    base.map[...] = 0
+    base.map[0, :] = base.map[-1, :] = base.map[:, 0] = base.map[:, -1] = base.items_id['wall']
+    base.set_agent_location(4, 4); base.set_agent_facing('NORTH')
+    base.map[6][6] = base.items_id['crafting_table']
+    base.items.add('oak_fence'); base.items_id.setdefault('oak_fence', len(base.items_id))
+    base.add_fence_around((5, 5), 'oak_fence')
+    f = base.items_id['oak_fence']
+    assert base.map[4][4] == 0 and base.map[6][6] == base.items_id['crafting_table']        # agent cell and occupied cells stay
+    assert [(r, c) for r in range(4, 7) for c in range(4, 7) if base.map[r][c] == f] == [(4, 5), (4, 6), (5, 4), (5, 5), (5, 6), (6, 4), (6, 5)]
+    base.map[base.map == f] = 0
+    base.block_items('crafting_table', 'tree_log')
+    assert [base.map[5][6], base.map[7][6], base.map[6][5], base.map[6][7]] == [base.items_id['tree_log']] * 4
+    base.map[3][3] = base.map[5][5] = base.items_id['wooden_axe']                             # an entity in the agent's 3x3, twice
+    base.grab_entities()
+    assert base.inventory_items_quantity['wooden_axe'] == 2 and base.map[3][3] == 0 and base.map[5][5] == 0
+    obs, reward, done, info = env.step(base.actions_id['Select_wooden_axe'])                 # the device sees the edited inventory
+    assert info['result'] is True and base.selected_item == 'wooden_axe'
+    np.random.seed(2)
+    new = base.remap_action({'Forward': 0, 'Left': 1, 'Right': 2}, 0)
+    assert sorted(new.values()) == [0, 1, 2] and new != {'Forward': 0, 'Left': 1, 'Right': 2}
