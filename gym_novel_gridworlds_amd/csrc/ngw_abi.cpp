@@ -60,6 +60,7 @@ struct ngw_handle {
     size_t lidar_lds = 0;
     NgwNx nx = {};                        // prepared next episodes (ngw_set_reset_prefetch); all null = off
     int prefetch_every = 0, since_refill = 0;
+    uint32_t off_rng = 0;                 // LDS dword offset of the reset path's Philox ring
     int ext = 0;                          // spec uses FireWall / FenceRestriction / Crate step predicates -> EXT kernels
     int8_t* view_out = nullptr;           // AgentMap windows
     int view_size = 0;
@@ -171,6 +172,7 @@ int layout_lds(ngw_handle* h) {
         p.lcfg = h->lidar_cfg; p.lout = h->lidar_out; p.lidar_len = h->lidar_len;
         p.l_beams = h->lidar_beams; p.l_range = h->lidar_range; p.l_chan = h->lidar_chan; p.l_inv = h->lidar_ninv;
     }
+    h->off_rng = off; off += (uint32_t)(NGW_EPB * 32);      // Philox word ring of the reset path (ngw_kernels.hip PHILOX_RING)
     if ((size_t)off * 4 > 160 * 1024)
         return fail(NGW_E_INVALID_ARG, "map_size %d%s needs %zu B of LDS per wavefront (> 160 KiB)", S,
                     h->lidar_fused ? " with the fused lidar observation" : "", (size_t)off * 4);
@@ -183,7 +185,17 @@ int upload_reset_u(ngw_handle* h) {
     const NgwLaunch& p = h->proto;
     NgwResetU ru = {};
     ru.perm = h->b.perm; ru.map = h->b.map; ru.inv = h->b.inv; ru.n_pad = h->n_pad; ru.seed = p.seed;
-    ru.S = p.S; ru.S2 = p.S2; ru.K = p.K; ru.CW = p.CW; ru.perm_lds = p.perm_lds; ru.magicS = p.magicS;
+    ru.S = p.S; ru.S2 = p.S2; ru.K = p.K; ru.CW = p.CW; ru.perm_lds = p.perm_lds; ru.magicS = p.magicS; ru.off_rng = h->off_rng;
+    const ngw_spec& s = h->spec;
+    ru.wall_item = s.wall_item; ru.tap_item = s.tap_item; ru.tap_near = s.tap_near;
+    int n_place = 0;
+    for (int j = 0; j < s.n_start; j++) n_place += s.start_qty[j];
+    ru.n_place = (uint8_t)n_place;
+    ru.additem_item = s.additem_item; ru.additem_span = (uint8_t)(s.additem_pct_hi - s.additem_pct_lo);
+    ru.replace_from = s.replace_from; ru.replace_to = s.replace_to; ru.replace_span = (uint8_t)(s.replace_pct_hi - s.replace_pct_lo);
+    ru.fence_item = s.fence_item; ru.fence_span = (uint8_t)(s.fence_pct_hi - s.fence_pct_lo);
+    ru.n_inv_start = s.n_inv_start;
+    for (int j = 0; j < NGW_MAX_INV_START; j++) { ru.inv_start_item[j] = s.inv_start_item[j]; ru.inv_start_qty[j] = s.inv_start_qty[j]; }
     HIP_TRY(hipMemcpyAsync(&h->dspec->ru, &ru, sizeof(ru), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return NGW_OK;

@@ -93,6 +93,14 @@ struct NgwResetU {
     uint64_t seed;
     int32_t S, S2, K, CW, perm_lds;
     uint32_t magicS;
+    uint32_t off_rng;     /* LDS dword offset of the Philox word ring [32][64] of the reset path */
+    /* the bytes of ngw_spec the reset reads, packed (6 dwords): fetched together with the rest of this struct, so the
+     * reset never waits on one more dependent load of the spec for each optional pass */
+    uint8_t wall_item, tap_item, tap_near, n_place;
+    uint8_t additem_item, additem_span, replace_from, replace_to;
+    uint8_t replace_span, fence_item, fence_span, n_inv_start;
+    uint8_t inv_start_item[NGW_MAX_INV_START], inv_start_qty[NGW_MAX_INV_START];
+    uint8_t _pad[4];
 };
 
 /* Uniform parameters of the step-time novelty predicates (kernel template flag EXT): FireWall, FenceRestriction, Crate */

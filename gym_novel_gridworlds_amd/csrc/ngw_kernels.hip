@@ -42,10 +42,17 @@ namespace {
 constexpr int EPB = NGW_EPB;   // envs per block = wavefront width
 
 // ---------------------------------------------------------------- Philox4x32-10 (counter-based, per env & episode)
+// The reset path draws its words from a per-lane ring of PHILOX_RING words in LDS, filled PHILOX_RING / 4 blocks at a
+// time.  (With a 4-word register buffer per lane the 64 lanes run out at different draws, so the wave ended up
+// executing the 10-round block for nearly EVERY draw.  All lanes start together and a plain reset needs < 32 words, so
+// now the block code runs once per reset for most waves.)  Word order is unchanged: block b = counter (b, episode,
+// env_lo, env_hi) yields words 4b .. 4b+3.
+constexpr int PHILOX_RING = 32;
 struct Philox {
     uint32_t k0, k1, c0, c1, c2, c3;
-    uint32_t w0, w1, w2, w3;
-    int have;
+    LDS_AS uint32_t* ring;                                                          // word j of this lane at ring[j * EPB]
+    int pos;
+    uint32_t nxt;                                                                   // ring[pos], requested one draw ahead
 };
 
 __device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
@@ -60,21 +67,29 @@ __device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t 
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
 
-__device__ __forceinline__ void philox_init(Philox& p, uint64_t seed, uint64_t env, uint32_t episode) {
+__device__ __forceinline__ void philox_fill(Philox& p) {
+    for (int b = 0; b < PHILOX_RING / 4; b++) {
+        uint32_t w0, w1, w2, w3;
+        philox_block(p.c0, p.c1, p.c2, p.c3, p.k0, p.k1, w0, w1, w2, w3);
+        p.c0++;
+        p.ring[(4 * b) * EPB] = w0; p.ring[(4 * b + 1) * EPB] = w1; p.ring[(4 * b + 2) * EPB] = w2; p.ring[(4 * b + 3) * EPB] = w3;
+    }
+    p.pos = 0;
+    p.nxt = p.ring[0];
+}
+
+__device__ __forceinline__ void philox_init(Philox& p, uint64_t seed, uint64_t env, uint32_t episode, LDS_AS uint32_t* ring) {
     p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32);
     p.c0 = 0; p.c1 = episode; p.c2 = (uint32_t)env; p.c3 = (uint32_t)(env >> 32);
-    p.have = 0;
+    p.ring = ring;
+    philox_fill(p);
 }
 
 __device__ __forceinline__ uint32_t philox_next(Philox& p) {
-    if (p.have == 0) {
-        philox_block(p.c0, p.c1, p.c2, p.c3, p.k0, p.k1, p.w0, p.w1, p.w2, p.w3);
-        p.c0++;
-        p.have = 4;
-    }
-    uint32_t r = p.w0;
-    p.w0 = p.w1; p.w1 = p.w2; p.w2 = p.w3;
-    p.have--;
+    const uint32_t r = p.nxt;
+    p.pos++;
+    if (p.pos == PHILOX_RING) philox_fill(p);                                      // (eager: the stream itself is unchanged)
+    else p.nxt = p.ring[p.pos * EPB];                                              // lands while the caller works on r
     return r;
 }
 
@@ -112,6 +127,8 @@ struct ResetArgs {
     uint64_t seed;
     int S, S2, K, CW, perm_lds;
     uint32_t magicS;                // ceil(2^32 / S): cell / S for cell < S*S
+    uint32_t rs0, rs1, rs2, rs3, rs4;   // NgwResetU's packed spec bytes: wall|tap|tap_near|n_place, additem|span|repl_from|repl_to,
+                                        // repl_span|fence|fence_span|n_inv_start, inv_start_item[4], inv_start_qty[4]
 };
 
 // The shuffled-subset reset passes - AddItem.reset (novelty_wrappers.py:1017-1028), ReplaceItem.reset (:1131-1144),
@@ -163,18 +180,21 @@ __device__ __forceinline__ void run_pass(const ResetArgs& a, LDS_AS uint16_t* pe
 // (LDS / global pointers carry their address space: across a real call generic pointers would turn every access
 //  into a flat_* instruction)
 __device__ __forceinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t* mp, LDS_AS int32_t* inv, LDS_AS uint32_t* cand,
-                                            const LDS_AS uint8_t* place_seq, LDS_AS uint16_t* perm_lds, uint64_t env_global,
-                                            int64_t env_local, uint32_t episode) {
-    const GLOBAL_AS ngw_spec& sp = *(const GLOBAL_AS ngw_spec*)&a.dspec->sp;
+                                            const LDS_AS uint8_t* place_seq, LDS_AS uint16_t* perm_lds, LDS_AS uint32_t* rng_ring,
+                                            uint64_t env_global, int64_t env_local, uint32_t episode) {
+    // the spec bytes this path needs arrived with the call's other uniform arguments (no dependent spec loads in here)
+    const int wall_item = a.rs0 & 255, tap_item = (a.rs0 >> 8) & 255, tap_near = (a.rs0 >> 16) & 255, n_place = a.rs0 >> 24;
+    const int additem_item = a.rs1 & 255, additem_span = (a.rs1 >> 8) & 255, replace_from = (a.rs1 >> 16) & 255, replace_to = a.rs1 >> 24;
+    const int replace_span = a.rs2 & 255, fence_item = (a.rs2 >> 8) & 255, fence_span = (a.rs2 >> 16) & 255, n_inv_start = a.rs2 >> 24;
     int r_out, c_out, f_out;
     const int S = a.S, K = a.K, W = S - 4, ncand = W * W;
     const uint32_t magicW = (uint32_t)((0x100000000ull + (uint32_t)W - 1) / (uint32_t)W);   // pos / W == umulhi(pos, magicW), pos < 2^12
     Philox px;
-    philox_init(px, a.seed, env_global, episode);
+    philox_init(px, a.seed, env_global, episode, rng_ring);
     for (int k = 0; k < K; k++) inv[k] = 0;                                        // :119
     for (int r = 0; r < S; r++)                                                    // :129-130 wall ring around air
         for (int c = 0; c < S; c++)
-            mp[r * S + c] = (r == 0 || c == 0 || r == S - 1 || c == S - 1) ? (int8_t)sp.wall_item : (int8_t)0;
+            mp[r * S + c] = (r == 0 || c == 0 || r == S - 1 || c == S - 1) ? (int8_t)wall_item : (int8_t)0;
     for (int w = 0; w < a.CW; w++) {                                               // :136-138 all interior candidates
         int left = ncand - w * 32;
         cand[w * EPB] = left >= 32 ? 0xFFFFFFFFu : (left > 0 ? ((1u << left) - 1u) : 0u);
@@ -188,27 +208,42 @@ __device__ __forceinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t*
     f_out = (int)bounded(px, 3);                                                   // :145
     // :147-148 + add_item_to_map :159-181, FLATTENED: placement n takes item place_seq[n] (items_quantity in insertion
     // order), so a wave iterates max-over-lanes of the TOTAL number of tries, not the sum of per-item maxima.
-    const int total = a.dspec->n_place;
+    const int total = n_place;
     int n = 0;
+    // Candidate bitmask: two words cover maps up to 10 x 10 (36 interior candidates) and then live in registers; larger
+    // maps keep them in LDS.  Every LDS read of a try is issued before the first one is needed (the item to place, the
+    // cell and its four neighbours - unconditionally: a short-circuit && would make them five dependent round trips).
+    const bool cand_regs = a.CW <= 2;
+    uint32_t cr0 = cand[0], cr1 = a.CW > 1 ? cand[EPB] : 0u;
     while (n < total) {
         if (len < 1) { flags |= NGW_F_PLACEMENT; break; }                         // :167
+        const int item = place_seq[n];
         int idx = (int)bounded(px, (uint32_t)len - 1);                             // :169
-        int w = 0, pc;
-        while (idx >= (pc = __popc(cand[w * EPB]))) { idx -= pc; w++; }             // idx-th remaining, row-major
-        const int bit = nth_set_bit(cand[w * EPB], idx);
-        cand[w * EPB] &= ~(1u << bit);                                             // list.pop(idx)
+        int pos;
+        if (cand_regs) {
+            const int pc0 = __popc(cr0);
+            const bool lo = idx < pc0;
+            const int bit = nth_set_bit(lo ? cr0 : cr1, lo ? idx : idx - pc0);     // idx-th remaining, row-major
+            if (lo) cr0 &= ~(1u << bit); else cr1 &= ~(1u << bit);                 // list.pop(idx)
+            pos = (lo ? 0 : 32) + bit;
+        } else {
+            int w = 0, pc;
+            while (idx >= (pc = __popc(cand[w * EPB]))) { idx -= pc; w++; }
+            const int bit = nth_set_bit(cand[w * EPB], idx);
+            cand[w * EPB] &= ~(1u << bit);
+            pos = w * 32 + bit;
+        }
         len--;
-        const int pos = w * 32 + bit;
         const int prow = (int)__umulhi((uint32_t)pos, magicW);
         const int cell = (2 + prow) * S + 2 + (pos - prow * W);
-        if (cell != agent &&                                                       // :172-174
-            mp[cell] == 0 && mp[cell - S] == 0 && mp[cell + S] == 0 && mp[cell - 1] == 0 && mp[cell + 1] == 0) {
-            mp[cell] = (int8_t)place_seq[n];                                       // :177-180
+        const int m0 = mp[cell], mN = mp[cell - S], mS = mp[cell + S], mW = mp[cell - 1], mE = mp[cell + 1];
+        if (cell != agent && (m0 | mN | mS | mW | mE) == 0) {                      // :172-178
+            mp[cell] = (int8_t)item;                                               // :177-180
             n++;
         }
     }
-    if (sp.tap_item && !flags) {                                                   // Pogostick-v0, pogostick_v0_env.py:156-178
-        const int near = sp.tap_near;
+    if (tap_item && !flags) {                                                      // Pogostick-v0, pogostick_v0_env.py:156-178
+        const int near = tap_near;
         int nl = 0;
         for (int i = 0; i < a.S2; i++) nl += (mp[i] == near);                     // np.where(map == tree_log)
         if (nl <= 1) flags |= NGW_F_PLACEMENT;                                     // assert len(result[0]) > 1
@@ -221,19 +256,19 @@ __device__ __forceinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t*
             const int lr = (int)__umulhi((uint32_t)cell, a.magicS);                // cell / S
             const int rr = lr + ((d == 0) ? -1 : (d == 1 ? 1 : 0)), cc = cell - lr * S + ((d == 2) ? -1 : (d == 3 ? 1 : 0));
             if (rr >= 0 && rr <= S - 1 && cc >= 0 && cc <= S - 1 && mp[rr * S + cc] == 0 && rr * S + cc != agent) {
-                mp[rr * S + cc] = (int8_t)sp.tap_item;
+                mp[rr * S + cc] = (int8_t)tap_item;
                 break;
             }
         }
     }
-    if (sp.additem_item && !flags)                                                 // AddItem / Crate
-        run_pass<NGW_PASS_ADDITEM>(a, perm_lds, env_local, px, mp, agent, 0, sp.additem_item, sp.additem_pct_hi - sp.additem_pct_lo);
-    if (sp.replace_to && !flags)                                                   // ReplaceItem / FireWall
-        run_pass<NGW_PASS_REPLACE>(a, perm_lds, env_local, px, mp, agent, sp.replace_from, sp.replace_to, sp.replace_pct_hi - sp.replace_pct_lo);
-    if (sp.fence_item && !flags)                                                   // Fence / FenceRestriction
-        run_pass<NGW_PASS_FENCE>(a, perm_lds, env_local, px, mp, agent, sp.wall_item, sp.fence_item, sp.fence_pct_hi - sp.fence_pct_lo);
-    if (!flags)
-        for (int j = 0; j < sp.n_inv_start; j++) inv[sp.inv_start_item[j]] = sp.inv_start_qty[j];   // AxeEasy.reset :33, AxetoBreakHard.reset :667-670
+    if (additem_item && !flags)                                                    // AddItem / Crate
+        run_pass<NGW_PASS_ADDITEM>(a, perm_lds, env_local, px, mp, agent, 0, additem_item, additem_span);
+    if (replace_to && !flags)                                                      // ReplaceItem / FireWall
+        run_pass<NGW_PASS_REPLACE>(a, perm_lds, env_local, px, mp, agent, replace_from, replace_to, replace_span);
+    if (fence_item && !flags)                                                      // Fence / FenceRestriction
+        run_pass<NGW_PASS_FENCE>(a, perm_lds, env_local, px, mp, agent, wall_item, fence_item, fence_span);
+    if (!flags)                                                                    // AxeEasy.reset :33, AxetoBreakHard.reset :667-670
+        for (int j = 0; j < n_inv_start; j++) inv[(a.rs3 >> (8 * j)) & 255u] = (int)((a.rs4 >> (8 * j)) & 255u);
     return flags | ((uint32_t)r_out << 8) | ((uint32_t)c_out << 16) | ((uint32_t)f_out << 24);
 }
 
@@ -302,13 +337,17 @@ __device__ __noinline__ uint32_t new_episode(const NgwDevSpec* dspec, LDS_AS int
     const GLOBAL_AS NgwNx* np = (const GLOBAL_AS NgwNx*)&dspec->nx;
     NgwResetU ru; NgwNx nx;
     ru.perm = rp->perm; ru.map = rp->map; ru.inv = rp->inv; ru.n_pad = rp->n_pad; ru.seed = rp->seed; ru.S = rp->S;
-    ru.S2 = rp->S2; ru.K = rp->K; ru.CW = rp->CW; ru.perm_lds = rp->perm_lds; ru.magicS = rp->magicS;
+    ru.S2 = rp->S2; ru.K = rp->K; ru.CW = rp->CW; ru.perm_lds = rp->perm_lds; ru.magicS = rp->magicS; ru.off_rng = rp->off_rng;
+    const GLOBAL_AS uint32_t* rsw = (const GLOBAL_AS uint32_t*)&rp->wall_item;
+    const uint32_t rs0 = rsw[0], rs1 = rsw[1], rs2 = rsw[2], rs3 = rsw[3], rs4 = rsw[4];
     nx.map = np->map; nx.loc = np->loc; nx.facing = np->facing; nx.inv = np->inv; nx.episode = np->episode;
     if (may_consume && nx.episode && ((const GLOBAL_AS uint32_t*)nx.episode)[env_local] == episode)
         return consume_lane(nx, mp, inv, (GLOBAL_AS int8_t*)ru.map + env_local * ru.S2, (GLOBAL_AS int32_t*)ru.inv + env_local * ru.K,
                             env_local, ru.S2, ru.K) | NGW_F_ROWS_STORED;
-    const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS};
-    return reset_lane(a, mp, inv, cand, place_seq, perm_lds, env_global, env_local, episode);
+    const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS, rs0, rs1, rs2, rs3, rs4};
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_base[];            // the kernel's dynamic LDS (offset 0)
+    return reset_lane(a, mp, inv, cand, place_seq, perm_lds, (LDS_AS uint32_t*)(lds_base + ru.off_rng + threadIdx.x), env_global,
+                      env_local, episode);
 }
 
 // ---------------------------------------------------------------- map staging HBM <-> LDS (coalesced 16-B pieces)
