@@ -54,6 +54,7 @@ class VecNovelGridworld:
         self.autoreset, self.horizon = bool(autoreset), int(horizon)
         _cabi.check(L.ngw_set_autoreset(self._h, int(self.autoreset), self.horizon))
         self.reset_prefetch = 0
+        self.lidar, self.lidar_fused, self.lidar_len = None, False, 0      # set by lidar_configure()
         if reset_prefetch:
             self.set_reset_prefetch(reset_prefetch)
         N, S, K = self.num_envs, self.map_size, self.n_items

@@ -1,0 +1,73 @@
+"""C-ABI argument validation (include/ngw.h): malformed specs and states are rejected with NGW_E_INVALID_ARG and a
+message, never launched - the kernels index look-up tables and the map with these values."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ngw_testlib as T
+from gym_novel_gridworlds_amd import VecNovelGridworld, _cabi
+from gym_novel_gridworlds_amd.spec import make_spec
+
+pytestmark = pytest.mark.gpu
+
+
+def _create(cspec, n=64):
+    h = C.c_void_p()
+    rc = _cabi.lib().ngw_create(C.byref(cspec), n, 0, 0, 0, C.byref(h))
+    if rc == 0:
+        _cabi.lib().ngw_destroy(h)
+    return rc, _cabi.last_error()
+
+
+@pytest.mark.parametrize('edit,needle', [
+    (lambda s: setattr(s, 'goal_item', 30), 'item id out of range'),
+    (lambda s: setattr(s, 'n_actions', 99), 'n_actions'),
+    (lambda s: s.act_kind.__setitem__(3, 77), 'unknown kind'),
+    (lambda s: s.act_arg.__setitem__(8, 7), 'recipe'),                     # action 8 = Craft_*: recipe index out of range
+    (lambda s: (setattr(s, 'additem_item', 3), setattr(s, 'additem_pct_lo', 40), setattr(s, 'additem_pct_hi', 30)), 'additem percent'),
+    (lambda s: (setattr(s, 'replace_to', 3), setattr(s, 'replace_pct_lo', 0), setattr(s, 'replace_pct_hi', 90)), 'replace percent'),
+    (lambda s: setattr(s, 'fence_mode', 2), 'fence_mode'),
+    (lambda s: s.crate_add.__setitem__(2, 3), 'crate_add'),
+    (lambda s: (setattr(s, 'n_inv_start', 1), s.inv_start_item.__setitem__(0, 0)), 'inv_start_item'),
+    (lambda s: setattr(s, 'map_size', 3), 'map_size'),
+    (lambda s: setattr(s, 'abi_version', 99), 'abi'),
+])
+def test_malformed_spec_is_rejected(edit, needle):
+    cs = make_spec(T.POGO, 10).compile()
+    edit(cs)
+    rc, msg = _create(cs)
+    assert rc == _cabi.E_INVALID_ARG and needle in msg, (rc, msg)
+
+
+def test_well_formed_spec_and_bad_counts():
+    cs = make_spec(T.POGO, 10).compile()
+    assert _create(cs)[0] == 0
+    rc, msg = _create(cs, n=0)
+    assert rc == _cabi.E_INVALID_ARG and 'n_envs' in msg
+    h = C.c_void_p()
+    assert _cabi.lib().ngw_create(C.byref(cs), 64, 99, 0, 0, C.byref(h)) in (_cabi.E_INVALID_ARG, _cabi.E_NO_DEVICE)
+
+
+def test_state_and_call_validation():
+    v = VecNovelGridworld(num_envs=100, seed=1)
+    v.reset()
+    st = v.get_state()
+    L = _cabi.lib()
+    for key, bad, needle in (('loc', np.array([[0, 3]], np.int32), 'walled interior'), ('loc', np.array([[4, 9]], np.int32), 'walled interior'),
+                             ('facing', np.array([4], np.int32), 'agent_facing_id'), ('selected', np.array([9], np.int32), 'selected item'),
+                             ('map', np.full((1, 100), 9, np.int8), 'map cell value')):
+        with pytest.raises(ValueError) as ei:
+            v.set_state(5, **{key: bad})
+        assert needle in str(ei.value), ei.value
+    with pytest.raises(ValueError):
+        v.set_state(99, facing=np.zeros(2, np.int32))                     # range [99, 101) out of bounds
+    after = v.get_state()
+    assert all((st[k] == after[k]).all() for k in st)                     # nothing was written by the rejected calls
+    for call in (lambda: v.rollout(0), lambda: v.graph_launch(1), lambda: v.lidar_observation(), lambda: v.agent_view(0),
+                 lambda: v.set_reset_prefetch(-1), lambda: _cabi.check(L.ngw_set_autoreset(v._h, 1, -5))):
+        with pytest.raises(ValueError):
+            call()
+    assert L.ngw_reset(None, None) == _cabi.E_INVALID_ARG and 'NULL' in _cabi.last_error()
+    v.step(np.zeros(100, np.int32))                                       # the handle is still usable
+    assert v.error_flags() == 0
