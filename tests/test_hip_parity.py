@@ -172,6 +172,30 @@ def test_prepared_next_episodes_are_bit_identical(cfg, n, steps, horizon, every)
     assert o.st.episode.min() >= 3 and v.error_flags() == 0
 
 
+@pytest.mark.parametrize('cfg,n,horizon,prefetch', [('pogo10', 8192, 37, 0), ('axe10', 4096, 53, 16), ('bow20', 2048, 41, 0), ('fire10h', 4096, 29, 8),
+                                                    ('crate10m', 4096, 61, 0), ('pogov0_10', 4096, 33, 4)])
+def test_long_soak_matches_oracle(cfg, n, horizon, prefetch):
+    """Soak: 4 000 batched steps (a hundred episodes per env, tens of millions of env-steps) in fused chunks of uneven
+    length, then 300 per-launch steps; the full state equals the oracle's after every chunk."""
+    spec = T.build_spec(cfg)
+    A = len(spec.actions_id)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=1234, autoreset=True, horizon=horizon, reset_prefetch=prefetch, env_index_base=7 * n)
+    o = Oracle(spec.compile(), n, seed=1234, autoreset=True, horizon=horizon, env_index_base=7 * n)
+    v.reset(); o.reset()
+    t0 = 0
+    for chunk in (1, 7, 100, 333, 1000, 2559):
+        v.rollout(chunk, action_seed=99, t0=t0); assert o.rollout(chunk, 99, t0) == 0
+        t0 += chunk
+        assert_state_equal(v, o, '%s soak t=%d' % (cfg, t0))
+    rs = np.random.RandomState(6)
+    for t in range(300):
+        a = rs.randint(0, A, size=n).astype(np.int32)
+        _, reward, done, info = v.step(a); o.step(a)
+        assert (reward == o.reward).all() and (done == o.done.astype(bool)).all(), t
+    assert_state_equal(v, o, cfg + ' soak end')
+    assert o.st.episode.min() >= 4000 // horizon and v.error_flags() == 0
+
+
 # ------------------------------------------------------------------ BASELINE sizes: size-independent properties
 def test_full_size_properties_pogostick_65536():
     """BASELINE config 2 at full size: determinism, shard independence, structural invariants, oracle on a sample."""
