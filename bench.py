@@ -111,8 +111,10 @@ def main():
     if nov:
         apply_novelty(spec, *nov)
     K, A = len(spec.items_id), len(spec.actions_id)
+    # headline: every env hits the horizon in the same step, where preparing next episodes ahead buys nothing (the refill
+    # launch costs what the inline resets cost); the staggered side measurement below switches it on
     v = VecNovelGridworld(spec=spec, num_envs=n, device=local_rank, seed=0, autoreset=True, horizon=HORIZON,
-                          env_index_base=rank * n)
+                          env_index_base=rank * n, reset_prefetch=0)
     v.reset()
     steps, warmup = args.steps, args.warmup
 
@@ -245,7 +247,7 @@ def main():
             'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 6), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8/int32', 'data': 'synthetic',
             'config': {'workload': desc, 'name': args.workload, 'envs_per_gpu': n, 'global_envs': n * world,
-                       'map_size': S, 'n_items': K, 'n_actions': A, 'horizon': HORIZON, 'autoreset': 'same-step',
+                       'map_size': S, 'n_items': K, 'n_actions': A, 'horizon': HORIZON, 'autoreset': 'same-step', 'reset_prefetch': 0,
                        'mode': ('one launch per batched step (%s), actions in HBM' % ('hipGraph replay' if use_graph else 'eager')) if args.mode == 'step'
                                else 'fused rollout: all steps in one launch, actions generated in-kernel',
                        'parallelism': 'envs sharded x%d, no collective' % world},

@@ -24,7 +24,7 @@ class ShardedVecNovelGridworld:
     """Rank-local view of `global_num_envs` environments sharded over the ranks of a torch.distributed group."""
 
     def __init__(self, env_id='NovelGridworld-Pogostick-v1', global_num_envs=65536, map_size=None, novelty=None, seed=0,
-                 autoreset=False, horizon=0, spec=None, device=None, group=None, local_factory=None, reset_prefetch=0):
+                 autoreset=False, horizon=0, spec=None, device=None, group=None, local_factory=None, reset_prefetch='auto'):
         import torch.distributed as dist
         self.dist = dist
         self.group = group

@@ -26,7 +26,7 @@ class _DevArray:
 
 class VecNovelGridworld:
     def __init__(self, env_id='NovelGridworld-Pogostick-v1', num_envs=1, map_size=None, novelty=None, device=0,
-                 seed=0, autoreset=False, horizon=0, env_index_base=0, spec=None, reset_prefetch=0):
+                 seed=0, autoreset=False, horizon=0, env_index_base=0, spec=None, reset_prefetch='auto'):
         if spec is None:
             spec = make_spec(env_id, map_size)
             if novelty:
@@ -54,6 +54,10 @@ class VecNovelGridworld:
         self.autoreset, self.horizon = bool(autoreset), int(horizon)
         _cabi.check(L.ngw_set_autoreset(self._h, int(self.autoreset), self.horizon))
         self.reset_prefetch = 0
+        if reset_prefetch == 'auto':
+            # autoreset users get prepared next episodes unless the episodes are too short for a refill every 32 steps to keep
+            # up (rows then go stale before they are needed and resets simply run inline, as without the feature)
+            reset_prefetch = 32 if self.autoreset and (self.horizon == 0 or self.horizon >= 64) else 0
         self.lidar, self.lidar_fused, self.lidar_len = None, False, 0      # set by lidar_configure()
         if reset_prefetch:
             self.set_reset_prefetch(reset_prefetch)

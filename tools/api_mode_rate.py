@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gym_novel_gridworlds_amd import VecNovelGridworld  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-v = VecNovelGridworld(num_envs=n, autoreset=True, horizon=100)
+v = VecNovelGridworld(num_envs=n, autoreset=True, horizon=100, reset_prefetch=0)
 v.reset()
 acts = np.random.randint(0, 17, size=(64, n)).astype(np.int32)
 for i in range(10):

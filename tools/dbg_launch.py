@@ -16,7 +16,7 @@ if sys.argv[1:] == ['calib']:
     print('calib n', n, 'bytes_read_per_launch', n * 157, 'bytes_written_per_launch', n * 166)
     sys.exit(0)
 for n in [int(x) for x in (sys.argv[1:] or ['65536', '262144', '1048576'])]:
-    v = VecNovelGridworld(num_envs=n, autoreset=True, horizon=100)
+    v = VecNovelGridworld(num_envs=n, autoreset=True, horizon=100, reset_prefetch=0)
     v.reset()
     acts = torch.randint(0, 17, (64, n), dtype=torch.int32, device='cuda')
     torch.cuda.synchronize()

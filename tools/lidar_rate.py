@@ -9,7 +9,7 @@ import torch  # noqa: E402
 from gym_novel_gridworlds_amd import VecNovelGridworld, _cabi  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-v = VecNovelGridworld(num_envs=n, autoreset=True, horizon=100)
+v = VecNovelGridworld(num_envs=n, autoreset=True, horizon=100, reset_prefetch=0)
 v.reset()
 v.lidar_configure(num_beams=8)
 acts = torch.randint(0, 17, (64, n), dtype=torch.int32, device='cuda')

@@ -11,7 +11,7 @@ from gym_novel_gridworlds_amd import VecNovelGridworld  # noqa: E402
 N, K = 65536, 400
 for split in (1, 2, 4, 8):
     n = N // split
-    hs = [VecNovelGridworld(num_envs=n, autoreset=True, horizon=100, env_index_base=i * n) for i in range(split)]
+    hs = [VecNovelGridworld(num_envs=n, autoreset=True, horizon=100, env_index_base=i * n, reset_prefetch=0) for i in range(split)]
     acts = [torch.randint(0, 17, (K, n), dtype=torch.int32, device='cuda') for _ in range(split)]
     torch.cuda.synchronize()
     for h, a in zip(hs, acts):

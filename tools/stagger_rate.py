@@ -17,7 +17,7 @@ prefetch = int(os.environ.get('NGW_PREFETCH', '0'))
 acts = torch.randint(0, 17, (64, n), dtype=torch.int32, device='cuda')
 torch.cuda.synchronize()
 for name, stagger in (('synchronized', False), ('staggered', True)):
-    v = VecNovelGridworld(num_envs=n, autoreset=True, horizon=H, seed=3)
+    v = VecNovelGridworld(num_envs=n, autoreset=True, horizon=H, seed=3, reset_prefetch=0)
     if prefetch and hasattr(v, 'set_reset_prefetch'):
         v.set_reset_prefetch(prefetch)
     v.reset()
