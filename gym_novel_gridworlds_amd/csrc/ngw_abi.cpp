@@ -49,6 +49,9 @@ struct ngw_handle {
     NgwDevSpec* dspec = nullptr;      // LUT blob in HBM
     int32_t* actions_dev = nullptr;   // staging for host actions
     uint8_t* mask_dev = nullptr;
+    uint32_t* info_host = nullptr;    // pinned staging of the packed info words (ngw_step_host)
+    uint8_t* zc_host = nullptr;       // small batches: actions + packed outputs in host memory the GPU addresses directly
+    uint8_t* zc_dev = nullptr;
     std::vector<void*> allocs;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing pair
     // LidarInFront observation
@@ -377,6 +380,8 @@ int ngw_destroy(ngw_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) (void)hipFree(p);
     drop_graph(h);
+    if (h->info_host) (void)hipHostFree(h->info_host);
+    if (h->zc_host) (void)hipHostFree(h->zc_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -483,6 +488,8 @@ int ngw_sync(ngw_handle* h) {
     return NGW_OK;
 }
 
+constexpr size_t NGW_ZERO_COPY_BYTES = 1u << 20;   // ngw_step_host: up to here the outputs go through mapped host memory
+
 #define D2H(dst, src, bytes)                                                                             \
     do {                                                                                                 \
         if (dst) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, h->stream));        \
@@ -516,6 +523,77 @@ int ngw_get_step_out(ngw_handle* h, int32_t* reward, uint8_t* done, uint8_t* res
     if (want_info)
         for (size_t i = 0; i < n; i++) {
             const uint32_t w = info[i];
+            if (result) result[i] = (uint8_t)NGW_INFO_RESULT(w);
+            if (cost_code) cost_code[i] = (uint8_t)NGW_INFO_COST(w);
+            if (msg_code) msg_code[i] = (uint16_t)NGW_INFO_MSG(w);
+            if (msg_arg) msg_arg[i] = (uint16_t)NGW_INFO_ARG(w);
+        }
+    return NGW_OK;
+}
+
+int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv, int32_t* reward,
+                  uint8_t* done, uint8_t* result, uint8_t* cost_code, uint16_t* msg_code, uint16_t* msg_arg, uint32_t* error_flags,
+                  uint8_t* selected, int32_t* step_count) {
+    if (!h || !actions_host) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    const int A = h->spec.n_actions;
+    const size_t n = (size_t)h->n, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
+    for (size_t i = 0; i < n; i++)
+        if (actions_host[i] < 0 || actions_host[i] >= A)
+            return fail(NGW_E_INVALID_ACTION, "%d is not in list", (int)actions_host[i]);   // pogostick_v1_env.py:236
+    HIP_TRY(hipSetDevice(h->device));
+    const bool want_info = result || cost_code || msg_code || msg_arg;
+    const uint32_t* info_words = nullptr;
+    // what the caller wants back: (host pointer, device source, bytes)
+    struct Out { void* host; const void* dev; size_t bytes; };
+    constexpr int NOUT = 10, INFO = NOUT - 1;
+    const Out outs[NOUT] = {{map, h->b.map, n * S2}, {loc, h->b.loc, n * 8}, {facing, h->b.facing, n * 4}, {inv, h->b.inv, n * K * 4},
+                            {reward, h->b.reward, n * 4}, {done, h->b.done, n}, {error_flags, h->b.flags, 4},
+                            {selected, h->b.selected, n}, {step_count, h->b.step_count, n * 4},
+                            {want_info ? (void*)h : nullptr, h->b.info, n * 4}};
+    size_t total = 0;
+    for (const Out& o : outs) if (o.host) total += (o.bytes + 255) & ~(size_t)255;
+    if (total <= NGW_ZERO_COPY_BYTES) {
+        // Small batch: no copy calls at all.  The kernel reads the actions from, and a pack kernel writes every output into,
+        // page-locked host memory that is mapped into the GPU's address space; one synchronisation, then plain memcpys.
+        if (!h->zc_host) {
+            const size_t cap = NGW_ZERO_COPY_BYTES + n * sizeof(int32_t) + 4096;
+            h->zc_host = static_cast<uint8_t*>(ngw_host_alloc(cap));
+            if (!h->zc_host) return NGW_E_HIP;
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zc_dev), h->zc_host, 0));
+        }
+        memcpy(h->zc_host, actions_host, n * sizeof(int32_t));
+        if (int rc = launch(h, NGW_MODE_STEP, 1, reinterpret_cast<const int32_t*>(h->zc_dev), nullptr, 0, 0)) return rc;
+        NgwPack p = {};
+        size_t off = (n * sizeof(int32_t) + 255) & ~(size_t)255, offs[NOUT] = {0};
+        p.dst = h->zc_dev;
+        for (int r = 0; r < NOUT; r++)
+            if (outs[r].host) {
+                p.src[p.n_regions] = static_cast<const uint8_t*>(outs[r].dev);
+                p.off[p.n_regions] = (uint32_t)off; p.nbytes[p.n_regions] = (uint32_t)outs[r].bytes; p.n_regions++;
+                offs[r] = off; off += (outs[r].bytes + 255) & ~(size_t)255;
+            }
+        if (p.n_regions) HIP_TRY(ngw_pack_launch(&p, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int r = 0; r < INFO; r++) if (outs[r].host) memcpy(outs[r].host, h->zc_host + offs[r], outs[r].bytes);
+        if (want_info) info_words = reinterpret_cast<const uint32_t*>(h->zc_host + offs[INFO]);
+    } else {
+        // actions in, launch, everything out, ONE synchronisation (ngw_step + ngw_get_obs + ngw_get_step_out take three)
+        HIP_TRY(hipMemcpyAsync(h->actions_dev, actions_host, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        if (int rc = launch(h, NGW_MODE_STEP, 1, h->actions_dev, nullptr, 0, 0)) return rc;
+        for (int r = 0; r < INFO; r++) D2H(outs[r].host, outs[r].dev, outs[r].bytes);
+        if (want_info) {
+            if (!h->info_host) {
+                h->info_host = static_cast<uint32_t*>(ngw_host_alloc(n * sizeof(uint32_t)));
+                if (!h->info_host) return NGW_E_HIP;
+            }
+            HIP_TRY(hipMemcpyAsync(h->info_host, h->b.info, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            info_words = h->info_host;
+        }
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    if (want_info)
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t w = info_words[i];
             if (result) result[i] = (uint8_t)NGW_INFO_RESULT(w);
             if (cost_code) cost_code[i] = (uint8_t)NGW_INFO_COST(w);
             if (msg_code) msg_code[i] = (uint16_t)NGW_INFO_MSG(w);

@@ -147,6 +147,22 @@ struct NgwLidarDev {
 #ifdef __cplusplus
 extern "C"
 #endif
+/* Small-batch host step: copy up to 12 device regions into ONE page-locked host buffer the GPU can address (region r:
+ * nbytes[r] bytes from src[r] to dst + off[r], off[r] 16-byte aligned); replaces seven hipMemcpyAsync calls whose fixed
+ * cost dominates at small batch sizes. */
+struct NgwPack {
+    const uint8_t* src[12];
+    uint8_t* dst;
+    uint32_t off[12], nbytes[12];
+    int32_t n_regions;
+};
+#ifdef __cplusplus
+extern "C"
+#endif
+hipError_t ngw_pack_launch(const struct NgwPack* p, hipStream_t stream);
+#ifdef __cplusplus
+extern "C"
+#endif
 /* AgentMap window gather: out = [n][2V+1][2V+1] int8 packed as n_dwords dwords */
 hipError_t ngw_agent_view_launch(const int8_t* map, const int32_t* loc, uint32_t* out, uint32_t n_dwords, int S, int V,
                                  hipStream_t stream);

@@ -1021,6 +1021,17 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const NgwLidarDev* _
     for (int p = tid; p < 16 * L; p += EPB) g4[p] = t4[p];
 }
 
+// Host-step pack: region blockIdx.y, 16 bytes per thread (a region's tail bytes go one by one); the destination is host memory mapped into the GPU's address space, so the stores travel over PCIe.
+__global__ __launch_bounds__(256) void ngw_pack_kernel(const NgwPack p) {
+    const int r = blockIdx.y;
+    const uint32_t nb = p.nbytes[r], i = (blockIdx.x * 256u + threadIdx.x) * 16u;     // sources and offsets are 16-byte aligned
+    if (i >= nb) return;
+    const uint8_t* s = p.src[r] + i;
+    uint8_t* d = p.dst + p.off[r] + i;
+    if (i + 16u <= nb) *reinterpret_cast<u32x4*>(d) = *reinterpret_cast<const u32x4*>(s);
+    else for (uint32_t j = 0; i + j < nb; j++) d[j] = s[j];
+}
+
 // AgentMap (reference observation_wrappers.py:104-121): the (2V+1) x (2V+1) window of the map centred on the agent, 0 outside
 // the map.  HBM-bound byte gather: one lane produces 4 consecutive output bytes (one coalesced dword store); the map reads
 // hit each env's 100-B row image, which one wave covers with a handful of cache lines.
@@ -1047,6 +1058,13 @@ __global__ __launch_bounds__(256) void ngw_agent_view_kernel(const int8_t* __res
 }
 
 }  // namespace
+
+extern "C" hipError_t ngw_pack_launch(const NgwPack* p, hipStream_t stream) {
+    uint32_t most = 0;
+    for (int r = 0; r < p->n_regions; r++) most = p->nbytes[r] > most ? p->nbytes[r] : most;
+    hipLaunchKernelGGL(ngw_pack_kernel, dim3((most / 16u + 256u) / 256u, (unsigned)p->n_regions), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t ngw_agent_view_launch(const int8_t* map, const int32_t* loc, uint32_t* out, uint32_t n_dwords, int S, int V,
                                             hipStream_t stream) {

@@ -77,6 +77,7 @@ class _NovelGridworldEnv(_EnvBase):
         self.reward_intermediate = sp.reward_intermediate
         self.reward_done = sp.reward_done
         self.last_done = False
+        self._dev_state, self._dev_state_of = None, None     # what the device is known to hold (envs.py _push)
 
     # ------------------------------------------------------------------ backend
     def _make_backend(self, spec, seed):
@@ -134,14 +135,24 @@ class _NovelGridworldEnv(_EnvBase):
         for name, q in self.inventory_items_quantity.items():
             inv[0, ids[name]] = q                            # KeyError for an unknown item name, like the reference
         m = np.ascontiguousarray(np.asarray(self.map).reshape(1, S * S), np.int8)
-        vec.set_state(0, map=m, loc=np.array([self.agent_location], np.int32),
-                      facing=np.array([self.agent_facing_id], np.int32), inv=inv,
-                      selected=np.array([ids[self.selected_item] if self.selected_item else 0], np.int32),
-                      step_count=np.array([self.step_count], np.int32))
+        st = dict(map=m, loc=np.array([self.agent_location], np.int32), facing=np.array([self.agent_facing_id], np.int32), inv=inv,
+                  selected=np.array([ids[self.selected_item] if self.selected_item else 0], np.int32),
+                  step_count=np.array([self.step_count], np.int32))
+        # the caller may have edited any attribute since the last pull - or nothing at all (the usual case in a step loop):
+        # then the device already holds exactly this state and the six copies are skipped
+        known = self._dev_state if self._dev_state_of is vec else None
+        if known is not None and all(np.array_equal(st[k], known[k]) for k in st):
+            return
+        vec.set_state(0, **st)
+        self._dev_state, self._dev_state_of = st, vec
 
-    def _pull(self, vec):
+    def _pull(self, vec, st=None):
         """device state -> host attributes (the map array object is kept: observations alias it)"""
-        st = vec.get_state(0, 1)
+        if st is None:
+            st = vec.get_state(0, 1)
+        self._dev_state = {k: np.array(st[k], dtype=(np.int8 if k == 'map' else np.int32)).reshape(1, -1) if k in ('map', 'inv', 'loc')
+                           else np.array(st[k], np.int32).reshape(1) for k in ('map', 'loc', 'facing', 'inv', 'selected', 'step_count')}
+        self._dev_state_of = vec
         S = self.map_size
         if self.map.shape != (S, S):
             self.map = np.zeros((S, S), dtype=int)
@@ -204,7 +215,7 @@ class _NovelGridworldEnv(_EnvBase):
         vec = self._backend()
         self._push(vec)
         _, reward, done, info = vec.step(np.array([action_id], np.int32))
-        self._pull(vec)
+        self._pull(vec, vec.last_state() if hasattr(vec, 'last_state') else None)   # the step() call already brought it back
         obs = self.get_observation()
         self.update_block_in_front()
         reward, done = int(reward[0]), bool(info_done(done))

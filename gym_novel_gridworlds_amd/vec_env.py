@@ -68,6 +68,9 @@ class VecNovelGridworld:
         self._reward = pin((N,), np.int32)
         self._done = pin((N,), np.uint8)
         self._act_pinned = pin((N,), np.int32)
+        self._flags_word = C.c_uint32(0)
+        self._sel_host = np.zeros(N, np.uint8)            # selected item / step_count after the last step() (single-env adapter)
+        self._steps_host = np.zeros(N, np.int32)
         self._result = np.zeros(N, np.uint8)
         self._cost = np.zeros(N, np.uint8)
         self._msg = np.zeros(N, np.uint16)
@@ -111,12 +114,25 @@ class VecNovelGridworld:
         a = np.ascontiguousarray(actions, np.int32)
         assert a.shape == (self.num_envs,)
         self._act_pinned[...] = a
-        _cabi.check(_cabi.lib().ngw_step(self._h, _cabi._ptr(self._act_pinned, np.int32)))
+        o, p = self._obs, _cabi._ptr
+        _cabi.check(_cabi.lib().ngw_step_host(                       # actions in, launch, observation + outputs out: one sync
+            self._h, p(self._act_pinned, np.int32), p(o['map'], np.int8), p(o['agent_location'], np.int32),
+            p(o['agent_facing_id'], np.int32), p(o['inventory_items_quantity'], np.int32), p(self._reward, np.int32),
+            p(self._done, np.uint8), p(self._result, np.uint8), p(self._cost, np.uint8), p(self._msg, np.uint16), p(self._arg, np.uint16),
+            C.byref(self._flags_word), p(self._sel_host, np.uint8), p(self._steps_host, np.int32)))
         self._last_actions = a
-        obs = self.get_observation(copy)
-        reward, done, info = self.get_step_out(copy)
-        self._raise_flags()
+        obs = {k: v.copy() for k, v in o.items()} if copy else o
+        reward, done, info = self._step_out_views(copy)
+        if self._flags_word.value:
+            self._raise_flags()
         return obs, reward, done, info
+
+    def last_state(self):
+        """State after the last step() as get_state() would return it, from the host buffers that call filled (no device
+        traffic; `episode` is not part of it)."""
+        o = self._obs
+        return dict(map=o['map'].reshape(self.num_envs, -1), loc=o['agent_location'], facing=o['agent_facing_id'],
+                    inv=o['inventory_items_quantity'], selected=self._sel_host.astype(np.int32), step_count=self._steps_host)
 
     def get_observation(self, copy=False):
         o = self._obs
@@ -129,6 +145,9 @@ class VecNovelGridworld:
         _cabi.check(_cabi.lib().ngw_get_step_out(self._h, _cabi._ptr(self._reward, np.int32), _cabi._ptr(self._done, np.uint8),
                                                  _cabi._ptr(self._result, np.uint8), _cabi._ptr(self._cost, np.uint8),
                                                  _cabi._ptr(self._msg, np.uint16), _cabi._ptr(self._arg, np.uint16)))
+        return self._step_out_views(copy)
+
+    def _step_out_views(self, copy=False):
         info = {'result': self._result.astype(bool), 'step_cost': _COST_F64[self._cost], 'step_cost_code': self._cost,
                 'message_code': self._msg, 'message_arg': self._arg}
         reward, done = self._reward, self._done.astype(bool)

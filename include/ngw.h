@@ -204,6 +204,14 @@ int ngw_reset(ngw_handle* h, const uint8_t* mask_host);
 int ngw_step(ngw_handle* h, const int32_t* actions_host);
 /* Same with actions already in HBM; an out-of-range id sets NGW_F_INVALID_ACTION and leaves that env untouched. */
 int ngw_step_device(ngw_handle* h, const int32_t* actions_dev);
+/* ngw_step + ngw_get_obs + ngw_get_step_out as ONE call with one stream synchronisation: what a host-driven loop pays per
+ * step() is launch and PCIe latency, so the three round trips of the separate calls matter at small batch sizes.  Any
+ * output pointer may be NULL; batches whose outputs fit in 1 MiB travel through host memory the GPU addresses directly
+ * (no copy calls at all); page-locked buffers (ngw_host_alloc) make the copies truly asynchronous. */
+int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv,
+                  int32_t* reward, uint8_t* done, uint8_t* result, uint8_t* cost_code, uint16_t* msg_code, uint16_t* msg_arg,
+                  uint32_t* error_flags /* the sticky NGW_F_* word, as ngw_error_flags */,
+                  uint8_t* selected /* item id, 0 = '' */, int32_t* step_count);
 /* Fused bench mode: T steps in one launch with on-device uniform actions
  * a(t, env) = (word (t & 3) of philox(action_seed; t >> 2, env) * A) >> 32; state stays in LDS/registers between
  * steps and every step's changes are written through to the observation buffers. */
