@@ -70,6 +70,8 @@ class LidarInFront(NoveltyWrapper):
     def step(self, action):
         if self._vec is not None:
             self._ensure(self._vec)
+            _, reward, done, info = self._vec.step(action, with_obs=False)      # the map batch stays on the device
+            return self.observation(), reward, done, info
         _, reward, done, info = self.env.step(action)
         return self.observation(), reward, done, info
 
@@ -117,5 +119,10 @@ class AgentMap(NoveltyWrapper):
         return self.observation(obs if self._vec is not None else None)
 
     def step(self, action):
+        if self._vec is not None:
+            _, reward, done, info = self._vec.step(action, with_obs=False)      # only the window, pose and inventory travel
+            o = self._vec._obs
+            return self.observation({'agent_facing_id': o['agent_facing_id'], 'inventory_items_quantity': o['inventory_items_quantity']}), \
+                reward, done, info
         obs, reward, done, info = self.env.step(action)
-        return self.observation(obs if self._vec is not None else None), reward, done, info
+        return self.observation(None), reward, done, info

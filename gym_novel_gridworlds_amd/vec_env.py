@@ -106,8 +106,10 @@ class VecNovelGridworld:
         self._raise_flags()
         return self.get_observation(copy)
 
-    def step(self, actions, copy=False):
+    def step(self, actions, copy=False, with_obs=True):
         """step(action_id) for every env: (obs, reward[N] i32, done[N] bool, info) with host arrays.
+        `with_obs=False` leaves the Dict observation on the device (obs is None): observation wrappers that return their
+        own observation (LidarInFront, AgentMap) use it to skip the largest copy of the call.
 
         info = {'result' bool[N], 'step_cost' f64[N], 'step_cost_code', 'message_code', 'message_arg'};
         `messages(info, actions)` formats the reference's strings lazily."""
@@ -115,13 +117,14 @@ class VecNovelGridworld:
         assert a.shape == (self.num_envs,)
         self._act_pinned[...] = a
         o, p = self._obs, _cabi._ptr
+        m = p(o['map'], np.int8) if with_obs else None
         _cabi.check(_cabi.lib().ngw_step_host(                       # actions in, launch, observation + outputs out: one sync
-            self._h, p(self._act_pinned, np.int32), p(o['map'], np.int8), p(o['agent_location'], np.int32),
+            self._h, p(self._act_pinned, np.int32), m, p(o['agent_location'], np.int32),
             p(o['agent_facing_id'], np.int32), p(o['inventory_items_quantity'], np.int32), p(self._reward, np.int32),
             p(self._done, np.uint8), p(self._result, np.uint8), p(self._cost, np.uint8), p(self._msg, np.uint16), p(self._arg, np.uint16),
             C.byref(self._flags_word), p(self._sel_host, np.uint8), p(self._steps_host, np.int32)))
         self._last_actions = a
-        obs = {k: v.copy() for k, v in o.items()} if copy else o
+        obs = None if not with_obs else ({k: v.copy() for k, v in o.items()} if copy else o)
         reward, done, info = self._step_out_views(copy)
         if self._flags_word.value:
             self._raise_flags()
