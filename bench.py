@@ -155,7 +155,8 @@ def main():
             torch.cuda.synchronize()
 
     if args.mode == 'rollout':
-        v.rollout(warmup, ACTION_SEED, 0)
+        if warmup > 0:
+            v.rollout(warmup, ACTION_SEED, 0)
     else:
         run_eager(warmup, -1)
     fence()
@@ -197,7 +198,8 @@ def main():
     # the other mode of the same workload, reported beside the headline (fused T-step rollout: SURVEY.md §8(d))
     fused = None
     if args.mode == 'step' and world == 1:
-        v.rollout(warmup, ACTION_SEED, 10 ** 6)
+        if warmup > 0:
+            v.rollout(warmup, ACTION_SEED, 10 ** 6)
         fence()
         v.timing_begin()
         t1 = time.perf_counter()
@@ -229,12 +231,13 @@ def main():
             v.set_reset_prefetch(every)
             v.reset()
             v.set_state(0, step_count=(np.arange(n) * 7919 % HORIZON).astype(np.int32))
-            v.graph_build(ptrs[warmup], n, 64)
-            v.graph_launch(4)
+            gs = max(2, min(64, len(ptrs) - warmup))          # the action rows resident in HBM bound the captured graph
+            v.graph_build(ptrs[warmup], n, gs)
+            v.graph_launch(max(1, 256 // gs))
             fence()
             v.timing_begin()
-            v.graph_launch(8)
-            s_ms = v.timing_end() / 512
+            v.graph_launch(max(1, 512 // gs))
+            s_ms = v.timing_end() / (max(1, 512 // gs) * gs)
             fence()
             stag[key] = {'ms_per_step': round(s_ms, 6), 'value': round(n / (s_ms * 1e-3), 1), 'unit': 'env-steps/s'}
         v.set_reset_prefetch(0)
