@@ -49,6 +49,12 @@ def cpu_baseline(spec, budget_s=12.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
+    try:                                                    # the box's CPU SHARE (cgroup quota), not the host's thread count:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]     # more threads than that only oversubscribe
+        if quota != 'max':
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
     out = {}
     for label, threads in (('1core', 1), ('allcores', cores)):
         used = orc.set_threads(threads)
@@ -56,12 +62,12 @@ def cpu_baseline(spec, budget_s=12.0):
         o = orc.Oracle(spec.compile(), n, seed=0, autoreset=True, horizon=HORIZON)
         o.reset()
         o.rollout(5, ACTION_SEED, 0)                       # warm-up
-        t0, steps, T = time.perf_counter(), 0, 100
-        while True:
+        t0, steps, T = time.perf_counter(), 0, 500
+        while True:                                        # about budget_s / 2 seconds of CPU work per leg
             o.rollout(T, ACTION_SEED, 5 + steps)
             steps += T
             dt = time.perf_counter() - t0
-            if dt > budget_s / 2 or steps >= 2000:
+            if dt > budget_s / 2:
                 break
         out[label] = dict(value=n * steps / dt, cores=used, sample='%d envs x %d steps in %.1f s' % (n, steps, dt))
     return out
