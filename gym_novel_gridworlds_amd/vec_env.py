@@ -61,20 +61,27 @@ class VecNovelGridworld:
         self.lidar, self.lidar_fused, self.lidar_len = None, False, 0      # set by lidar_configure()
         if reset_prefetch:
             self.set_reset_prefetch(reset_prefetch)
-        N, S, K = self.num_envs, self.map_size, self.n_items
-        pin = _cabi.pinned_array                              # page-locked: D2H / H2D at full PCIe rate (API mode)
-        self._obs = {'map': pin((N, S, S), np.int8), 'agent_location': pin((N, 2), np.int32),
-                     'agent_facing_id': pin((N,), np.int32), 'inventory_items_quantity': pin((N, K), np.int32)}
-        self._reward = pin((N,), np.int32)
-        self._done = pin((N,), np.uint8)
-        self._act_pinned = pin((N,), np.int32)
         self._flags_word = C.c_uint32(0)
-        self._sel_host = np.zeros(N, np.uint8)            # selected item / step_count after the last step() (single-env adapter)
-        self._steps_host = np.zeros(N, np.int32)
-        self._result = np.zeros(N, np.uint8)
-        self._cost = np.zeros(N, np.uint8)
-        self._msg = np.zeros(N, np.uint16)
-        self._arg = np.zeros(N, np.uint16)
+        self._host = None                                     # host mirrors of the host API: allocated on first use
+
+    _HOST_ATTRS = ('_obs', '_reward', '_done', '_act_pinned', '_sel_host', '_steps_host', '_result', '_cost', '_msg', '_arg')
+
+    def __getattr__(self, name):
+        # The host mirrors (10 MB page-locked at 65 536 envs, 157 B per env) exist only for the host API; a handle that is
+        # only ever driven through device pointers (step_device / rollout / device_observation) never pays for them.
+        if name in VecNovelGridworld._HOST_ATTRS:
+            if self.__dict__.get('_host') is None:
+                N, S, K = self.num_envs, self.map_size, self.n_items
+                pin = _cabi.pinned_array                      # page-locked: D2H / H2D at full PCIe rate (API mode)
+                self.__dict__['_host'] = dict(
+                    _obs={'map': pin((N, S, S), np.int8), 'agent_location': pin((N, 2), np.int32),
+                          'agent_facing_id': pin((N,), np.int32), 'inventory_items_quantity': pin((N, K), np.int32)},
+                    _reward=pin((N,), np.int32), _done=pin((N,), np.uint8), _act_pinned=pin((N,), np.int32),
+                    _sel_host=np.zeros(N, np.uint8), _steps_host=np.zeros(N, np.int32),   # selected item / step_count after the last step()
+                    _result=np.zeros(N, np.uint8), _cost=np.zeros(N, np.uint8), _msg=np.zeros(N, np.uint16), _arg=np.zeros(N, np.uint16))
+                self.__dict__.update(self.__dict__['_host'])   # plain attributes from now on (no __getattr__ detour per access)
+            return self.__dict__[name]
+        raise AttributeError(name)
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):

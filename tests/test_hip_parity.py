@@ -235,6 +235,42 @@ def test_full_size_properties_pogostick_65536():
             assert (os_[k][0] == st[k][e]).all(), (k, e)
 
 
+def test_thirty_million_envs_match_oracle_slices():
+    """33 554 432 envs on one GPU straight through the C-ABI (5.6 GB of state, 524 288 wavefronts; the map array alone
+    exceeds 2^31 bytes - the 288 GB of HBM would hold 50x that): slices at the start, across the 2^31-byte mark of the map
+    array, in the middle and at the very end equal the oracle run on those global env indices alone."""
+    import ctypes as C
+    from gym_novel_gridworlds_amd import _cabi
+    n, base = 1 << 25, 1 << 40
+    spec = T.build_spec('pogo10')
+    cs = spec.compile()
+    S2, K = spec.map_size ** 2, len(spec.items_id)
+    L, h = _cabi.lib(), C.c_void_p()
+    _cabi.check(L.ngw_create(C.byref(cs), n, 0, 5, base, C.byref(h)))
+    try:
+        _cabi.check(L.ngw_set_autoreset(h, 1, 13))
+        _cabi.check(L.ngw_reset(h, None))
+        _cabi.check(L.ngw_rollout(h, 30, 77, 3))
+        flags = C.c_uint32(1)
+        _cabi.check(L.ngw_error_flags(h, C.byref(flags)))
+        assert flags.value == 0
+        over = (1 << 31) // S2                                          # env whose map row straddles byte 2^31
+        for first in (0, over - 1000, n // 2 + 17, n - 2048):
+            cnt = 2048
+            st = dict(map=np.zeros((cnt, S2), np.int8), loc=np.zeros((cnt, 2), np.int32), facing=np.zeros(cnt, np.int32),
+                      inv=np.zeros((cnt, K), np.int32), selected=np.zeros(cnt, np.int32), step_count=np.zeros(cnt, np.int32),
+                      episode=np.zeros(cnt, np.uint32))
+            _cabi.check(L.ngw_get_state(h, first, cnt, *[st[k].ctypes.data for k in STATE_KEYS]))
+            o = Oracle(cs, cnt, seed=5, autoreset=True, horizon=13, env_index_base=base + first)
+            o.reset()
+            assert o.rollout(30, 77, 3) == 0
+            os_ = oracle_state(o)
+            for k in STATE_KEYS:
+                assert (os_[k].reshape(st[k].shape) == st[k]).all(), (k, first)
+    finally:
+        L.ngw_destroy(h)
+
+
 def test_full_size_bow_65536_and_device_views():
     """BASELINE config 3 at full size + zero-copy device observation == host observation."""
     import torch
