@@ -5,7 +5,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_BRANCH" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU"; do
   tag=$(echo $set | cut -d' ' -f1)
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/$tag -- python3 bench.py --no-cpu-baseline --no-stagger --mode rollout --steps 200 --warmup 20 > $OUT/$tag.log 2>&1 || echo "set failed: $set"
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/$tag -- python3 bench.py --no-cpu-baseline --no-stagger --mode ${NGW_SQ_MODE:-rollout} --launch eager --steps 200 --warmup 20 > $OUT/$tag.log 2>&1 || echo "set failed: $set"
 done
 python3 - <<'PY'
 import csv, glob, re
