@@ -133,6 +133,8 @@ int check_spec(const ngw_spec* s) {
     for (int i = 0; i < NGW_MAX_ITEMS; i++)
         if (s->crate_add[i] && (i >= K || !s->crate_item || s->crate_add[i] > 15)) return fail(NGW_E_INVALID_ARG, "crate_add[%d] invalid", i);
     if (s->fence_mode && !s->fence_item) return fail(NGW_E_INVALID_ARG, "fence_mode without fence_item");
+    if ((1 << s->pass_order[0] | 1 << s->pass_order[1] | 1 << s->pass_order[2]) != 0xE)
+        return fail(NGW_E_INVALID_ARG, "pass_order must be a permutation of {1, 2, 3}");
     return NGW_OK;
 }
 
@@ -198,6 +200,7 @@ int upload_reset_u(ngw_handle* h) {
     ru.replace_from = s.replace_from; ru.replace_to = s.replace_to; ru.replace_span = (uint8_t)(s.replace_pct_hi - s.replace_pct_lo);
     ru.fence_item = s.fence_item; ru.fence_span = (uint8_t)(s.fence_pct_hi - s.fence_pct_lo);
     ru.n_inv_start = s.n_inv_start;
+    for (int j = 0; j < 3; j++) ru.pass_order[j] = s.pass_order[j];
     for (int j = 0; j < NGW_MAX_INV_START; j++) { ru.inv_start_item[j] = s.inv_start_item[j]; ru.inv_start_qty[j] = s.inv_start_qty[j]; }
     HIP_TRY(hipMemcpyAsync(&h->dspec->ru, &ru, sizeof(ru), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));

@@ -100,7 +100,7 @@ struct NgwResetU {
     uint8_t additem_item, additem_span, replace_from, replace_to;
     uint8_t replace_span, fence_item, fence_span, n_inv_start;
     uint8_t inv_start_item[NGW_MAX_INV_START], inv_start_qty[NGW_MAX_INV_START];
-    uint8_t _pad[4];
+    uint8_t pass_order[3], _pad[1];
 };
 
 /* Uniform parameters of the step-time novelty predicates (kernel template flag EXT): FireWall, FenceRestriction, Crate */

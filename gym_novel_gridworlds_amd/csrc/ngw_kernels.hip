@@ -127,7 +127,7 @@ struct ResetArgs {
     uint64_t seed;
     int S, S2, K, CW, perm_lds;
     uint32_t magicS;                // ceil(2^32 / S): cell / S for cell < S*S
-    uint32_t rs0, rs1, rs2, rs3, rs4;   // NgwResetU's packed spec bytes: wall|tap|tap_near|n_place, additem|span|repl_from|repl_to,
+    uint32_t rs0, rs1, rs2, rs3, rs4, rs5;   // NgwResetU's packed spec bytes (rs5 = pass_order): wall|tap|tap_near|n_place, additem|span|repl_from|repl_to,
                                         // repl_span|fence|fence_span|n_inv_start, inv_start_item[4], inv_start_qty[4]
 };
 
@@ -261,12 +261,16 @@ __device__ __forceinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t*
             }
         }
     }
-    if (additem_item && !flags)                                                    // AddItem / Crate
-        run_pass<NGW_PASS_ADDITEM>(a, perm_lds, env_local, px, mp, agent, 0, additem_item, additem_span);
-    if (replace_to && !flags)                                                      // ReplaceItem / FireWall
-        run_pass<NGW_PASS_REPLACE>(a, perm_lds, env_local, px, mp, agent, replace_from, replace_to, replace_span);
-    if (fence_item && !flags)                                                      // Fence / FenceRestriction
-        run_pass<NGW_PASS_FENCE>(a, perm_lds, env_local, px, mp, agent, wall_item, fence_item, fence_span);
+    if ((additem_item | replace_to | fence_item) && !flags)
+        for (int j = 0; j < 3; j++) {                                              // stacked wrappers reset innermost first
+            const int kind = (a.rs5 >> (8 * j)) & 255;
+            if (kind == 1 && additem_item)                                         // AddItem / Crate
+                run_pass<NGW_PASS_ADDITEM>(a, perm_lds, env_local, px, mp, agent, 0, additem_item, additem_span);
+            if (kind == 2 && replace_to)                                           // ReplaceItem / FireWall
+                run_pass<NGW_PASS_REPLACE>(a, perm_lds, env_local, px, mp, agent, replace_from, replace_to, replace_span);
+            if (kind == 3 && fence_item)                                           // Fence / FenceRestriction
+                run_pass<NGW_PASS_FENCE>(a, perm_lds, env_local, px, mp, agent, wall_item, fence_item, fence_span);
+        }
     if (!flags)                                                                    // AxeEasy.reset :33, AxetoBreakHard.reset :667-670
         for (int j = 0; j < n_inv_start; j++) inv[(a.rs3 >> (8 * j)) & 255u] = (int)((a.rs4 >> (8 * j)) & 255u);
     return flags | ((uint32_t)r_out << 8) | ((uint32_t)c_out << 16) | ((uint32_t)f_out << 24);
@@ -339,12 +343,12 @@ __device__ __noinline__ uint32_t new_episode(const NgwDevSpec* dspec, LDS_AS int
     ru.perm = rp->perm; ru.map = rp->map; ru.inv = rp->inv; ru.n_pad = rp->n_pad; ru.seed = rp->seed; ru.S = rp->S;
     ru.S2 = rp->S2; ru.K = rp->K; ru.CW = rp->CW; ru.perm_lds = rp->perm_lds; ru.magicS = rp->magicS; ru.off_rng = rp->off_rng;
     const GLOBAL_AS uint32_t* rsw = (const GLOBAL_AS uint32_t*)&rp->wall_item;
-    const uint32_t rs0 = rsw[0], rs1 = rsw[1], rs2 = rsw[2], rs3 = rsw[3], rs4 = rsw[4];
+    const uint32_t rs0 = rsw[0], rs1 = rsw[1], rs2 = rsw[2], rs3 = rsw[3], rs4 = rsw[4], rs5 = rsw[5];
     nx.map = np->map; nx.loc = np->loc; nx.facing = np->facing; nx.inv = np->inv; nx.episode = np->episode;
     if (may_consume && nx.episode && ((const GLOBAL_AS uint32_t*)nx.episode)[env_local] == episode)
         return consume_lane(nx, mp, inv, (GLOBAL_AS int8_t*)ru.map + env_local * ru.S2, (GLOBAL_AS int32_t*)ru.inv + env_local * ru.K,
                             env_local, ru.S2, ru.K) | NGW_F_ROWS_STORED;
-    const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS, rs0, rs1, rs2, rs3, rs4};
+    const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS, rs0, rs1, rs2, rs3, rs4, rs5};
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_base[];            // the kernel's dynamic LDS (offset 0)
     return reset_lane(a, mp, inv, cand, place_seq, perm_lds, (LDS_AS uint32_t*)(lds_base + ru.off_rng + threadIdx.x), env_global,
                       env_local, episode);

@@ -40,6 +40,8 @@ def apply_novelty(spec, novelty_name, difficulty='hard', novelty_arg1='', novelt
             _axe_hard(spec, novelty_arg1, breakincrease)
         else:
             _axe(spec, difficulty, novelty_arg1, breakincrease)
+        spec.break_increase = None        # stacked wrappers: the OUTERMOST Break-overriding wrapper handles Break alone (none of
+                                          # AxeEasy/Medium/Hard, AxetoBreak*, BreakIncrease delegates Break to the wrapped env)
     elif novelty_name == 'axetobreak':
         assert novelty_arg1 in ['wooden', 'iron'], \
             "For axe novelty, novelty_arg1 (attribute of axe, e.g. wooden, iron) is needed"             # :1623
@@ -47,12 +49,15 @@ def apply_novelty(spec, novelty_name, difficulty='hard', novelty_arg1='', novelt
             _axe_hard(spec, novelty_arg1, 'false', required=True)
         else:
             _axe(spec, difficulty, novelty_arg1, 'false', required=True)
+        spec.break_increase = None
     elif novelty_name == 'breakincrease':
         if novelty_arg1 and novelty_arg1 not in spec.items:
             # the reference's assert message dereferences env.itemtobreakmore, which does not exist (:1634, SURVEY
             # appendix #11): what surfaces is this AttributeError, not an AssertionError
             raise AttributeError("'%s' object has no attribute 'itemtobreakmore'" % spec.class_name)
         spec.break_increase = novelty_arg1                         # BreakIncrease.__init__ :1421-1424 ('' = every block)
+        spec.axe = None                   # an axe wrapper below it no longer sees Break (its item, entity, Select action and
+                                          # start inventory stay)
     elif novelty_name == 'extractincdec':
         assert novelty_arg1 in ['increase', 'decrease'], \
             "For extractincdec novelty, novelty_arg1 ('increase', 'decrease') is needed"                # :1642
@@ -91,6 +96,12 @@ def apply_novelty(spec, novelty_name, difficulty='hard', novelty_arg1='', novelt
         assert novelty_arg1 and novelty_arg2, "For replaceitem novelty, novelty_arg1 (Item to replace) and novelty_arg2" \
                                               "(Item to replace with) are needed"                       # :1672
         _replace_item(spec, difficulty, novelty_arg1, novelty_arg2)
+    kind = {'additem': 'additem', 'crate': 'additem', 'replaceitem': 'replace', 'firewall': 'replace', 'fence': 'fence',
+            'fencerestriction': 'fence'}.get(novelty_name)
+    if kind:                              # reset passes run innermost wrapper first = injection order (Wrapper.reset calls env.reset() first)
+        if kind in spec.reset_passes:
+            raise NotImplementedError("two %s-type reset passes in one stack are outside this build's scope" % kind)
+        spec.reset_passes.append(kind)
     spec.novelties.append((novelty_name, difficulty, novelty_arg1, novelty_arg2))
     return spec
 

@@ -75,7 +75,8 @@ class NgwSpec(C.Structure):
         ('fence_item', C.c_uint8), ('fence_pct_lo', C.c_uint8), ('fence_pct_hi', C.c_uint8), ('fence_mode', C.c_uint8),
         ('fire_item', C.c_uint8), ('fire_reward', C.c_int8),
         ('crate_item', C.c_uint8), ('crate_add', C.c_uint8 * MAX_ITEMS),
-        ('_pad', C.c_uint8 * 1),
+        ('pass_order', C.c_uint8 * 3),
+        ('_pad', C.c_uint8 * 2),
     ]
 
 
@@ -183,6 +184,7 @@ class EnvSpec:
         self.fire_wall = None      # FireWall: item name whose 4-neighbourhood kills the agent
         self.crate = None          # Crate: dict(item='crate', ingredients=[names drawn at injection])
         self.recipe_rewards = {}   # recipe -> reward of a successful craft when it differs from craft_reward (craftable axe)
+        self.reset_passes = []     # 'additem' / 'replace' / 'fence' in the order their wrappers were stacked (innermost first)
         self.novelties = []
 
     # -- table edits used by inject_novelty ---------------------------------------------------
@@ -302,6 +304,9 @@ class EnvSpec:
             s.inv_start_item[j], s.inv_start_qty[j] = ids[item], q
         if self.tap_pass:
             s.tap_item, s.tap_near = ids[self.tap_pass['item']], ids[self.tap_pass['near']]
+        order = list(self.reset_passes) + [k for k in ('additem', 'replace', 'fence') if k not in self.reset_passes]
+        for j, k in enumerate(order):
+            s.pass_order[j] = {'additem': 1, 'replace': 2, 'fence': 3}[k]
         if self.additem:
             s.additem_item = ids[self.additem['item']]
             s.additem_pct_lo, s.additem_pct_hi = self.additem['pct']

@@ -144,7 +144,10 @@ typedef struct ngw_spec {
      * inventory (the ingredient multiset drawn at injection, :1055-1068); crate_item = 0 -> disabled */
     uint8_t crate_item;
     uint8_t crate_add[NGW_MAX_ITEMS];
-    uint8_t _pad[1];
+    /* order of the shuffled-subset reset passes (1 = AddItem/Crate, 2 = ReplaceItem/FireWall, 3 = Fence): stacked wrappers
+     * reset innermost first, i.e. in the order they were injected; a permutation of {1, 2, 3} */
+    uint8_t pass_order[3];
+    uint8_t _pad[2];
 } ngw_spec;
 
 /* LidarInFront observation (reference gym_novel_gridworlds/observation_wrappers.py:10-80): `num_beams` rays at equally

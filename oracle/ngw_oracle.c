@@ -197,12 +197,15 @@ static int reset_env(const ngw_spec* sp, ngwo_rng* rng, int8_t* map, int32_t* lo
         }
         free(logs);
     }
-    if (sp->additem_item)                                         /* AddItem.reset, novelty_wrappers.py:1017-1028 (also Crate.reset :1071) */
-        subset_pass(sp, rng, map, agent, PASS_ADDITEM, sp->additem_pct_lo, sp->additem_pct_hi);
-    if (sp->replace_to)                                           /* ReplaceItem.reset :1129-1148 (also FireWall.reset :1160) */
-        subset_pass(sp, rng, map, agent, PASS_REPLACE, sp->replace_pct_lo, sp->replace_pct_hi);
-    if (sp->fence_item)                                           /* Fence.reset :867-889 (also FenceRestriction.reset :904) */
-        subset_pass(sp, rng, map, agent, PASS_FENCE, sp->fence_pct_lo, sp->fence_pct_hi);
+    for (int j = 0; j < 3; j++) {                                 /* stacked wrappers reset innermost first (pass_order) */
+        const int kind = sp->pass_order[j];
+        if (kind == 1 && sp->additem_item)                        /* AddItem.reset, novelty_wrappers.py:1017-1028 (also Crate.reset :1071) */
+            subset_pass(sp, rng, map, agent, PASS_ADDITEM, sp->additem_pct_lo, sp->additem_pct_hi);
+        if (kind == 2 && sp->replace_to)                          /* ReplaceItem.reset :1129-1148 (also FireWall.reset :1160) */
+            subset_pass(sp, rng, map, agent, PASS_REPLACE, sp->replace_pct_lo, sp->replace_pct_hi);
+        if (kind == 3 && sp->fence_item)                          /* Fence.reset :867-889 (also FenceRestriction.reset :904) */
+            subset_pass(sp, rng, map, agent, PASS_FENCE, sp->fence_pct_lo, sp->fence_pct_hi);
+    }
     for (int j = 0; j < sp->n_inv_start; j++) inv[sp->inv_start_item[j]] = sp->inv_start_qty[j];   /* AxeEasy.reset :33, AxetoBreakHard.reset :667-670 */
     return 0;
 }

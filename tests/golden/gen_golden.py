@@ -79,6 +79,14 @@ CFGS = {
     'crate10m':    (POGO, 10, ('crate', 'medium', '', '')),
     'crate12h':    (BOW, 12, ('crate', 'hard', '', '')),
     'crate11e':    (POGO, 11, ('crate', 'easy', '', '')),
+    # stacked novelties (wrapper over wrapper): who handles Break, and in which order the reset passes run, follows the nesting
+    'stk_axe_bi10':   (POGO, 10, [('axe', 'medium', 'wooden', ''), ('breakincrease', 'hard', '', '')]),
+    'stk_bi_axe10':   (POGO, 10, [('breakincrease', 'hard', 'tree_log', ''), ('axe', 'medium', 'iron', 'true')]),
+    'stk_add_axe12':  (POGO, 12, [('additem', 'easy', 'arrow', ''), ('axe', 'easy', 'wooden', '')]),
+    'stk_atb_bi11':   (BOW, 11, [('axetobreak', 'easy', 'iron', ''), ('breakincrease', 'hard', '', '')]),
+    'stk_fen_fire12': (POGO, 12, [('fence', 'easy', 'oak', ''), ('firewall', 'medium', '', '')]),
+    # (firewall then fence crashes in the reference: Fence.reset fences the fire_wall cells of the ring -> IndexError)
+    'stk_add_repl12': (BOW, 12, [('additem', 'medium', 'arrow', ''), ('replaceitem', 'medium', 'arrow', 'dart')]),
     # the v0 variants
     'pogov0_10':   (POGO0, 10, None),
     'pogov0_14':   (POGO0, 14, ('axe', 'medium', 'wooden', '')),
@@ -96,8 +104,13 @@ def make_env(cfg):
     if nov is not None:
         if cfg in REMAP_SEED:
             np.random.seed(REMAP_SEED[cfg])     # remapaction shuffles with the global stream at injection time
-        env = inject_novelty(env, *nov)
+        for one in novelty_list(nov):           # a stack: injected in order, the last one is the outermost wrapper
+            env = inject_novelty(env, *one)
     return env
+
+
+def novelty_list(nov):
+    return [] if nov is None else ([nov] if isinstance(nov[0], str) else list(nov))
 
 
 def snap(base):
@@ -229,7 +242,7 @@ def gen_resets(cfg, nseeds, out):
         for _ in range(3):
             env.reset()
             m, loc, f, sel, inv = snap(base)
-            assert sel == 0 and (not inv.any() or cfg in ('axeeasy10', 'axetbe10', 'atbhard10', 'atbhardi11'))
+            assert sel == 0 and (not inv.any() or cfg in ('axeeasy10', 'axetbe10', 'atbhard10', 'atbhardi11', 'stk_add_axe12', 'stk_atb_bi11'))
             maps.append(m), locs.append(loc), facs.append(f), invs.append(inv)
         words.append(next_word())
     out['rs_map'] = np.array(maps, np.int8).reshape(nseeds, 3, -1)
@@ -635,6 +648,9 @@ PLAN = {  # cfg: (reset seeds, traces, steps per trace, single-step cases, solve
     'fencer10m': (16, 3, 1200, 5000, 0), 'fencer12h': (16, 3, 1200, 5000, 0), 'repl10m': (16, 2, 1000, 2500, 0),
     'replwall12e': (16, 2, 1000, 2500, 1), 'fire10h': (16, 3, 1200, 4000, 1), 'fire14m': (16, 3, 1200, 4000, 1),
     'crate10m': (12, 3, 1200, 4000, 2), 'crate12h': (12, 2, 1000, 3000, 1), 'crate11e': (8, 2, 1000, 2500, 1),
+    'stk_axe_bi10': (8, 2, 1000, 3000, 0), 'stk_bi_axe10': (8, 2, 1000, 3000, 0), 'stk_add_axe12': (8, 2, 800, 2000, 0),
+    'stk_atb_bi11': (8, 2, 1000, 3000, 0), 'stk_fen_fire12': (12, 2, 800, 2000, 0),
+    'stk_add_repl12': (12, 2, 800, 2000, 0),
 }
 
 

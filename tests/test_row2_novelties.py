@@ -32,7 +32,10 @@ def test_argument_errors_match_reference():
         assert str(ei.value) == text
 
 
-@pytest.mark.parametrize('cfg', ROW2 + ROW3)
+STACKS = ['stk_axe_bi10', 'stk_bi_axe10', 'stk_add_axe12', 'stk_atb_bi11', 'stk_fen_fire12', 'stk_add_repl12']
+
+
+@pytest.mark.parametrize('cfg', ROW2 + ROW3 + STACKS)
 def test_adapter_replays_row2_traces(cfg):
     """inject_novelty on the reference-shaped single env (incl. remapaction reproducing the reference's permutation)."""
     np.random.seed(T.REMAP_SEED.get(cfg, 0))
