@@ -133,6 +133,7 @@ int check_spec(const ngw_spec* s) {
     for (int i = 0; i < NGW_MAX_ITEMS; i++)
         if (s->crate_add[i] && (i >= K || !s->crate_item || s->crate_add[i] > 15)) return fail(NGW_E_INVALID_ARG, "crate_add[%d] invalid", i);
     if (s->fence_mode && !s->fence_item) return fail(NGW_E_INVALID_ARG, "fence_mode without fence_item");
+    if (s->ext_flags > 3 || s->fire_skip_recipe > s->n_recipes) return fail(NGW_E_INVALID_ARG, "ext_flags / fire_skip_recipe out of range");
     if ((1 << s->pass_order[0] | 1 << s->pass_order[1] | 1 << s->pass_order[2]) != 0xE)
         return fail(NGW_E_INVALID_ARG, "pass_order must be a permutation of {1, 2, 3}");
     return NGW_OK;
@@ -308,6 +309,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
         hs.sp = *spec;
         hs.x.fire_item = spec->fire_item; hs.x.fire_reward = spec->fire_reward; hs.x.fence_item = spec->fence_item;
         hs.x.fence_mode = spec->fence_mode; hs.x.crate_item = spec->crate_item;
+        hs.x.nest = (uint32_t)spec->ext_flags | ((uint32_t)spec->fire_skip_recipe << 8);
         for (int i = 0; i < K; i++) hs.x.crate_add[i >> 3] |= (uint32_t)(spec->crate_add[i] & 15u) << (4 * (i & 7));
         h->ext = (spec->fire_item || spec->fence_mode || spec->crate_item) ? 1 : 0;
         for (int i = 0; i < 64; i++) {

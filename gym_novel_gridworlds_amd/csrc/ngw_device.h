@@ -107,6 +107,7 @@ struct NgwResetU {
 struct NgwExtU {
     int32_t fire_item, fire_reward, fence_item, fence_mode, crate_item;
     uint32_t crate_add[3];                  /* 4 bits per item id: how many of it a crate holds */
+    uint32_t nest;                          /* ngw_spec.ext_flags | fire_skip_recipe << 8 (wrapper nesting of a stack) */
 };
 
 /* Per-action descriptor, NGW_ACT_DW dwords, copied to LDS (the only lane-varying LUT of the step):

@@ -677,12 +677,12 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     PIN_S(ext_cost_ok); PIN_S(axe_item); PIN_S(axe_cost); PIN_S(axe_qty); PIN_S(place_reward); PIN_S(ext_reward); PIN_S(axe_reward);
     // step-time novelty predicates (FireWall / FenceRestriction / Crate): only the EXT instantiation carries them
     int fire_item = 0, fire_reward = 0, fence_item = 0, fence_mode = 0, crate_item = 0;
-    uint32_t crate_a0 = 0, crate_a1 = 0, crate_a2 = 0;
+    uint32_t crate_a0 = 0, crate_a1 = 0, crate_a2 = 0, nest = 0;
     if (EXT) {
         const NgwExtU& X = dspec->x;
         fire_item = X.fire_item; fire_reward = X.fire_reward; fence_item = X.fence_item; fence_mode = X.fence_mode;
-        crate_item = X.crate_item; crate_a0 = X.crate_add[0]; crate_a1 = X.crate_add[1]; crate_a2 = X.crate_add[2];
-        PIN_S(fire_item); PIN_S(fire_reward); PIN_S(fence_item); PIN_S(fence_mode); PIN_S(crate_item);
+        crate_item = X.crate_item; crate_a0 = X.crate_add[0]; crate_a1 = X.crate_add[1]; crate_a2 = X.crate_add[2]; nest = X.nest;
+        PIN_S(nest); PIN_S(fire_item); PIN_S(fire_reward); PIN_S(fence_item); PIN_S(fence_mode); PIN_S(crate_item);
         PIN_S(crate_a0); PIN_S(crate_a1); PIN_S(crate_a2);
     }
 
@@ -749,15 +749,11 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                     case NGW_ACT_RIGHT:                                            // :269-279  N->E S->W W->N E->S
                         f = (0x1023 >> (f * 4)) & 3; cost = cost_turn;
                         break;
-                    case NGW_ACT_BREAK:                                            // :280-294, axe: novelty_wrappers.py:144-183
+                    case NGW_ACT_BREAK: {                                          // :280-294, axe: novelty_wrappers.py:144-183
                         cost = cost_break;
-                        if (EXT && crate_item && front == crate_item) {            // Crate.step :1086-1089: the ingredients come first
-                            for (int i = 1; i < K; i++) {
-                                const uint32_t w = i < 8 ? crate_a0 : (i < 16 ? crate_a1 : crate_a2);
-                                const int q = (int)((w >> (4 * (i & 7))) & 15u);
-                                if (q) { const int nv = inv[i] + q; inv[i] = nv; gi[i] = nv; }
-                            }
-                        }
+                        // Crate.step :1086-1089: the ingredients come first - unless the Crate wrapper sits BELOW FenceRestriction
+                        // (NGW_XF_CRATE_IN_FENCE): then a restricted Break never reaches it
+                        bool crate_now = EXT && crate_item && front == crate_item;
                         if (EXT && fence_mode && ((brk_mask >> front) & 1u)) {     // FenceRestriction.step :924-946
                             bool restricted = false;
                             if (front != fence_item) {
@@ -769,9 +765,18 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                                         for (int dc2 = -1; dc2 <= 1; dc2++) restricted |= mp[fcell + dq + dc2] == fence_item;
                                 }
                             }
-                            if (restricted) { result = 0; msg = NGW_MSG_FENCE_RESTRICTION; break; }
-                            fence_twice = true;                                    // the wrapper runs env.step() AND its own epilogue
+                            if (restricted) {
+                                result = 0; msg = NGW_MSG_FENCE_RESTRICTION;
+                                if (nest & NGW_XF_CRATE_IN_FENCE) crate_now = false;
+                            } else fence_twice = true;                             // the wrapper runs env.step() AND its own epilogue
                         }
+                        if (crate_now)
+                            for (int i = 1; i < K; i++) {
+                                const uint32_t w = i < 8 ? crate_a0 : (i < 16 ? crate_a1 : crate_a2);
+                                const int q = (int)((w >> (4 * (i & 7))) & 15u);
+                                if (q) { const int nv = inv[i] + q; inv[i] = nv; gi[i] = nv; }
+                            }
+                        if (msg == NGW_MSG_FENCE_RESTRICTION) break;
                         if ((brk_mask >> front) & 1u) {
                             const bool axe_ok = axe_item && inv_axe >= 1 && sel == axe_item;
                             if (!axe_ok && axe_required) {                         // AxetoBreak*: novelty_wrappers.py:589-591
@@ -786,6 +791,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                             }
                         } else { result = 0; msg = NGW_MSG_CANNOT_BREAK; arg = front; }
                         break;
+                    }
                     case NGW_ACT_CHOP:                                             // AddChopAction.step, novelty_wrappers.py:1288-1308
                         cost = cost_chop;
                         if ((brk_mask >> front) & 1u) {
@@ -866,7 +872,8 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                             result = 1; cost = cost_break; msg = NGW_MSG_NONE; arg = 0;   // second step_count += 1 (:966)
                             steps += 1;
                         }
-                        if (fire_item) {                                           // FireWall.step :1168-1189, after the wrapped step
+                        if (fire_item && !((nest & NGW_XF_FIRE_SKIP_BREAK) && kind == NGW_ACT_BREAK) &&
+                            !((nest >> 8) && kind == NGW_ACT_CRAFT && (uint32_t)aarg + 1u == (nest >> 8))) {   // FireWall.step :1168-1189, after the wrapped step
                             const int ac = r * S + c;
                             if (mp[ac - S] == fire_item || mp[ac + S] == fire_item || mp[ac - 1] == fire_item || mp[ac + 1] == fire_item) {
                                 rew = fire_reward; done = 1; msg = NGW_MSG_FIRE_WALL; arg = 0;

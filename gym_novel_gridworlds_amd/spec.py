@@ -75,8 +75,7 @@ class NgwSpec(C.Structure):
         ('fence_item', C.c_uint8), ('fence_pct_lo', C.c_uint8), ('fence_pct_hi', C.c_uint8), ('fence_mode', C.c_uint8),
         ('fire_item', C.c_uint8), ('fire_reward', C.c_int8),
         ('crate_item', C.c_uint8), ('crate_add', C.c_uint8 * MAX_ITEMS),
-        ('pass_order', C.c_uint8 * 3),
-        ('_pad', C.c_uint8 * 2),
+        ('pass_order', C.c_uint8 * 3), ('ext_flags', C.c_uint8), ('fire_skip_recipe', C.c_uint8),
     ]
 
 
@@ -310,15 +309,29 @@ class EnvSpec:
         if self.additem:
             s.additem_item = ids[self.additem['item']]
             s.additem_pct_lo, s.additem_pct_hi = self.additem['pct']
+        # wrapper nesting of a stack (injection order = inner to outer), as far as the step can tell
+        names = [nv[0] for nv in self.novelties]
+        last = lambda pred: max([i for i, nv in enumerate(self.novelties) if pred(nv)], default=-1)
+        B = last(lambda nv: nv[0] in ('axe', 'axetobreak', 'breakincrease'))           # who handles Break (alone)
+        f = last(lambda nv: nv[0] == 'fencerestriction' and nv[1] != 'easy')
+        c, w = last(lambda nv: nv[0] == 'crate'), last(lambda nv: nv[0] == 'firewall')
+        h = last(lambda nv: nv[0] in ('axe', 'axetobreak') and nv[1] == 'hard')
+        fence_on, crate_on = f > B, c > B                      # below the Break handler they are never consulted
+        if w >= 0 and w < B:
+            s.ext_flags |= 1                                   # NGW_XF_FIRE_SKIP_BREAK
+        if w >= 0 and h > w:
+            s.fire_skip_recipe = 1 + rnames.index(self.novelties[h][2] + '_axe')
+        if crate_on and fence_on and c < f:
+            s.ext_flags |= 2                                   # NGW_XF_CRATE_IN_FENCE
         if self.replace:
             s.replace_from, s.replace_to = ids[self.replace['src']], ids[self.replace['dst']]
             s.replace_pct_lo, s.replace_pct_hi = self.replace['pct']
         if self.fence:
-            s.fence_item, s.fence_mode = ids[self.fence['item']], self.fence['mode']
+            s.fence_item, s.fence_mode = ids[self.fence['item']], (self.fence['mode'] if fence_on or f < 0 else 0)
             s.fence_pct_lo, s.fence_pct_hi = self.fence['pct']
         if self.fire_wall:
             s.fire_item, s.fire_reward = ids[self.fire_wall], -self.reward_done // 2        # novelty_wrappers.py:1187
-        if self.crate:
+        if self.crate and crate_on:
             s.crate_item = ids[self.crate['item']]
             for name in self.crate['ingredients']:
                 s.crate_add[ids[name]] += 1

@@ -51,6 +51,7 @@ enum { NGW_ACT_FORWARD = 0, NGW_ACT_LEFT = 1, NGW_ACT_RIGHT = 2, NGW_ACT_BREAK =
        NGW_ACT_CHOP = 8 /* AddChopAction, novelty_wrappers.py:1267 */, NGW_ACT_JUMP = 9 /* AddJumpAction, :1340 */ };
 
 /* info['message'] codes; the host formats the string (reference strings cited in spec.py) */
+enum { NGW_XF_FIRE_SKIP_BREAK = 1, NGW_XF_CRATE_IN_FENCE = 2 };
 enum { NGW_MSG_NONE = 0, NGW_MSG_BLOCK_IN_PATH = 1, NGW_MSG_CANNOT_BREAK = 2 /* arg = item */,
        NGW_MSG_PLACED = 3 /* arg = item */, NGW_MSG_ALREADY_EXISTS = 4 /* arg = front item */,
        NGW_MSG_NOT_IN_INVENTORY = 5, NGW_MSG_EXTRACT_NO_SRC = 6, NGW_MSG_EXTRACT_NOT_NEAR = 7,
@@ -147,7 +148,12 @@ typedef struct ngw_spec {
     /* order of the shuffled-subset reset passes (1 = AddItem/Crate, 2 = ReplaceItem/FireWall, 3 = Fence): stacked wrappers
      * reset innermost first, i.e. in the order they were injected; a permutation of {1, 2, 3} */
     uint8_t pass_order[3];
-    uint8_t _pad[2];
+    /* wrapper nesting of a stack, as far as the step can tell: NGW_XF_FIRE_SKIP_BREAK - the FireWall wrapper sits BELOW a
+     * Break-overriding one (axe / axetobreak / breakincrease handle Break without calling the env they wrap), so its check
+     * does not run on Break steps; fire_skip_recipe = 1 + recipe of a craftable axe whose wrapper sits above FireWall (its
+     * Craft action is handled the same way); NGW_XF_CRATE_IN_FENCE - the Crate wrapper sits below FenceRestriction, so a
+     * restricted Break never reaches it */
+    uint8_t ext_flags, fire_skip_recipe;
 } ngw_spec;
 
 /* LidarInFront observation (reference gym_novel_gridworlds/observation_wrappers.py:10-80): `num_beams` rays at equally

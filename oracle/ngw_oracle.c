@@ -258,8 +258,8 @@ void ngwo_step(const ngw_spec* sp, int8_t* map, int32_t* loc, int32_t* facing, i
     case NGW_ACT_RIGHT: f = TURN_RIGHT[f]; cost = sp->cost_turn; break;    /* :269-279 */
     case NGW_ACT_BREAK:                                           /* :280-294; axe: novelty_wrappers.py:144-183 */
         cost = sp->cost_break;
-        if (sp->crate_item && front == sp->crate_item)            /* Crate.step :1086-1089: the ingredients come first */
-            for (int i = 0; i < sp->n_items; i++) inv[i] += sp->crate_add[i];
+        if (sp->crate_item && front == sp->crate_item && !(sp->ext_flags & NGW_XF_CRATE_IN_FENCE))
+            for (int i = 0; i < sp->n_items; i++) inv[i] += sp->crate_add[i];   /* Crate.step :1086-1089: the ingredients come first */
         if (sp->fence_mode && sp->breakable[front] && front != sp->fence_item) {   /* FenceRestriction.step :924-946 */
             int restricted = 0;
             if (sp->fence_mode == 1) {                            /* medium: fence beside the AGENT, across its facing */
@@ -271,6 +271,8 @@ void ngwo_step(const ngw_spec* sp, int8_t* map, int32_t* loc, int32_t* facing, i
             }
             if (restricted) { result = 0; msg = NGW_MSG_FENCE_RESTRICTION; break; }
         }
+        if (sp->crate_item && front == sp->crate_item && (sp->ext_flags & NGW_XF_CRATE_IN_FENCE))
+            for (int i = 0; i < sp->n_items; i++) inv[i] += sp->crate_add[i];   /* Crate below FenceRestriction: only when delegated to */
         if (sp->fence_mode && sp->breakable[front]) fence_twice = 1;  /* the wrapper runs env.step() AND its own epilogue */
         if (sp->breakable[front]) {
             const int axe_ok = sp->axe_item && inv[sp->axe_item] >= 1 && *selected == sp->axe_item;
@@ -368,7 +370,8 @@ void ngwo_step(const ngw_spec* sp, int8_t* map, int32_t* loc, int32_t* facing, i
         result = 1; cost = sp->cost_break; msg = NGW_MSG_NONE; arg = 0;   /* ... and a second step_count += 1 (:966) */
         *step_count += 1;
     }
-    if (sp->fire_item) {                                          /* FireWall.step :1168-1187, after the wrapped step */
+    if (sp->fire_item && !((sp->ext_flags & NGW_XF_FIRE_SKIP_BREAK) && kind == NGW_ACT_BREAK) &&
+        !(sp->fire_skip_recipe && kind == NGW_ACT_CRAFT && aarg + 1 == sp->fire_skip_recipe)) {   /* FireWall.step :1168-1187, after the wrapped step */
         if (map[(r - 1) * S + c] == sp->fire_item || map[(r + 1) * S + c] == sp->fire_item ||
             map[r * S + c - 1] == sp->fire_item || map[r * S + c + 1] == sp->fire_item) {
             reward = sp->fire_reward; done = 1; msg = NGW_MSG_FIRE_WALL; arg = 0;

@@ -87,13 +87,20 @@ CFGS = {
     'stk_fen_fire12': (POGO, 12, [('fence', 'easy', 'oak', ''), ('firewall', 'medium', '', '')]),
     # (firewall then fence crashes in the reference: Fence.reset fences the fire_wall cells of the ring -> IndexError)
     'stk_add_repl12': (BOW, 12, [('additem', 'medium', 'arrow', ''), ('replaceitem', 'medium', 'arrow', 'dart')]),
+    'stk_fire_axe10': (POGO, 10, [('firewall', 'medium', '', ''), ('axe', 'medium', 'wooden', '')]),     # fire check skipped on Break
+    'stk_fire_axeh10': (POGO, 10, [('firewall', 'medium', '', ''), ('axe', 'hard', 'wooden', '')]),      # ... and on Craft_<axe>
+    'stk_fr_axe10':   (POGO, 10, [('fencerestriction', 'hard', 'oak', ''), ('axe', 'easy', 'wooden', '')]),   # restriction never consulted
+    'stk_axe_fr10':   (POGO, 10, [('axe', 'easy', 'wooden', ''), ('fencerestriction', 'medium', 'oak', '')]),
+    'stk_crate_fr12': (BOW, 12, [('crate', 'medium', '', ''), ('fencerestriction', 'hard', 'oak', '')]),      # crate inside the restriction
+    'stk_fr_crate12': (BOW, 12, [('fencerestriction', 'hard', 'oak', ''), ('crate', 'medium', '', '')]),
+    'stk_crate_bi10': (POGO, 10, [('crate', 'hard', '', ''), ('breakincrease', 'hard', '', '')]),             # no crate bonus
     # the v0 variants
     'pogov0_10':   (POGO0, 10, None),
     'pogov0_14':   (POGO0, 14, ('axe', 'medium', 'wooden', '')),
     'bowv0_12':    (BOW0, 12, None),
 }
 REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13,      # np.random.seed right before inject_novelty
-              'crate10m': 31, 'crate12h': 32, 'crate11e': 33}      # (remapaction shuffles / Crate draws its ingredients there)
+              'crate10m': 31, 'crate12h': 32, 'crate11e': 33, 'stk_crate_fr12': 34, 'stk_fr_crate12': 35, 'stk_crate_bi10': 36}      # (remapaction shuffles / Crate draws its ingredients there)
 DIRS = ['NORTH', 'SOUTH', 'WEST', 'EAST']
 
 
@@ -242,7 +249,7 @@ def gen_resets(cfg, nseeds, out):
         for _ in range(3):
             env.reset()
             m, loc, f, sel, inv = snap(base)
-            assert sel == 0 and (not inv.any() or cfg in ('axeeasy10', 'axetbe10', 'atbhard10', 'atbhardi11', 'stk_add_axe12', 'stk_atb_bi11'))
+            assert sel == 0 and (not inv.any() or cfg in ('axeeasy10', 'axetbe10', 'atbhard10', 'atbhardi11', 'stk_add_axe12', 'stk_atb_bi11', 'stk_fr_axe10', 'stk_axe_fr10'))
             maps.append(m), locs.append(loc), facs.append(f), invs.append(inv)
         words.append(next_word())
     out['rs_map'] = np.array(maps, np.int8).reshape(nseeds, 3, -1)
@@ -651,6 +658,9 @@ PLAN = {  # cfg: (reset seeds, traces, steps per trace, single-step cases, solve
     'stk_axe_bi10': (8, 2, 1000, 3000, 0), 'stk_bi_axe10': (8, 2, 1000, 3000, 0), 'stk_add_axe12': (8, 2, 800, 2000, 0),
     'stk_atb_bi11': (8, 2, 1000, 3000, 0), 'stk_fen_fire12': (12, 2, 800, 2000, 0),
     'stk_add_repl12': (12, 2, 800, 2000, 0),
+    'stk_fire_axe10': (8, 2, 1000, 4000, 0), 'stk_fire_axeh10': (8, 2, 1000, 4000, 0), 'stk_fr_axe10': (8, 2, 800, 4000, 0),
+    'stk_axe_fr10': (8, 2, 800, 4000, 0), 'stk_crate_fr12': (8, 2, 800, 4000, 0), 'stk_fr_crate12': (8, 2, 800, 4000, 0),
+    'stk_crate_bi10': (8, 2, 800, 3000, 0),
 }
 
 

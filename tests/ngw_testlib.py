@@ -43,12 +43,20 @@ CFGS.update({
     'stk_atb_bi11': (BOW, 11, [('axetobreak', 'easy', 'iron', ''), ('breakincrease', 'hard', '', '')]),
     'stk_fen_fire12': (POGO, 12, [('fence', 'easy', 'oak', ''), ('firewall', 'medium', '', '')]),
     'stk_add_repl12': (BOW, 12, [('additem', 'medium', 'arrow', ''), ('replaceitem', 'medium', 'arrow', 'dart')]),
+    'stk_fire_axe10': (POGO, 10, [('firewall', 'medium', '', ''), ('axe', 'medium', 'wooden', '')]),
+    'stk_fire_axeh10': (POGO, 10, [('firewall', 'medium', '', ''), ('axe', 'hard', 'wooden', '')]),
+    'stk_fr_axe10': (POGO, 10, [('fencerestriction', 'hard', 'oak', ''), ('axe', 'easy', 'wooden', '')]),
+    'stk_axe_fr10': (POGO, 10, [('axe', 'easy', 'wooden', ''), ('fencerestriction', 'medium', 'oak', '')]),
+    'stk_crate_fr12': (BOW, 12, [('crate', 'medium', '', ''), ('fencerestriction', 'hard', 'oak', '')]),
+    'stk_fr_crate12': (BOW, 12, [('fencerestriction', 'hard', 'oak', ''), ('crate', 'medium', '', '')]),
+    'stk_crate_bi10': (POGO, 10, [('crate', 'hard', '', ''), ('breakincrease', 'hard', '', '')]),
 })
 # configurations WITHOUT reference fixtures (larger maps of pinned components: the oracle is the checker there)
 CFGS.update({'fire32m': (POGO, 32, ('firewall', 'medium', '', '')), 'fencer24h': (BOW, 24, ('fencerestriction', 'hard', 'oak', '')),
              'repl40e': (POGO, 40, ('replaceitem', 'easy', 'wall', 'brick'))})
 NO_FIXTURES = ('fire32m', 'fencer24h', 'repl40e')
-REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13, 'crate10m': 31, 'crate12h': 32, 'crate11e': 33}
+REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13, 'crate10m': 31, 'crate12h': 32, 'crate11e': 33,
+              'stk_crate_fr12': 34, 'stk_fr_crate12': 35, 'stk_crate_bi10': 36}
 HEADLINE = ['pogo10', 'bow20', 'axe10', 'add32']       # BASELINE.json configs 2-5
 
 _spec_json = None

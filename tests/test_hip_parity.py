@@ -74,7 +74,8 @@ def test_reset_matches_oracle(cfg, n):
                                                  ('fire14m', 500, 100, 0), ('crate10m', 2048, 200, 40), ('repl10m', 1000, 120, 30),
                                                  ('atbhard10', 1000, 150, 35), ('axehardi12', 640, 100, 30), ('fence12h', 500, 80, 25),
                                                  ('fire32m', 128, 60, 20), ('fencer24h', 256, 60, 20), ('stk_fen_fire12', 1000, 100, 25),
-                                                 ('stk_bi_axe10', 1000, 100, 30), ('stk_atb_bi11', 800, 100, 0)])
+                                                 ('stk_bi_axe10', 1000, 100, 30), ('stk_atb_bi11', 800, 100, 0), ('stk_fire_axe10', 1500, 120, 40),
+                                                 ('stk_crate_fr12', 800, 100, 30), ('stk_fr_crate12', 800, 100, 30), ('stk_fr_axe10', 800, 80, 25)])
 def test_autoreset_steps_match_oracle(cfg, n, steps, horizon):
     """Random actions with same-step autoreset (done or horizon): outputs every step, full state at checkpoints."""
     spec = T.build_spec(cfg)

@@ -22,8 +22,9 @@ def test_spec_tables_match_reference(cfg):
     assert spec.action_space_n == ref['action_space_n']          # the wrapper's; only addchop / addjump grow it
     novs = T.novelty_list(ref['novelty'])
     hard = any(nv[0] in ('axe', 'axetobreak') and nv[1] == 'hard' for nv in novs)
-    assert ref['base_action_space_n'] == (17 if 'Pogostick' in ref['env_id'] else 15) + (2 if hard else 0)
-    assert getattr(spec, 'base_action_space_n', ref['base_action_space_n']) == ref['base_action_space_n']
+    if len(novs) < 2:          # (in a stack the craftable-axe wrapper re-makes the action_space of the WRAPPER below it, not the env's)
+        assert ref['base_action_space_n'] == (17 if 'Pogostick' in ref['env_id'] else 15) + (2 if hard else 0)
+        assert getattr(spec, 'base_action_space_n', ref['base_action_space_n']) == ref['base_action_space_n']
     assert [[k, v] for k, v in spec.items_quantity.items()] == ref['items_quantity']
     assert sorted(spec.entities) == ref['entities']
     assert sorted(spec.unbreakable_items) == ref['unbreakable_items']

@@ -32,7 +32,8 @@ def test_argument_errors_match_reference():
         assert str(ei.value) == text
 
 
-STACKS = ['stk_axe_bi10', 'stk_bi_axe10', 'stk_add_axe12', 'stk_atb_bi11', 'stk_fen_fire12', 'stk_add_repl12']
+STACKS = ['stk_axe_bi10', 'stk_bi_axe10', 'stk_add_axe12', 'stk_atb_bi11', 'stk_fen_fire12', 'stk_add_repl12', 'stk_fire_axe10',
+          'stk_fire_axeh10', 'stk_fr_axe10', 'stk_axe_fr10', 'stk_crate_fr12', 'stk_fr_crate12', 'stk_crate_bi10']
 
 
 @pytest.mark.parametrize('cfg', ROW2 + ROW3 + STACKS)
