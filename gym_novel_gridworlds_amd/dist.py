@@ -7,7 +7,6 @@ observation batch of all ranks on one rank (RCCL gather over xGMI for device ten
 On MI355X the 7 xGMI links of the root are all inbound peers, so a direct gather moves each shard over its own
 link (shard bytes / ~153 GB/s) instead of a ring's per-link serialisation.
 """
-import numpy as np
 
 from .vec_env import VecNovelGridworld
 

@@ -18,7 +18,7 @@ import numpy as np
 
 from . import spaces
 from .spec import DIRECTION_ID, DIRECTION_STR, STEP_COSTS, EnvSpec
-from .vec_env import PLACEMENT_MESSAGE, VecNovelGridworld
+from .vec_env import VecNovelGridworld
 
 try:
     import gym as _gym

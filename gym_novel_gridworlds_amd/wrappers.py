@@ -11,7 +11,6 @@ import os
 import pickle
 from datetime import datetime
 
-import numpy as np
 
 from . import spaces
 from .novelty_wrappers import NoveltyWrapper
