@@ -21,7 +21,7 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_out_device_ptrs', 'ngw_sync', 'ngw_error_flags', 'ngw_timing_begin', 'ngw_timing_end',
            'ngw_graph_build', 'ngw_graph_launch', 'ngw_lidar_configure', 'ngw_lidar', 'ngw_lidar_fuse',
            'ngw_get_lidar', 'ngw_lidar_device_ptr', 'ngw_host_alloc', 'ngw_host_free', 'ngw_agent_view',
-           'ngw_get_agent_view', 'ngw_agent_view_device_ptr', 'ngw_set_reset_prefetch', 'ngw_step_host']
+           'ngw_get_agent_view', 'ngw_agent_view_device_ptr', 'ngw_set_reset_prefetch', 'ngw_step_host', 'ngw_lidar_set_output']
 
 _lib = None
 
@@ -99,6 +99,8 @@ def lib():
     L.ngw_lidar_configure.argtypes = [vp, vp]
     L.ngw_lidar.argtypes = [vp]
     L.ngw_lidar_fuse.argtypes = [vp, C.c_int]
+    if hasattr(L, 'ngw_lidar_set_output'):
+        L.ngw_lidar_set_output.argtypes = [vp, C.c_int]
     L.ngw_get_lidar.argtypes = [vp, vp]
     L.ngw_lidar_device_ptr.argtypes = [vp, C.POINTER(vp)]
     L.ngw_agent_view.argtypes = [vp, C.c_int]

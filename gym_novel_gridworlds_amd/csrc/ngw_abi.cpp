@@ -58,6 +58,7 @@ struct ngw_handle {
     NgwLidarDev* lidar_cfg = nullptr;     // device tables
     int32_t* lidar_out = nullptr;
     int lidar_len = 0;
+    int lidar_bits = 32;                  // element width of the lidar observation (ngw_lidar_set_output)
     uint32_t lidar_magic = 0, lidar_off_tab = 0, lidar_off_tile = 0, lidar_off_map = 0;
     int lidar_fused = 0, lidar_range = 0, lidar_beams = 0, lidar_chan = 0, lidar_ninv = 0;
     size_t lidar_lds = 0;
@@ -177,8 +178,13 @@ int layout_lds(ngw_handle* h) {
         p.off_ltile = off; off += (uint32_t)(NGW_EPB * h->lidar_len);
         p.lcfg = h->lidar_cfg; p.lout = h->lidar_out; p.lidar_len = h->lidar_len;
         p.l_beams = h->lidar_beams; p.l_range = h->lidar_range; p.l_chan = h->lidar_chan; p.l_inv = h->lidar_ninv;
+        p.l_i16 = h->lidar_bits == 16;
     }
-    h->off_rng = off; off += (uint32_t)(NGW_EPB * 32);      // Philox word ring of the reset path (ngw_kernels.hip PHILOX_RING)
+    // Philox word ring of the reset path (ngw_kernels.hip PHILOX_RING, 8 KB).  With the fused lidar epilogue it shares the
+    // observation tile's region (the tile is rebuilt after any reset, the ring is dead by then): 8 KB more would take the
+    // wave past 40 KB and a CU from four resident waves to three - measured as 13.6 -> 21.7 us per batched step.
+    if (h->lidar_fused && h->lidar_len >= 32) h->off_rng = p.off_ltile;
+    else { h->off_rng = off; off += (uint32_t)(NGW_EPB * 32); }
     if ((size_t)off * 4 > 160 * 1024)
         return fail(NGW_E_INVALID_ARG, "map_size %d%s needs %zu B of LDS per wavefront (> 160 KiB)", S,
                     h->lidar_fused ? " with the fused lidar observation" : "", (size_t)off * 4);
@@ -759,6 +765,17 @@ int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg) {
     return NGW_OK;
 }
 
+int ngw_lidar_set_output(ngw_handle* h, int bits) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (bits != 16 && bits != 32) return fail(NGW_E_INVALID_ARG, "lidar output width must be 16 or 32 bits");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    drop_graph(h);                                   // captured launches bake the width in
+    h->lidar_bits = bits;
+    h->proto.l_i16 = bits == 16;
+    return NGW_OK;
+}
+
 int ngw_lidar_fuse(ngw_handle* h, int enable) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     if (enable && !h->lidar_len) return fail(NGW_E_INVALID_ARG, "ngw_lidar_fuse before ngw_lidar_configure");
@@ -778,16 +795,17 @@ int ngw_lidar(ngw_handle* h) {
     HIP_TRY(hipSetDevice(h->device));
     NgwLaunch a = h->proto;
     a.b = h->b;
+    a.l_i16 = h->lidar_bits == 16;
     HIP_TRY(ngw_lidar_launch(h->lidar_cfg, &a, h->map_mode, h->lidar_out, h->lidar_len, h->lidar_off_map, h->lidar_off_tab,
                              h->lidar_off_tile, (unsigned)(h->n_pad / NGW_EPB), h->lidar_lds, h->stream));
     return NGW_OK;
 }
 
-int ngw_get_lidar(ngw_handle* h, int32_t* out_host) {
+int ngw_get_lidar(ngw_handle* h, void* out_host) {
     if (!h || !out_host) return fail(NGW_E_INVALID_ARG, "NULL argument");
     if (!h->lidar_len) return fail(NGW_E_INVALID_ARG, "ngw_get_lidar before ngw_lidar_configure");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpyAsync(out_host, h->lidar_out, (size_t)h->n * h->lidar_len * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(out_host, h->lidar_out, (size_t)h->n * h->lidar_len * (h->lidar_bits / 8), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return NGW_OK;
 }

@@ -47,6 +47,7 @@ struct NgwLaunch {
     const struct NgwLidarDev* lcfg;
     int32_t* lout;               /* [n_pad][lidar_len] */
     int32_t lidar_len, l_beams, l_range, l_chan, l_inv;
+    int32_t l_i16;               /* 1: the observation is stored as int16 (values saturate at 32767), 0: int32 */
     uint32_t off_ltab, off_ltile;
     int32_t perm_lds;            /* AddItem shuffle array: 1 = LDS at off_perm ([S2][32] u16, two half-wave batches), 0 = HBM scratch */
     uint32_t off_perm;

@@ -531,6 +531,23 @@ __device__ __forceinline__ void lidar_march(const int8_t* agent, int f, int B, i
     }
 }
 
+// The wave's 64 observation rows leave the LDS tile as one contiguous block: 16 * L pieces of int32, or - with the int16
+// output - 8 * L pieces, each packing eight consecutive values (they are >= 0; anything above 32767 saturates).
+// (pointers carry their address space: a pinned generic pointer would turn every access into a flat_* instruction)
+__device__ __forceinline__ void lidar_store(const LDS_AS uint32_t* tile, GLOBAL_AS uint32_t* out_chunk, int L, bool i16, int tid) {
+    const LDS_AS u32x4* t4 = (const LDS_AS u32x4*)tile;
+    GLOBAL_AS u32x4* g4 = (GLOBAL_AS u32x4*)out_chunk;
+    if (!i16) {
+        for (int p = tid; p < 16 * L; p += EPB) g4[p] = t4[p];
+    } else {
+        for (int p = tid; p < 8 * L; p += EPB) {
+            const u32x4 a = t4[2 * p], b = t4[2 * p + 1];
+            g4[p] = u32x4{min(a.x, 32767u) | (min(a.y, 32767u) << 16), min(a.z, 32767u) | (min(a.w, 32767u) << 16),
+                          min(b.x, 32767u) | (min(b.y, 32767u) << 16), min(b.z, 32767u) | (min(b.w, 32767u) << 16)};
+        }
+    }
+}
+
 constexpr int LIDAR_TAB16 = 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE * 2 / 16;     // ray table = 512 pieces of 16 B
 static_assert(LIDAR_TAB16 == 8 * NGW_EPB, "ray table is 8 pieces per lane");
 static_assert(offsetof(NgwLidarDev, chan_of_item) == 16 * LIDAR_TAB16 && offsetof(NgwLidarDev, inv_item) == 16 * LIDAR_TAB16 + NGW_MAX_ITEMS,
@@ -646,7 +663,8 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     g_u8* gdone = (g_u8*)(a.b.done + e);
     g_u32* ginfo = (g_u32*)(a.b.info + e);
     PIN_V(gmap); PIN_V(ginv); PIN_V(gm); PIN_V(gi); PIN_V(gloc); PIN_V(gfac); PIN_V(grew); PIN_V(gdone); PIN_V(ginfo);
-    g_u32x4* glid = LIDAR ? (g_u32x4*)(reinterpret_cast<u32x4*>(a.lout + env0 * a.lidar_len)) : nullptr;
+    // int16 output: the same buffer holds half as many bytes per row (chunk start = env0 * L * 2 bytes)
+    GLOBAL_AS uint32_t* glid = LIDAR ? (GLOBAL_AS uint32_t*)(reinterpret_cast<uint32_t*>(a.lout) + ((env0 * a.lidar_len) >> (a.l_i16 ? 1 : 0))) : nullptr;
     int lB = 0, lR = 0, lNC = 0, lNI = 0;
     if (LIDAR) {
         lB = a.l_beams; lR = a.l_range; lNC = a.l_chan; lNI = a.l_inv;
@@ -943,7 +961,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                 for (int j = 0; j < LNI; j++) row[LB * LNC + j] = inv[inv_item[j]];           // :74-75, inventory is in LDS
             }
             __syncthreads();
-            for (int p = tid; p < 16 * L; p += EPB) glid[p] = t4[p];
+            lidar_store((const LDS_AS uint32_t*)(lds + a.off_ltile), glid, L, a.l_i16 != 0, tid);
         }
     }
     if (live) {
@@ -1027,9 +1045,8 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const NgwLidarDev* _
     }
     __syncthreads();
     // the wave's 64 rows are one contiguous block of 64 * L dwords in HBM = 16 * L pieces of 16 B
-    const u32x4* t4 = reinterpret_cast<const u32x4*>(lds + off_tile);
-    u32x4* g4 = reinterpret_cast<u32x4*>(out + env0 * L);                          // out is padded to n_pad rows
-    for (int p = tid; p < 16 * L; p += EPB) g4[p] = t4[p];
+    lidar_store((const LDS_AS uint32_t*)(lds + off_tile), (GLOBAL_AS uint32_t*)(reinterpret_cast<uint32_t*>(out) + ((env0 * L) >> (a.l_i16 ? 1 : 0))), L,
+                a.l_i16 != 0, tid);   // out is padded to n_pad rows
 }
 
 // Host-step pack: region blockIdx.y, 16 bytes per thread (a region's tail bytes go one by one); the destination is host memory mapped into the GPU's address space, so the stores travel over PCIe.

@@ -17,9 +17,10 @@ from .vec_env import VecNovelGridworld
 
 
 class LidarInFront(NoveltyWrapper):
-    def __init__(self, env, num_beams=8, fused=True):
+    def __init__(self, env, num_beams=8, fused=True, dtype=np.int32):
         super().__init__(env)
         self.num_beams = num_beams
+        self._dtype = np.dtype(dtype)                           # batched envs: int32 (default) or int16 observation rows
         self._fused = fused                                     # batched envs: compute the observation inside the step launch
         self._vec = env if isinstance(env, VecNovelGridworld) else None
         spec = env.spec if self._vec is not None else self._base()._sync_spec()
@@ -47,7 +48,7 @@ class LidarInFront(NoveltyWrapper):
     def _ensure(self, vec):
         key = (id(vec), tuple(vec.spec.items_id.items()))
         if self._configured_for != key:
-            vec.lidar_configure(self._lidar, fused=self._fused and vec is self._vec)
+            vec.lidar_configure(self._lidar, fused=self._fused and vec is self._vec, dtype=self._dtype if vec is self._vec else np.int32)
             self._configured_for = key
 
     def observation(self, obs=None):

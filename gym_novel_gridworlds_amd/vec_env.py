@@ -227,7 +227,7 @@ class VecNovelGridworld:
                 'info': torch.as_tensor(_DevArray(p[2].value, (N,), '<i4'), device=dev)}
 
     # ------------------------------------------------------------------ LidarInFront observation
-    def lidar_configure(self, lidar_config=None, num_beams=8, fused=False):
+    def lidar_configure(self, lidar_config=None, num_beams=8, fused=False, dtype=np.int32):
         """Enable the LidarInFront observation (reference observation_wrappers.py:10-80).  `lidar_config` fixes the lidar
         item set at wrap time like the reference wrapper does; by default it is built from the current spec.
         fused=True: every reset / step / rollout launch refreshes the observation in its own epilogue (no extra launch)."""
@@ -236,7 +236,11 @@ class VecNovelGridworld:
         self._lidar_c = self.lidar.compile(self.spec)
         _cabi.check(_cabi.lib().ngw_lidar_configure(self._h, C.byref(self._lidar_c)))
         self.lidar_len = self.lidar.obs_len(self.spec)
-        self._lidar_host = np.zeros((self.num_envs, self.lidar_len), np.int32)
+        self.lidar_dtype = np.dtype(dtype)
+        assert self.lidar_dtype in (np.dtype(np.int32), np.dtype(np.int16)), "lidar dtype must be int32 or int16"
+        if hasattr(_cabi.lib(), 'ngw_lidar_set_output') or self.lidar_dtype.itemsize != 4:   # (older builds through NGW_LIB: int32 only)
+            _cabi.check(_cabi.lib().ngw_lidar_set_output(self._h, self.lidar_dtype.itemsize * 8))
+        self._lidar_host = _cabi.pinned_array((self.num_envs, self.lidar_len), self.lidar_dtype)
         self.lidar_fused = bool(fused)
         _cabi.check(_cabi.lib().ngw_lidar_fuse(self._h, int(self.lidar_fused)))
 
@@ -250,8 +254,8 @@ class VecNovelGridworld:
             p = C.c_void_p()
             _cabi.check(_cabi.lib().ngw_lidar_device_ptr(self._h, C.byref(p)))
             self.sync()
-            return torch.as_tensor(_DevArray(p.value, (self.num_envs, self.lidar_len), '<i4'), device='cuda:%d' % self.device)
-        _cabi.check(_cabi.lib().ngw_get_lidar(self._h, _cabi._ptr(self._lidar_host, np.int32)))
+            return torch.as_tensor(_DevArray(p.value, (self.num_envs, self.lidar_len), self.lidar_dtype.str), device='cuda:%d' % self.device)
+        _cabi.check(_cabi.lib().ngw_get_lidar(self._h, _cabi._ptr(self._lidar_host, self.lidar_dtype)))
         return self._lidar_host.copy() if copy else self._lidar_host
 
     # ------------------------------------------------------------------ state (checkpoint / oracle injection)

@@ -271,7 +271,11 @@ int ngw_lidar(ngw_handle* h);
 /* enable = 1: every following reset / step / rollout launch also refreshes the lidar observation in its epilogue (the
  * maps are already in LDS there), so ngw_lidar() is not needed; 0 restores the plain kernels. */
 int ngw_lidar_fuse(ngw_handle* h, int enable);
-int ngw_get_lidar(ngw_handle* h, int32_t* out_host);
+/* Element width of the observation: 32 (default, int32) or 16 (int16, values saturate at 32767 - beam ranges are < 128,
+ * the inventory tail is the only part that could ever exceed it).  Halves the largest transfer of a LidarInFront loop;
+ * ngw_get_lidar / ngw_lidar_device_ptr then deal in int16 rows of the same length. */
+int ngw_lidar_set_output(ngw_handle* h, int bits);
+int ngw_get_lidar(ngw_handle* h, void* out_host /* int32 or int16 [n_envs][len] */);
 int ngw_lidar_device_ptr(ngw_handle* h, void** out);
 
 /* AgentMap (observation_wrappers.py:83-129): ngw_agent_view() gathers, for every env, the (2*view_size+1)^2 window of the

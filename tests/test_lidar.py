@@ -183,3 +183,36 @@ def test_fused_lidar_epilogue_matches_oracle(cfg, n, steps, prefetch):
     v.reset(mask); o.reset(mask); check('masked reset')
     v.lidar_configure(lc, fused=False)                     # back to the separate launch
     v.step(an[0]); o.step(an[0]); check('unfused')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('fused', [False, True])
+def test_int16_lidar_output(fused):
+    """ngw_lidar_set_output(16): the same observation as int16 rows (half the bytes), separate launch and fused epilogue,
+    host copy and zero-copy device view; values above 32767 saturate."""
+    import gym_novel_gridworlds_amd as G
+    from oracle.ngw_oracle import Oracle, lidar
+    spec, lc = lidar_setup('pogo10')
+    n = 1000
+    v = G.VecNovelGridworld(spec=spec, num_envs=n, seed=3, autoreset=True, horizon=19)
+    v.lidar_configure(lc, fused=fused, dtype=np.int16)
+    o = Oracle(spec.compile(), n, seed=3, autoreset=True, horizon=19)
+    cc = lc.compile(spec)
+    v.reset(); o.reset()
+    rs = np.random.RandomState(0)
+    for t in range(40):
+        a = rs.randint(0, 17, size=n).astype(np.int32)
+        v.step(a); o.step(a)
+        got = v.lidar_observation()
+        assert got.dtype == np.int16 and got.shape == (n, lc.obs_len(spec))
+        assert (got == lidar(cc, 10, 9, o.st.map, o.st.loc, o.st.facing, o.st.inv)).all(), t
+    assert (v.lidar_observation(device=True).cpu().numpy() == got).all()
+    st = v.get_state()
+    st['inv'][:, spec.items_id['plank']] = 100000                       # beyond int16: saturates instead of wrapping
+    v.set_state(0, inv=st['inv'])
+    v.step(np.ones(n, np.int32))                                        # a turn: refreshes the fused observation, leaves the inventory alone
+    big = v.lidar_observation()
+    col = lc.num_beams * len(lc.lidar_items_id) + lc.inventory_order(spec).index('plank')
+    assert (big[:, col] == 32767).all()
+    w = G.LidarInFront(G.VecNovelGridworld(spec=spec, num_envs=64, seed=1), num_beams=8, dtype=np.int16)
+    assert w.reset().dtype == np.int16

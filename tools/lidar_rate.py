@@ -44,3 +44,14 @@ print('  same, hipGraph replay: %.2f us per batched step -> %.2f G env-steps/s' 
 v.rollout(50, 1, 0); v.sync()
 v.timing_begin(); t = time.perf_counter(); v.rollout(500, 1, 50); ms = v.timing_end(); dt = time.perf_counter() - t
 print('fused rollout with lidar every step: %.2f us per batched step -> %.2f G env-steps/s' % (dt / 500 * 1e6, n * 500 / dt / 1e9))
+import numpy as np
+v.lidar_configure(num_beams=8, fused=True, dtype=np.int16)
+for k in range(20):
+    v.step_device(acts[k].data_ptr())
+v.sync()
+v.graph_build(acts.data_ptr(), n, 64); v.graph_launch(1); v.sync()
+v.timing_begin(); t = time.perf_counter(); v.graph_launch(8); ms = v.timing_end(); dt = time.perf_counter() - t
+print('int16 observation rows, fused, hipGraph replay: %.2f us per batched step -> %.2f G env-steps/s' % (dt / 512 * 1e6, n * 512 / dt / 1e9))
+v.rollout(50, 1, 0); v.sync()
+v.timing_begin(); t = time.perf_counter(); v.rollout(500, 1, 50); ms = v.timing_end(); dt = time.perf_counter() - t
+print('int16, fused rollout with lidar every step: %.2f us per batched step -> %.2f G env-steps/s' % (dt / 500 * 1e6, n * 500 / dt / 1e9))
