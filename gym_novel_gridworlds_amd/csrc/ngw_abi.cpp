@@ -183,8 +183,19 @@ int layout_lds(ngw_handle* h) {
     // Philox word ring of the reset path (ngw_kernels.hip PHILOX_RING, 8 KB).  With the fused lidar epilogue it shares the
     // observation tile's region (the tile is rebuilt after any reset, the ring is dead by then): 8 KB more would take the
     // wave past 40 KB and a CU from four resident waves to three - measured as 13.6 -> 21.7 us per batched step.
-    if (h->lidar_fused && h->lidar_len >= 32) h->off_rng = p.off_ltile;
-    else { h->off_rng = off; off += (uint32_t)(NGW_EPB * 32); }
+    // The ring is used when the reset has no shuffled-subset pass (those draw hundreds of words per lane: register blocks,
+    // PhiloxRegs) and when its LDS does not cost a resident wave per CU (C5: 76 KB + 8 KB would halve the occupancy).
+    {
+        const bool passes = h->spec.additem_item || h->spec.replace_to || h->spec.fence_item;
+        auto waves_per_cu = [](uint32_t dwords) { return (160u * 1024u) / (((dwords * 4u + 511u) / 512u) * 512u); };
+        h->off_rng = 0xFFFFFFFFu;                                  // = PhiloxRegs
+        if (!passes) {
+            if (h->lidar_fused && h->lidar_len >= 32) h->off_rng = p.off_ltile;
+            else if (waves_per_cu(off + NGW_EPB * 32) == waves_per_cu(off) || waves_per_cu(off + NGW_EPB * 32) >= 4) {
+                h->off_rng = off; off += (uint32_t)(NGW_EPB * 32);
+            }
+        }
+    }
     if ((size_t)off * 4 > 160 * 1024)
         return fail(NGW_E_INVALID_ARG, "map_size %d%s needs %zu B of LDS per wavefront (> 160 KiB)", S,
                     h->lidar_fused ? " with the fused lidar observation" : "", (size_t)off * 4);

@@ -42,18 +42,16 @@ namespace {
 constexpr int EPB = NGW_EPB;   // envs per block = wavefront width
 
 // ---------------------------------------------------------------- Philox4x32-10 (counter-based, per env & episode)
-// The reset path draws its words from a per-lane ring of PHILOX_RING words in LDS, filled PHILOX_RING / 4 blocks at a
-// time.  (With a 4-word register buffer per lane the 64 lanes run out at different draws, so the wave ended up
-// executing the 10-round block for nearly EVERY draw.  All lanes start together and a plain reset needs < 32 words, so
-// now the block code runs once per reset for most waves.)  Word order is unchanged: block b = counter (b, episode,
-// env_lo, env_hi) yields words 4b .. 4b+3.
+// Two word sources with one interface (same stream: block b = counter (b, episode, env_lo, env_hi) yields words 4b .. 4b+3).
+//
+// PhiloxRing: a per-lane ring of PHILOX_RING words in LDS, filled PHILOX_RING / 4 blocks at a time.  With a 4-word register
+// buffer the 64 lanes run dry at different draws, so the wave executes the 10-round block for nearly EVERY draw; all lanes
+// start together and a plain reset needs < 32 words, so with the ring the block code runs once per reset for most waves.
+//
+// PhiloxRegs: one block at a time in registers.  For resets with a shuffled-subset pass (hundreds of draws per lane - the
+// lanes run dry at different draws whatever the buffer, and a 32-word refill per lane would execute the 8-block burst
+// 64 times over: C5 50 -> 151 us per step), and wherever the ring's 8 KB of LDS would cost a resident wave per CU.
 constexpr int PHILOX_RING = 32;
-struct Philox {
-    uint32_t k0, k1, c0, c1, c2, c3;
-    LDS_AS uint32_t* ring;                                                          // word j of this lane at ring[j * EPB]
-    int pos;
-    uint32_t nxt;                                                                   // ring[pos], requested one draw ahead
-};
 
 __device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                              uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
@@ -67,38 +65,67 @@ __device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t 
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
 
-__device__ __forceinline__ void philox_fill(Philox& p) {
-    for (int b = 0; b < PHILOX_RING / 4; b++) {
-        uint32_t w0, w1, w2, w3;
-        philox_block(p.c0, p.c1, p.c2, p.c3, p.k0, p.k1, w0, w1, w2, w3);
-        p.c0++;
-        p.ring[(4 * b) * EPB] = w0; p.ring[(4 * b + 1) * EPB] = w1; p.ring[(4 * b + 2) * EPB] = w2; p.ring[(4 * b + 3) * EPB] = w3;
+struct PhiloxRing {
+    uint32_t k0, k1, c0, c1, c2, c3;
+    LDS_AS uint32_t* ring;                                                          // word j of this lane at ring[j * EPB]
+    int pos;
+    uint32_t nxt;                                                                   // ring[pos], requested one draw ahead
+
+    __device__ __forceinline__ void fill() {
+        for (int b = 0; b < PHILOX_RING / 4; b++) {
+            uint32_t w0, w1, w2, w3;
+            philox_block(c0, c1, c2, c3, k0, k1, w0, w1, w2, w3);
+            c0++;
+            ring[(4 * b) * EPB] = w0; ring[(4 * b + 1) * EPB] = w1; ring[(4 * b + 2) * EPB] = w2; ring[(4 * b + 3) * EPB] = w3;
+        }
+        pos = 0;
+        nxt = ring[0];
     }
-    p.pos = 0;
-    p.nxt = p.ring[0];
-}
+    __device__ __forceinline__ void init(uint64_t seed, uint64_t env, uint32_t episode, LDS_AS uint32_t* ring_) {
+        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+        c0 = 0; c1 = episode; c2 = (uint32_t)env; c3 = (uint32_t)(env >> 32);
+        ring = ring_;
+        fill();
+    }
+    __device__ __forceinline__ uint32_t next() {
+        const uint32_t r = nxt;
+        pos++;
+        if (pos == PHILOX_RING) fill();                                            // (eager: the stream itself is unchanged)
+        else nxt = ring[pos * EPB];                                                // lands while the caller works on r
+        return r;
+    }
+};
 
-__device__ __forceinline__ void philox_init(Philox& p, uint64_t seed, uint64_t env, uint32_t episode, LDS_AS uint32_t* ring) {
-    p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32);
-    p.c0 = 0; p.c1 = episode; p.c2 = (uint32_t)env; p.c3 = (uint32_t)(env >> 32);
-    p.ring = ring;
-    philox_fill(p);
-}
+struct PhiloxRegs {
+    uint32_t k0, k1, c0, c1, c2, c3;
+    uint32_t w0, w1, w2, w3;
+    int have;
 
-__device__ __forceinline__ uint32_t philox_next(Philox& p) {
-    const uint32_t r = p.nxt;
-    p.pos++;
-    if (p.pos == PHILOX_RING) philox_fill(p);                                      // (eager: the stream itself is unchanged)
-    else p.nxt = p.ring[p.pos * EPB];                                              // lands while the caller works on r
-    return r;
-}
+    __device__ __forceinline__ void init(uint64_t seed, uint64_t env, uint32_t episode, LDS_AS uint32_t*) {
+        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+        c0 = 0; c1 = episode; c2 = (uint32_t)env; c3 = (uint32_t)(env >> 32);
+        have = 0;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        if (have == 0) {
+            philox_block(c0, c1, c2, c3, k0, k1, w0, w1, w2, w3);
+            c0++;
+            have = 4;
+        }
+        const uint32_t r = w0;
+        w0 = w1; w1 = w2; w2 = w3;
+        have--;
+        return r;
+    }
+};
 
 // numpy legacy bounded draw in [0, max]: max == 0 consumes no word; else mask & reject (random_interval).
-__device__ __forceinline__ uint32_t bounded(Philox& p, uint32_t max) {
+template <class RNG>
+__device__ __forceinline__ uint32_t bounded(RNG& p, uint32_t max) {
     if (max == 0) return 0;
     uint32_t mask = 0xFFFFFFFFu >> __clz((int)max);
     uint32_t v;
-    do { v = philox_next(p) & mask; } while (v > max);
+    do { v = p.next() & mask; } while (v > max);
     return v;
 }
 
@@ -134,8 +161,8 @@ struct ResetArgs {
 // The shuffled-subset reset passes - AddItem.reset (novelty_wrappers.py:1017-1028), ReplaceItem.reset (:1131-1144),
 // Fence.reset (:871-884) - on a shuffle array `perm` with element stride `ps`: np.where(<predicate>) in row-major order,
 // np.random.shuffle (Fisher-Yates from the top), percent = randint(lo, hi), edit the first ceil(len * (percent / 100)).
-template <int KIND, typename P>
-__device__ __forceinline__ void subset_pass(P perm, int64_t ps, Philox& px, LDS_AS int8_t* mp, int S, int S2, int agent, int match,
+template <int KIND, typename P, class RNG>
+__device__ __forceinline__ void subset_pass(P perm, int64_t ps, RNG& px, LDS_AS int8_t* mp, int S, int S2, int agent, int match,
                                             int item, int pct_span, const GLOBAL_AS double* pctq) {
     int n = 0;
     for (int i = 0; i < S2; i++) {
@@ -162,8 +189,8 @@ __device__ __forceinline__ void subset_pass(P perm, int64_t ps, Philox& px, LDS_
     }
 }
 
-template <int KIND>
-__device__ __forceinline__ void run_pass(const ResetArgs& a, LDS_AS uint16_t* perm_lds, int64_t env_local, Philox& px, LDS_AS int8_t* mp,
+template <int KIND, class RNG>
+__device__ __forceinline__ void run_pass(const ResetArgs& a, LDS_AS uint16_t* perm_lds, int64_t env_local, RNG& px, LDS_AS int8_t* mp,
                                          int agent, int match, int item, int pct_span) {
     const GLOBAL_AS double* pctq = (const GLOBAL_AS double*)a.dspec->pctq[KIND];
     if (a.perm_lds) {
@@ -179,6 +206,7 @@ __device__ __forceinline__ void run_pass(const ResetArgs& a, LDS_AS uint16_t* pe
 
 // (LDS / global pointers carry their address space: across a real call generic pointers would turn every access
 //  into a flat_* instruction)
+template <class RNG>
 __device__ __forceinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t* mp, LDS_AS int32_t* inv, LDS_AS uint32_t* cand,
                                             const LDS_AS uint8_t* place_seq, LDS_AS uint16_t* perm_lds, LDS_AS uint32_t* rng_ring,
                                             uint64_t env_global, int64_t env_local, uint32_t episode) {
@@ -189,8 +217,8 @@ __device__ __forceinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t*
     int r_out, c_out, f_out;
     const int S = a.S, K = a.K, W = S - 4, ncand = W * W;
     const uint32_t magicW = (uint32_t)((0x100000000ull + (uint32_t)W - 1) / (uint32_t)W);   // pos / W == umulhi(pos, magicW), pos < 2^12
-    Philox px;
-    philox_init(px, a.seed, env_global, episode, rng_ring);
+    RNG px;
+    px.init(a.seed, env_global, episode, rng_ring);
     for (int k = 0; k < K; k++) inv[k] = 0;                                        // :119
     for (int r = 0; r < S; r++)                                                    // :129-130 wall ring around air
         for (int c = 0; c < S; c++)
@@ -350,8 +378,10 @@ __device__ __noinline__ uint32_t new_episode(const NgwDevSpec* dspec, LDS_AS int
                             env_local, ru.S2, ru.K) | NGW_F_ROWS_STORED;
     const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS, rs0, rs1, rs2, rs3, rs4, rs5};
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_base[];            // the kernel's dynamic LDS (offset 0)
-    return reset_lane(a, mp, inv, cand, place_seq, perm_lds, (LDS_AS uint32_t*)(lds_base + ru.off_rng + threadIdx.x), env_global,
-                      env_local, episode);
+    if (ru.off_rng != 0xFFFFFFFFu)                                                 // which word source: decided with the LDS layout (ngw_abi.cpp)
+        return reset_lane<PhiloxRing>(a, mp, inv, cand, place_seq, perm_lds, (LDS_AS uint32_t*)(lds_base + ru.off_rng + threadIdx.x),
+                                      env_global, env_local, episode);
+    return reset_lane<PhiloxRegs>(a, mp, inv, cand, place_seq, perm_lds, nullptr, env_global, env_local, episode);
 }
 
 // ---------------------------------------------------------------- map staging HBM <-> LDS (coalesced 16-B pieces)
