@@ -54,8 +54,9 @@ for mode in ('step', 'rollout'):
     out.append('')
     if mode == 'step':
         steps = d[1:]                                  # first launch is the reset-all
-        resets = [steps[i] for i in range(99, len(steps), 100)]      # every env hits the horizon H = 100 together
-        normal = [steps[i] for i in range(len(steps)) if i % 100 != 99]
+        cut = 3 * st.median(steps)                                   # every env hits the horizon H = 100 together: 1 launch in 100
+        resets = [x for x in steps if x > cut]
+        normal = [x for x in steps if x <= cut]
         big = sorted(normal)[-3:]
         out.append('Per-dispatch (kernel_trace.csv): reset-all launch %.1f us; %d step launches: median %.2f us, mean %.2f us; '
                    '%d of them hit the horizon (every env resets in that launch): %s us; the other %d: mean %.2f us, '
