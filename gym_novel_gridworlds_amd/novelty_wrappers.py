@@ -28,7 +28,16 @@ class NoveltyWrapper(object):
     def unwrapped(self):
         return getattr(self.env, 'unwrapped', self.env)
 
+    # (action name that must survive a LimitActions wrapper BELOW this one, assertion text) - the reference's step()
+    # overrides check these on every step when `limited_actions_id` is visible through the wrapped env
+    _limit_requirements = ()
+
     def step(self, action_id):
+        if self._limit_requirements and hasattr(self, 'limited_actions_id'):
+            limited = self.limited_actions_id
+            for name, message in self._limit_requirements:
+                ok = any(a.startswith(name[:-1]) for a in limited) if name.endswith('*') else name in limited
+                assert ok, message
         return self.env.step(action_id)
 
     def reset(self, **kwargs):
@@ -45,44 +54,46 @@ class NoveltyWrapper(object):
 
 
 class AxeEasy(NoveltyWrapper):
-    pass
+    _limit_requirements = (('Break', "Cannot use breakincrease novelty_arg2 because you do not have Break in LimitActions"),)   # :40
 
 
 class AxeMedium(NoveltyWrapper):
-    pass
+    _limit_requirements = (('Break', "Cannot use breakincrease novelty_arg2 because you do not have Break in LimitActions"),)   # :139
 
 
 class AxeHard(NoveltyWrapper):
-    pass
+    _limit_requirements = (('Break', "Cannot use breakincrease novelty_arg2 because you do not have Break in LimitActions"),)   # :265 (+ Craft_<axe>, set per instance)
 
 
 class AxetoBreakHard(NoveltyWrapper):
+    _limit_requirements = (('Break', "Cannot use axetobreak novelty because you do not have Break in LimitActions"),)   # :680
+
     def reset(self):                                          # novelty_wrappers.py:664 takes no kwargs
         return self.env.reset()
 
 
 class AxetoBreakEasy(NoveltyWrapper):
-    pass
+    _limit_requirements = (('Break', "Cannot use axetobreak novelty because you do not have Break in LimitActions"),)   # :467
 
 
 class AxetoBreakMedium(NoveltyWrapper):
-    pass
+    _limit_requirements = (('Break', "Cannot use axetobreak novelty because you do not have Break in LimitActions"),)   # :557
 
 
 class BreakIncrease(NoveltyWrapper):
-    pass
+    _limit_requirements = (('Break', "Cannot use breakincrease novelty because you do not have Break in LimitActions"),)   # :1429
 
 
 class ExtractIncDec(NoveltyWrapper):
-    pass
+    _limit_requirements = (('Extract*', "Cannot use extractincdec novelty because you do not have Extract action in LimitActions"),)   # :1504-1510
 
 
 class AddChopAction(NoveltyWrapper):
-    pass
+    _limit_requirements = (('Chop', "Cannot use addchop novelty because you do not have Chop in LimitActions"),)   # :1283
 
 
 class AddJumpAction(NoveltyWrapper):
-    pass
+    _limit_requirements = (('Jump', "Cannot use addjump novelty because you do not have Jump in LimitActions"),)   # :1355
 
 
 class AddItem(NoveltyWrapper):
@@ -95,11 +106,11 @@ class Fence(AddItem):                                         # reset() without 
 
 
 class FenceRestriction(AddItem):                              # :902
-    pass
+    _limit_requirements = (('Break', "Cannot use fencerestriction novelty because you do not have Break in LimitActions"),)   # :913
 
 
 class Crate(AddItem):                                         # :1070
-    pass
+    _limit_requirements = (('Break', "Cannot use crate novelty because you do not have Break in LimitActions"),)   # :1080
 
 
 class ReplaceItem(AddItem):                                   # :1128
@@ -133,6 +144,9 @@ def inject_novelty(env, novelty_name, difficulty='hard', novelty_arg1='', novelt
         from . import spaces
         had_iron = 'iron' in base.inventory_items_quantity or novelty_arg1 != 'iron'
         w = AxeHard(env) if novelty_name == 'axe' else AxetoBreakHard(env)     # copies the OLD action_space (gym.Wrapper.__init__)
+        craft = 'Craft_' + novelty_arg1 + '_axe'                               # :263-264 / :678-679: checked before Break
+        w._limit_requirements = ((craft, "Cannot use " + type(w).__name__ + " novelty because you do not have " + craft +
+                                  " in LimitActions"),) + type(w)._limit_requirements
         base.action_space = spaces.Discrete(len(base.actions_id))              # :256 / :662 re-make the base env's space
         base.inventory_items_quantity.update({novelty_arg1 + '_axe': 0})       # :230 / :643
         if novelty_name == 'axetobreak':

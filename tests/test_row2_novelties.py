@@ -162,3 +162,34 @@ def test_limit_actions_compiled_into_batched_env():
     assert (st['map'] == o.st.map).all() and (st['inv'] == o.st.inv).all()
     with pytest.raises(ValueError):
         lim.step(np.full(n, 7, np.int32))
+
+
+def test_novelty_over_limit_actions_asserts_like_reference():
+    """A novelty wrapper stacked ON a LimitActions wrapper checks on every step that the action it overrides survived the
+    limiting (novelty_wrappers.py:40, :139, :264-265, :467, :913, :1080, :1283, :1429, :1510)."""
+    def limited(actions, nov):
+        env = G.make(T.POGO if nov[0] != 'extractincdec' else T.BOW)
+        env._make_backend = lambda spec, seed_: T.OracleVec(spec, 1, seed=seed_)
+        env.seed(1)
+        env = G.inject_novelty(G.LimitActions(env, set(actions)), *nov)
+        env.reset()
+        return env
+    cases = [(('axe', 'medium', 'wooden'), "Cannot use breakincrease novelty_arg2 because you do not have Break in LimitActions"),
+             (('axetobreak', 'easy', 'iron'), "Cannot use axetobreak novelty because you do not have Break in LimitActions"),
+             (('breakincrease', 'hard'), "Cannot use breakincrease novelty because you do not have Break in LimitActions"),
+             (('crate', 'easy'), "Cannot use crate novelty because you do not have Break in LimitActions"),
+             (('fencerestriction', 'hard', 'oak'), "Cannot use fencerestriction novelty because you do not have Break in LimitActions"),
+             (('addchop', 'hard'), "Cannot use addchop novelty because you do not have Chop in LimitActions"),
+             (('axe', 'hard', 'wooden'), "Cannot use AxeHard novelty because you do not have Craft_wooden_axe in LimitActions")]
+    for nov, text in cases:
+        env = limited(['Forward', 'Left', 'Right'], nov)
+        with pytest.raises(AssertionError) as ei:
+            env.step(0)
+        assert str(ei.value) == text, (nov, ei.value)
+    env = limited(['Forward', 'Left', 'Right'], ('extractincdec', 'hard', 'decrease'))
+    with pytest.raises(AssertionError) as ei:
+        env.step(0)
+    assert str(ei.value) == "Cannot use extractincdec novelty because you do not have Extract action in LimitActions"
+    env = limited(['Forward', 'Left', 'Right', 'Break'], ('axe', 'medium', 'wooden'))        # requirement met: steps go through
+    obs, reward, done, info = env.step(env.limited_actions_id['Break'])
+    assert info['step_cost'] == 3600.0
