@@ -224,6 +224,18 @@ def main():
                               'frac_of_peak_on_min_bytes': round(obs_bytes * n * steps / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               'traffic': None}}
         add_traffic(fused['roofline'], 'rollout', n * steps)
+        # the same fused launch taking the caller's action rows from HBM (ngw_rollout_actions) instead of the in-kernel policy
+        rows_a = min(steps, len(ptrs) - warmup)
+        if rows_a >= 2:
+            v.rollout_actions(ptrs[warmup], n, rows_a)
+            fence()
+            v.timing_begin()
+            v.rollout_actions(ptrs[warmup], n, rows_a)
+            a_ms = v.timing_end()
+            fence()
+            fused['with_supplied_actions'] = {'value': round(n * rows_a / (a_ms * 1e-3), 1), 'unit': 'env-steps/s',
+                                              'ms_per_step': round(a_ms / rows_a, 6), 'steps': rows_a,
+                                              'what': 'ngw_rollout_actions: one launch, step t reads the [t, :] int32 action row resident in HBM'}
         assert v.error_flags() == 0
 
     # side measurement: the SAME workload with episode ends spread over the batch (step_count offset e * 7919 % H: about

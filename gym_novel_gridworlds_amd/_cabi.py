@@ -21,7 +21,7 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_out_device_ptrs', 'ngw_sync', 'ngw_error_flags', 'ngw_timing_begin', 'ngw_timing_end',
            'ngw_graph_build', 'ngw_graph_launch', 'ngw_lidar_configure', 'ngw_lidar', 'ngw_lidar_fuse',
            'ngw_get_lidar', 'ngw_lidar_device_ptr', 'ngw_host_alloc', 'ngw_host_free', 'ngw_agent_view',
-           'ngw_get_agent_view', 'ngw_agent_view_device_ptr', 'ngw_set_reset_prefetch', 'ngw_step_host', 'ngw_lidar_set_output']
+           'ngw_get_agent_view', 'ngw_agent_view_device_ptr', 'ngw_set_reset_prefetch', 'ngw_step_host', 'ngw_lidar_set_output', 'ngw_rollout_actions']
 
 _lib = None
 
@@ -84,6 +84,8 @@ def lib():
     if hasattr(L, 'ngw_step_host'):
         L.ngw_step_host.argtypes = [vp] + [vp] * 14
     L.ngw_rollout.argtypes = [vp, i32, u64, i64]
+    if hasattr(L, 'ngw_rollout_actions'):
+        L.ngw_rollout_actions.argtypes = [vp, vp, i64, i32]
     L.ngw_get_obs.argtypes = [vp, vp, vp, vp, vp]
     L.ngw_get_step_out.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.ngw_get_state.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp]

@@ -238,7 +238,7 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     a.t0 = t0;
     const unsigned grid = (unsigned)(h->n_pad / NGW_EPB);
     HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, (h->lidar_fused ? 1 : 0) | (h->ext ? 2 : 0), grid, h->lds_bytes, h->stream));
-    if (h->prefetch_every > 0 && (mode == NGW_MODE_STEP || mode == NGW_MODE_RESET || mode == NGW_MODE_ROLLOUT)) {
+    if (h->prefetch_every > 0 && (mode == NGW_MODE_STEP || mode == NGW_MODE_RESET || mode == NGW_MODE_ROLLOUT || mode == NGW_MODE_ROLLOUT_ACT)) {
         // Prepared next episodes: every `prefetch_every` batched steps (and right after an explicit reset) one more launch
         // refills the shadow rows that resets have consumed since.  Same stream, so it is ordered between the steps.
         h->since_refill += mode == NGW_MODE_RESET ? h->prefetch_every : n_steps;
@@ -492,6 +492,14 @@ int ngw_rollout(ngw_handle* h, int32_t n_steps, uint64_t action_seed, int64_t t0
     if (n_steps < 1) return fail(NGW_E_INVALID_ARG, "n_steps must be >= 1");
     HIP_TRY(hipSetDevice(h->device));
     return launch(h, NGW_MODE_ROLLOUT, n_steps, nullptr, nullptr, action_seed, t0);
+}
+
+int ngw_rollout_actions(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps) {
+    if (!h || !actions_dev) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    if (n_steps < 1) return fail(NGW_E_INVALID_ARG, "n_steps must be >= 1");
+    if (step_stride < h->n) return fail(NGW_E_INVALID_ARG, "step_stride %lld is smaller than n_envs", (long long)step_stride);
+    HIP_TRY(hipSetDevice(h->device));
+    return launch(h, NGW_MODE_ROLLOUT_ACT, n_steps, actions_dev, nullptr, 0, step_stride);
 }
 
 /* Diagnostic launches (profiling only, not part of include/ngw.h): mode 8 = empty kernel, 9 = stage in/out only. */

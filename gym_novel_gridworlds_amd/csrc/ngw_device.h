@@ -9,6 +9,7 @@
 
 enum { NGW_MODE_STEP = 0, NGW_MODE_RESET = 1, NGW_MODE_ROLLOUT = 2,
        NGW_MODE_REFILL = 3 /* prepare next episodes in the shadow buffers: a.b = shadow set, a.actions = the main episode[] */,
+       NGW_MODE_ROLLOUT_ACT = 4 /* fused rollout with the caller's actions: step t of env e takes a.actions[t * a.t0 + e] */,
        NGW_MODE_DBG_NOP = 8 /* exit at once: launch floor */, NGW_MODE_DBG_COPY = 9 /* stage in/out, no step logic */ };
 /* how a wave's map chunk is laid out in LDS: same image as HBM / odd-dword-padded rows / byte-granular (odd S) */
 enum { NGW_MAP_STRAIGHT = 0, NGW_MAP_DWORD = 1, NGW_MAP_BYTE = 2 };

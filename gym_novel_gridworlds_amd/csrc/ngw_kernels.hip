@@ -647,7 +647,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
             steps = a.b.step_count[e];
             episode = a.b.episode[e];
         }
-        if (MODE == NGW_MODE_STEP) action = a.actions[e];
+        if (MODE == NGW_MODE_STEP || MODE == NGW_MODE_ROLLOUT_ACT) action = a.actions[e];
         else if (MODE == NGW_MODE_RESET) action = a.reset_mask ? (int)a.reset_mask[e] : 1;
     }
     u32x4 iq[IQ];
@@ -680,6 +680,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     int reward = 0, ended = 0;
     uint32_t info = 0;
     uint32_t aw0 = 0, aw1 = 0, aw2 = 0, aw3 = 0;                                   // rollout: 4 actions per Philox block
+    int act_next = action;                                                         // rollout with the caller's actions: one step ahead
 
     // ---- everything the step loop needs, fetched once and pinned in registers
     // per-lane output addresses (VGPR pairs; 1 wave per SIMD leaves plenty)
@@ -701,7 +702,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
         PIN_V(glid); PIN_S(lB); PIN_S(lR); PIN_S(lNC); PIN_S(lNI);
     }
     constexpr int mode = MODE;
-    int n_steps = (MODE == NGW_MODE_ROLLOUT) ? a.n_steps : 1, autoreset = a.autoreset, horizon = a.horizon;
+    int n_steps = (MODE == NGW_MODE_ROLLOUT || MODE == NGW_MODE_ROLLOUT_ACT) ? a.n_steps : 1, autoreset = a.autoreset, horizon = a.horizon;
     PIN_S(n_steps); PIN_S(autoreset); PIN_S(horizon);
     const uint64_t env_global = (uint64_t)(a.env_base + e);
     uint32_t key0 = (uint32_t)a.action_seed, key1 = (uint32_t)(a.action_seed >> 32) ^ 0xA511E9B3u;
@@ -750,6 +751,12 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                     const uint32_t q = (uint32_t)tt & 3u;
                     const uint32_t w = q == 0 ? aw0 : (q == 1 ? aw1 : (q == 2 ? aw2 : aw3));
                     action = (int)__umulhi(w, (uint32_t)n_actions);
+                }
+                if (mode == NGW_MODE_ROLLOUT_ACT) {
+                    // the caller's action rows: this step's action was requested one step ago (or in the prologue), the next
+                    // step's load is issued now and lands while this step runs
+                    action = act_next;
+                    if (t + 1 < n_steps) act_next = a.actions[(int64_t)(t + 1) * a.t0 + e];
                 }
                 if (action < 0 || action >= n_actions) {                         // reference: ValueError before any change (:236)
                     flags |= NGW_F_INVALID_ACTION;
@@ -1181,6 +1188,7 @@ static hipError_t launch_mode(const NgwDevSpec* dspec, const NgwLaunch* a, unsig
     case NGW_MODE_STEP: return launch_one<MAPMODE, NGW_MODE_STEP, LIDAR, EXT>(dspec, a, grid, lds_bytes, stream);
     case NGW_MODE_RESET: return launch_one<MAPMODE, NGW_MODE_RESET, LIDAR, EXT>(dspec, a, grid, lds_bytes, stream);
     case NGW_MODE_ROLLOUT: return launch_one<MAPMODE, NGW_MODE_ROLLOUT, LIDAR, EXT>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MODE_ROLLOUT_ACT: return launch_one<MAPMODE, NGW_MODE_ROLLOUT_ACT, LIDAR, EXT>(dspec, a, grid, lds_bytes, stream);
     default: break;
     }
     if (a->mode == NGW_MODE_REFILL) return launch_one<MAPMODE, NGW_MODE_REFILL, false, false>(dspec, a, grid, lds_bytes, stream);

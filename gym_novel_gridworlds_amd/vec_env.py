@@ -190,6 +190,11 @@ class VecNovelGridworld:
         """Fused mode: n_steps steps in one launch with on-device uniform actions."""
         _cabi.check(_cabi.lib().ngw_rollout(self._h, int(n_steps), int(action_seed), int(t0)))
 
+    def rollout_actions(self, actions_ptr, step_stride, n_steps):
+        """Fused mode with the caller's actions: n_steps steps in one launch, step t reads int32 actions at device address
+        actions_ptr + 4 * t * step_stride (e.g. a [T, N] int32 tensor: data_ptr(), N, T)."""
+        _cabi.check(_cabi.lib().ngw_rollout_actions(self._h, C.c_void_p(int(actions_ptr)), int(step_stride), int(n_steps)))
+
     def sync(self):
         _cabi.check(_cabi.lib().ngw_sync(self._h))
 

@@ -225,6 +225,10 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
  * a(t, env) = (word (t & 3) of philox(action_seed; t >> 2, env) * A) >> 32; state stays in LDS/registers between
  * steps and every step's changes are written through to the observation buffers. */
 int ngw_rollout(ngw_handle* h, int32_t n_steps, uint64_t action_seed, int64_t t0);
+/* The same fused launch driven by the CALLER's actions (open-loop sequences, action repeat / frame skip, evaluating plans):
+ * batched step t takes int32 actions_dev[t * step_stride + e] (device memory, step_stride >= n_envs).  An action outside
+ * [0, n_actions) leaves that env untouched for that step and raises NGW_F_INVALID_ACTION, as in ngw_step_device. */
+int ngw_rollout_actions(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps);
 
 /* get_observation(): pogostick_v1_env.py:214-228, batched: map i8 [N,S,S], agent_location i32 [N,2] (r,c),
  * agent_facing_id i32 [N], inventory_items_quantity i32 [N,K] in items_id order.  Any pointer may be NULL. */

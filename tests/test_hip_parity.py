@@ -199,6 +199,42 @@ def test_long_soak_matches_oracle(cfg, n, horizon, prefetch):
     assert o.st.episode.min() >= 4000 // horizon and v.error_flags() == 0
 
 
+@pytest.mark.parametrize('cfg,n,T_,horizon', [('pogo10', 4096, 150, 40), ('bow20', 777, 60, 25), ('fire10h', 2048, 120, 30), ('add12m', 500, 40, 17)])
+def test_rollout_with_supplied_actions_matches_oracle(cfg, n, T_, horizon):
+    """ngw_rollout_actions: T steps in one launch taking the caller's [T, stride] int32 action rows == the oracle stepping
+    through the same rows; a stride wider than n, an out-of-range action (env untouched for that step, flag raised)."""
+    import time
+    import torch
+    spec = T.build_spec(cfg)
+    A = len(spec.actions_id)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=17, autoreset=True, horizon=horizon)
+    o = Oracle(spec.compile(), n, seed=17, autoreset=True, horizon=horizon)
+    v.reset(); o.reset()
+    stride = n + 13
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    acts = torch.randint(0, A, (T_, stride), dtype=torch.int32, device='cuda', generator=g)
+    torch.cuda.synchronize()
+    v.rollout_actions(acts.data_ptr(), stride, 1)                       # a single step first, then the rest in one launch
+    v.rollout_actions(acts[1:].data_ptr(), stride, T_ - 1)
+    an = acts.cpu().numpy()
+    for t in range(T_):
+        assert o.step(np.ascontiguousarray(an[t, :n])) == 0
+    assert_state_equal(v, o, cfg + ' rollout_actions')
+    reward, done, info = v.get_step_out()
+    assert (reward == o.reward).all() and (done == o.done.astype(bool)).all() and (info['message_code'] == o.msg_code).all()
+    assert v.error_flags() == 0
+    bad = acts[:3].clone(); bad[1, 5] = A                               # one invalid action in the middle row
+    torch.cuda.synchronize()
+    v.rollout_actions(bad.data_ptr(), stride, 3)
+    bn = bad.cpu().numpy()
+    for t in range(3):
+        o.step(np.ascontiguousarray(bn[t, :n]))
+    assert_state_equal(v, o, cfg + ' rollout_actions with an invalid action')
+    assert v.error_flags() & 1
+    with pytest.raises(ValueError):
+        v.rollout_actions(acts.data_ptr(), n - 1, 2)
+
+
 # ------------------------------------------------------------------ BASELINE sizes: size-independent properties
 def test_full_size_properties_pogostick_65536():
     """BASELINE config 2 at full size: determinism, shard independence, structural invariants, oracle on a sample."""
