@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -65,6 +66,7 @@ struct ngw_handle {
     NgwNx nx = {};                        // prepared next episodes (ngw_set_reset_prefetch); all null = off
     int prefetch_every = 0, since_refill = 0;
     uint32_t off_rng = 0;                 // LDS dword offset of the reset path's Philox ring
+    int lean = 1;                         // plain configurations step through ngw_step_lean (NGW_LEAN=0 in the environment: general kernel, A/B)
     int ext = 0;                          // spec uses FireWall / FenceRestriction / Crate step predicates -> EXT kernels
     int8_t* view_out = nullptr;           // AgentMap windows
     int view_size = 0;
@@ -221,6 +223,9 @@ int upload_reset_u(ngw_handle* h) {
     for (int j = 0; j < 3; j++) ru.pass_order[j] = s.pass_order[j];
     for (int j = 0; j < NGW_MAX_INV_START; j++) { ru.inv_start_item[j] = s.inv_start_item[j]; ru.inv_start_qty[j] = s.inv_start_qty[j]; }
     HIP_TRY(hipMemcpyAsync(&h->dspec->ru, &ru, sizeof(ru), hipMemcpyHostToDevice, h->stream));
+    NgwLaunch lp = h->proto;                                   // what the lean kernel's cold path reads instead of its kernarg
+    lp.b = h->b;
+    HIP_TRY(hipMemcpyAsync(&h->dspec->lp, &lp, sizeof(lp), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return NGW_OK;
 }
@@ -237,7 +242,7 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     a.action_seed = action_seed;
     a.t0 = t0;
     const unsigned grid = (unsigned)(h->n_pad / NGW_EPB);
-    HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, (h->lidar_fused ? 1 : 0) | (h->ext ? 2 : 0), grid, h->lds_bytes, h->stream));
+    HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, (h->lidar_fused ? 1 : 0) | (h->ext ? 2 : 0) | (h->lean ? 4 : 0), grid, h->lds_bytes, h->stream));
     if (h->prefetch_every > 0 && (mode == NGW_MODE_STEP || mode == NGW_MODE_RESET || mode == NGW_MODE_ROLLOUT || mode == NGW_MODE_ROLLOUT_ACT)) {
         // Prepared next episodes: every `prefetch_every` batched steps (and right after an explicit reset) one more launch
         // refills the shadow rows that resets have consumed since.  Same stream, so it is ordered between the steps.
@@ -300,6 +305,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     auto bail = [&](int rc) { ngw_destroy(h); return rc; };
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(NGW_E_HIP, "hipStreamCreate failed"));
     h->own_stream = true;
+    if (const char* v = getenv("NGW_LEAN")) h->lean = atoi(v) != 0;
 
     const int S = spec->map_size, S2 = S * S, K = spec->n_items;
     const size_t np = (size_t)h->n_pad;
@@ -352,6 +358,10 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
         u.place_reward = spec->place_reward; u.ext_reward = spec->ext_reward; u.axe_reward = spec->axe_reward;
         u.axe_required = spec->axe_required;
         u.cost_chop = spec->cost_chop; u.cost_jump = spec->cost_jump; u.chop_reward = spec->chop_reward;
+        for (int a = 0; a < spec->n_actions; a++) {
+            if (spec->act_kind[a] == NGW_ACT_JUMP) u.feat |= NGW_FEAT_JUMP;
+            if (spec->act_kind[a] == NGW_ACT_CHOP) u.feat |= NGW_FEAT_CHOP;
+        }
         for (int j = 0; j < spec->n_start; j++)
             for (int q = 0; q < spec->start_qty[j]; q++) hs.place_seq[hs.n_place++] = spec->start_item[j];
         for (int a = 0; a < spec->n_actions; a++) {
@@ -370,6 +380,13 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
                        ((uint32_t)spec->cost_missing[r] << 16) | ((uint32_t)spec->cost_no_table[r] << 24);
                 d[4] = spec->cost_ok[r] | ((uint32_t)(uint8_t)spec->recipe_reward[r] << 8);
             }
+            // the lean kernel's entry: the same fields, the kind's fixed cost code folded in (costs of a Craft come from d3/d4)
+            static_assert(NGW_ACT_JUMP < 16 && NGW_MAX_RECIPE_INPUTS < 8, "act_lean packs kind in 4 bits, n_inputs in 3");
+            const uint8_t base_cost[10] = {spec->cost_forward, spec->cost_turn, spec->cost_turn, spec->cost_break, spec->cost_place,
+                                           spec->cost_extract, 0, spec->cost_select, spec->cost_chop, spec->cost_jump};
+            uint32_t* l = hs.act_lean + a * NGW_ACT_DW;
+            l[0] = kind | (((d[0] >> 16) & 7u) << 4) | (((d[0] >> 24) & 1u) << 7) | (arg << 8) | ((uint32_t)(base_cost[kind] & 63u) << 16);
+            l[1] = d[1]; l[2] = d[2]; l[3] = d[3]; l[4] = d[4];
         }
         if (hipMemcpyAsync(h->dspec, &hs, sizeof(hs), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess)
@@ -500,6 +517,16 @@ int ngw_rollout_actions(ngw_handle* h, const int32_t* actions_dev, int64_t step_
     if (step_stride < h->n) return fail(NGW_E_INVALID_ARG, "step_stride %lld is smaller than n_envs", (long long)step_stride);
     HIP_TRY(hipSetDevice(h->device));
     return launch(h, NGW_MODE_ROLLOUT_ACT, n_steps, actions_dev, nullptr, 0, step_stride);
+}
+
+/* Diagnostics builds (-DNGW_STAMPS): device buffer [grid][16] uint64 the kernels write their clock stamps to; NULL = off. */
+int ngw_debug_set_stamps(ngw_handle* h, void* stamps_dev) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    drop_graph(h);
+    h->proto.stamps = static_cast<uint64_t*>(stamps_dev);
+    return NGW_OK;
 }
 
 /* Diagnostic launches (profiling only, not part of include/ngw.h): mode 8 = empty kernel, 9 = stage in/out only. */

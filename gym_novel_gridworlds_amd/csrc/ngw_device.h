@@ -56,6 +56,7 @@ struct NgwLaunch {
     uint32_t magicK;             /* ceil(2^32 / K): exact division of inventory chunk offsets (< 64*K) */
     uint32_t magicS;             /* ceil(2^32 / S): cell / S */
     uint32_t off_inv, off_cand, off_act;    /* LDS dword offsets */
+    uint64_t* stamps;            /* diagnostics builds (-DNGW_STAMPS): [grid][16] in-kernel clock stamps, or nullptr */
 };
 
 /* Uniform step parameters: every lane uses the same value, so the kernel reads them with SCALAR loads straight
@@ -69,10 +70,12 @@ struct NgwStepU {
     uint8_t ext_cost_ok, axe_item, axe_cost, axe_qty;
     uint8_t cost_chop, cost_jump;
     int8_t chop_reward;
-    uint8_t _pad;
+    uint8_t feat;                           /* NGW_FEAT_*: which optional action kinds the spec has (uniform skip of their reads) */
     int8_t place_reward, ext_reward, axe_reward;
     uint8_t axe_required;                   /* AxetoBreak*: Break fails without the selected axe */
 };
+
+enum { NGW_FEAT_JUMP = 1, NGW_FEAT_CHOP = 2 };
 
 /* Prepared next episodes (ngw_set_reset_prefetch): shadow buffers holding, for env e, the first state of episode
  * nx.episode[e]; a reset whose new episode number matches copies it instead of running the placement loop.  All null
@@ -127,6 +130,10 @@ struct NgwDevSpec {
     uint8_t place_seq[NGW_MAX_PLACE];   /* item id of the n-th placement of a reset (items_quantity flattened in order) */
     /* --- */
     int32_t n_place;
+    /* lean per-launch step kernel (ngw_lean.inc): one entry per action, read with ds_bpermute from the lane that holds it.
+     *   e0 = kind | n_inputs<<4 | needs_table<<7 | arg<<8 | base cost code<<16      e1..e4 = d1..d4 of act_desc */
+    uint32_t act_lean[NGW_MAX_ACTIONS * NGW_ACT_DW];
+    NgwLaunch lp;                /* launch prototype (layout + buffer pointers): the lean kernel's cold reset path reads it from here */
     ngw_spec sp;                 /* full spec: the (cold) reset path reads it with scalar loads */
     NgwExtU x;
     NgwNx nx;

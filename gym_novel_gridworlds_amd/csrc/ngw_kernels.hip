@@ -41,6 +41,18 @@ namespace {
 
 constexpr int EPB = NGW_EPB;   // envs per block = wavefront width
 
+// In-kernel timeline stamps (diagnostics build only: make stamps -> libngw_hip_stamps.so; tools/stamp_timeline.py).
+// s_memrealtime = the chip-wide 100 MHz clock (aligns waves of different XCDs), s_memtime = shader cycles.
+#ifdef NGW_STAMPS
+#define STAMP_DECL uint64_t st_rt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_cy[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); st_rt[i] = __builtin_amdgcn_s_memrealtime(); st_cy[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_FLUSH(a) do { if ((a).stamps && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; i_++) { (a).stamps[(size_t)blockIdx.x * 16 + i_] = st_rt[i_]; (a).stamps[(size_t)blockIdx.x * 16 + 8 + i_] = st_cy[i_]; } } } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH(a)
+#endif
+
 // ---------------------------------------------------------------- Philox4x32-10 (counter-based, per env & episode)
 // Two word sources with one interface (same stream: block b = counter (b, episode, env_lo, env_hi) yields words 4b .. 4b+3).
 //
@@ -591,6 +603,8 @@ template <int MAPMODE, int MODE, bool LIDAR, bool EXT>
 __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restrict__ dspec, const NgwLaunch a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if (MODE == NGW_MODE_DBG_NOP) return;
+    STAMP_DECL;
+    STAMP(0);
     const int tid = threadIdx.x;
     const int64_t env0 = (int64_t)blockIdx.x * EPB;
     const int64_t e = env0 + tid;                                                  // local env index of this lane
@@ -656,6 +670,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
 #pragma unroll
         for (int j = 0; j < IQ; j++) iq[j] = (j * EPB < 16 * K) ? gi[min(tid + EPB * j, 16 * K - 1)] : u32x4{0u, 0u, 0u, 0u};
     }
+    STAMP(1);
     // ---- land them in LDS
     {
         uint32_t* dst = lds + a.off_act;
@@ -675,6 +690,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
         if (tid < 2 * NGW_MAX_ITEMS / 4) lds[a.off_ltab + 4 * LIDAR_TAB16 + tid] = lit;
     }
     __syncthreads();
+    STAMP(2);
 
     uint32_t flags = 0;
     int reward = 0, ended = 0;
@@ -735,6 +751,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
         PIN_S(crate_a0); PIN_S(crate_a1); PIN_S(crate_a2);
     }
 
+    STAMP(3);
     for (int t = 0; t < n_steps; t++, tt++) {
         bool do_reset = false;
         if (live && mode != NGW_MODE_DBG_COPY) {
@@ -958,6 +975,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                 sel = 0; steps = 0;
             }
         }
+        if (t == 0) STAMP(4);
         // ---- a reset rewrote whole maps / inventory rows in LDS: store the wave's chunk back with coalesced 16-B pieces
         //      (wave-uniform decision; lanes that only stepped have already written their few changed bytes through)
         if (mode == NGW_MODE_DBG_COPY || __any(do_reset)) {
@@ -1009,7 +1027,15 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
         a.b.episode[e] = episode;
     }
     if (flags) atomicOr(a.b.flags, flags);
+#ifdef NGW_STAMPS
+    STAMP(5);
+    __builtin_amdgcn_s_waitcnt(0);                                                 // every store acknowledged
+    STAMP(6);
+    STAMP_FLUSH(a);
+#endif
 }
+
+#include "ngw_lean.inc"
 
 // ---------------------------------------------------------------- LidarInFront observation kernel
 // observation_wrappers.py:32-80.  Same wave = 64 envs decomposition and the same coalesced map staging as the step
@@ -1217,6 +1243,13 @@ extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, in
         const unsigned tpb = a->mode == 10 ? 256 : (a->mode == 11 ? 1024 : 128);
         hipLaunchKernelGGL(ngw_nop_kernel, dim3(grid * NGW_EPB / tpb), dim3(tpb), a->mode == 12 ? lds_bytes * 2 : 0, stream, dspec, *a);
         return hipGetLastError();
+    }
+    if ((feat & 4) && a->mode == NGW_MODE_STEP && !(feat & 3)) {    // plain configuration, one step: the lean kernel
+        switch (map_mode) {
+        case NGW_MAP_STRAIGHT: return launch_lean<NGW_MAP_STRAIGHT>(dspec, a, grid, lds_bytes, stream);
+        case NGW_MAP_DWORD: return launch_lean<NGW_MAP_DWORD>(dspec, a, grid, lds_bytes, stream);
+        default: return launch_lean<NGW_MAP_BYTE>(dspec, a, grid, lds_bytes, stream);
+        }
     }
     switch (map_mode) {
     case NGW_MAP_STRAIGHT: return launch_feat<NGW_MAP_STRAIGHT>(dspec, a, feat, grid, lds_bytes, stream);

@@ -1,0 +1,65 @@
+"""In-kernel timeline of ONE step launch (diagnostics build: make -C gym_novel_gridworlds_amd/csrc stamps).
+
+    NGW_LIB=$PWD/gym_novel_gridworlds_amd/libngw_hip_stamps.so python tools/stamp_timeline.py [C2 C4 ...]
+
+Every wavefront records the chip-wide 100 MHz clock (s_memrealtime) and its shader clock (s_memtime) at: 0 entry,
+1 all prologue loads issued, 2 data landed in LDS (after the barrier), 3 uniform scalars unpacked (loop entry),
+4 step body done, 5 outputs issued, 6 every store acknowledged.  The launch sampled is the last of a back-to-back series
+(hipGraph replay), i.e. steady state.  Prints, per stamp, when the waves reach it relative to the first wave's entry."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from gym_novel_gridworlds_amd import VecNovelGridworld, _cabi, apply_novelty, make_spec  # noqa: E402
+
+NAMES = ['entry', 'loads issued', 'landed in LDS', 'scalars ready', 'step done', 'outputs issued', 'stores acked']
+
+
+def main():
+    L = _cabi.lib()
+    L.ngw_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
+    for wl in (sys.argv[1:] or ['C2']):
+        env_id, S, nov, n, desc = bench.WORKLOADS[wl]
+        spec = make_spec(env_id, S)
+        if nov:
+            apply_novelty(spec, *nov)
+        A = len(spec.actions_id)
+        v = VecNovelGridworld(spec=spec, num_envs=n, device=0, seed=0, autoreset=True, horizon=100, reset_prefetch=0)
+        v.reset()
+        grid = (n + 63) // 64
+        stamps = torch.zeros((grid, 16), dtype=torch.int64, device='cuda')
+        acts = torch.randint(0, A, (40, n), dtype=torch.int32, device='cuda')
+        torch.cuda.synchronize()
+        _cabi.check(L.ngw_debug_set_stamps(v._h, C.c_void_p(stamps.data_ptr())))
+        v.graph_build(acts.data_ptr(), n, 40)
+        v.graph_launch(1)
+        v.sync()
+        v.timing_begin()
+        v.graph_launch(1)
+        ms = v.timing_end()
+        st = stamps.cpu().numpy()
+        rt, cy = st[:, :8].astype(np.float64), st[:, 8:].astype(np.float64)
+        t0 = rt[:, 0].min()
+        print('== %s: %s; %d waves; event time per launch %.2f us' % (wl, desc, grid, ms / 40 * 1e3))
+        print('%-16s %8s %8s %8s %8s %8s   (us after the first wave entered)' % ('stamp', 'min', 'p10', 'median', 'p90', 'max'))
+        for i, nm in enumerate(NAMES):
+            x = (rt[:, i] - t0) * 0.01
+            print('%-16s %8.2f %8.2f %8.2f %8.2f %8.2f' % (nm, x.min(), np.percentile(x, 10), np.median(x), np.percentile(x, 90), x.max()))
+        print('per-wave shader cycles between stamps (median / p90):')
+        for i in range(1, 7):
+            d = cy[:, i] - cy[:, i - 1]
+            print('  %-16s -> %-16s %8.0f %8.0f' % (NAMES[i - 1], NAMES[i], np.median(d), np.percentile(d, 90)))
+        life = cy[:, 6] - cy[:, 0]
+        print('  wave life %.0f cycles median; clock ~%.2f GHz' % (np.median(life), np.median(life / np.maximum((rt[:, 6] - rt[:, 0]) * 10.0, 1.0))))
+        _cabi.check(L.ngw_debug_set_stamps(v._h, None))
+        v.close()
+
+
+if __name__ == '__main__':
+    main()
