@@ -380,13 +380,59 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
                        ((uint32_t)spec->cost_missing[r] << 16) | ((uint32_t)spec->cost_no_table[r] << 24);
                 d[4] = spec->cost_ok[r] | ((uint32_t)(uint8_t)spec->recipe_reward[r] << 8);
             }
-            // the lean kernel's entry: the same fields, the kind's fixed cost code folded in (costs of a Craft come from d3/d4)
-            static_assert(NGW_ACT_JUMP < 16 && NGW_MAX_RECIPE_INPUTS < 8, "act_lean packs kind in 4 bits, n_inputs in 3");
-            const uint8_t base_cost[10] = {spec->cost_forward, spec->cost_turn, spec->cost_turn, spec->cost_break, spec->cost_place,
-                                           spec->cost_extract, 0, spec->cost_select, spec->cost_chop, spec->cost_jump};
-            uint32_t* l = hs.act_lean + a * NGW_ACT_DW;
-            l[0] = kind | (((d[0] >> 16) & 7u) << 4) | (((d[0] >> 24) & 1u) << 7) | (arg << 8) | ((uint32_t)(base_cost[kind] & 63u) << 16);
-            l[1] = d[1]; l[2] = d[2]; l[3] = d[3]; l[4] = d[4];
+            // the lean kernel's micro-op entry (NGW_LEAN_DW): conditions, per-outcome message / argument / cost, success effects
+            {
+                uint32_t* l = hs.act_lean + a * NGW_LEAN_DW;
+                uint32_t abit = NGW_CB_FALSE, bbit = NGW_CB_FALSE, msg[3] = {0, 0, 0}, asel[3] = {0, 0, 0}, move = 0, turn = 0, cellw = 0, selflag = 0;
+                uint32_t argconst = 0, is_break = 0, cslot = 0, cellv = 0, rbit = NGW_CB_FALSE, slotsel = 0, cost[3] = {0, 0, 0};
+                int delta = 0, rewc = 0;
+                auto costs = [&](uint32_t c) { cost[0] = cost[1] = cost[2] = c; };
+                switch (kind) {
+                case NGW_ACT_FORWARD: abit = NGW_CB_FRONT_NZ; msg[1] = NGW_MSG_BLOCK_IN_PATH; move = 1; costs(spec->cost_forward); break;
+                case NGW_ACT_JUMP: abit = NGW_CB_JUMP_BLOCKED; msg[1] = NGW_MSG_BLOCK_IN_PATH; move = 2; costs(spec->cost_jump); break;
+                case NGW_ACT_LEFT: turn = 1; costs(spec->cost_turn); break;
+                case NGW_ACT_RIGHT: turn = 2; costs(spec->cost_turn); break;
+                case NGW_ACT_BREAK:
+                    abit = NGW_CB_NOT_BRK; msg[1] = NGW_MSG_CANNOT_BREAK; asel[1] = 1;
+                    bbit = NGW_CB_NEED_AXE; msg[2] = NGW_MSG_NEED_AXE; asel[2] = 2; argconst = spec->axe_item;
+                    cellw = 1; slotsel = 1; is_break = 1; rbit = NGW_CB_BRK_REWARD; costs(spec->cost_break);
+                    break;
+                case NGW_ACT_CHOP:
+                    abit = NGW_CB_NOT_BRK; msg[1] = NGW_MSG_CANNOT_CHOP; asel[1] = 1;
+                    cellw = 1; slotsel = 1; delta = 2; rbit = NGW_CB_TRUE; rewc = spec->chop_reward; costs(spec->cost_chop);
+                    break;
+                case NGW_ACT_PLACE:
+                    abit = NGW_CB_NO_PLACE_ITEM; msg[1] = NGW_MSG_NOT_IN_INVENTORY;
+                    bbit = NGW_CB_FRONT_NZ; msg[2] = NGW_MSG_ALREADY_EXISTS; asel[2] = 1;
+                    msg[0] = NGW_MSG_PLACED; asel[0] = 2; argconst = spec->place_item;
+                    cellw = 1; cellv = spec->place_item; slotsel = 2; cslot = spec->place_item; delta = -1;
+                    rbit = NGW_CB_NEAR_PLACE; rewc = spec->place_reward; costs(spec->cost_place);
+                    break;
+                case NGW_ACT_EXTRACT:
+                    abit = NGW_CB_NOT_SRC; msg[1] = NGW_MSG_EXTRACT_NO_SRC; bbit = NGW_CB_NOT_NEAR; msg[2] = NGW_MSG_EXTRACT_NOT_NEAR;
+                    slotsel = 2; cslot = spec->ext_out; delta = spec->ext_qty; cellw = spec->ext_consume ? 1 : 0;
+                    rbit = NGW_CB_TRUE; rewc = spec->ext_reward; costs(spec->cost_extract); cost[0] = spec->ext_cost_ok;
+                    break;
+                case NGW_ACT_CRAFT: {
+                    const int r = (int)arg;
+                    abit = NGW_CB_MISSING; msg[1] = NGW_MSG_MISSING_ITEMS; asel[1] = 3; cost[1] = spec->cost_missing[r];
+                    bbit = NGW_CB_NEED_TABLE; msg[2] = NGW_MSG_NEED_TABLE; cost[2] = spec->cost_no_table[r];
+                    msg[0] = NGW_MSG_CRAFTED; asel[0] = 2; argconst = spec->recipe_out_item[r];
+                    slotsel = 2; cslot = spec->recipe_out_item[r]; delta = spec->recipe_out_qty[r];
+                    rbit = NGW_CB_TRUE; rewc = spec->recipe_reward[r]; cost[0] = spec->cost_ok[r];
+                    break;
+                }
+                case NGW_ACT_SELECT: abit = NGW_CB_NO_ARG_ITEM; msg[1] = NGW_MSG_NOT_IN_INVENTORY; selflag = 1; costs(spec->cost_select); break;
+                default: break;
+                }
+                static_assert(NGW_ACT_JUMP < 16 && NGW_MAX_RECIPE_INPUTS < 8 && NGW_MSG_FIRE_WALL < 16, "act_lean field widths");
+                l[0] = kind | (((d[0] >> 16) & 7u) << 4) | (((d[0] >> 24) & 1u) << 7) | (arg << 8) | (argconst << 16) | (is_break << 24);
+                l[1] = d[1]; l[2] = d[2];
+                l[3] = cslot | (cellv << 8) | ((uint32_t)(uint16_t)(int16_t)delta << 16);
+                l[4] = abit | (bbit << 4) | (msg[0] << 8) | (msg[1] << 12) | (msg[2] << 16) | (asel[0] << 20) | (asel[1] << 22) | (asel[2] << 24) |
+                       (move << 26) | (turn << 28) | (cellw << 30) | (selflag << 31);
+                l[5] = (uint32_t)(uint8_t)(int8_t)rewc | (rbit << 8) | (slotsel << 12) | ((cost[0] & 63u) << 14) | ((cost[1] & 63u) << 20) | ((cost[2] & 63u) << 26);
+            }
         }
         if (hipMemcpyAsync(h->dspec, &hs, sizeof(hs), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess)

@@ -73,9 +73,27 @@ struct NgwStepU {
     uint8_t feat;                           /* NGW_FEAT_*: which optional action kinds the spec has (uniform skip of their reads) */
     int8_t place_reward, ext_reward, axe_reward;
     uint8_t axe_required;                   /* AxetoBreak*: Break fails without the selected axe */
+    uint32_t _pad64;                        /* 64 bytes: the kernels fetch the struct as 16 dwords with ONE scalar load */
 };
 
 enum { NGW_FEAT_JUMP = 1, NGW_FEAT_CHOP = 2 };
+
+/* Lean step kernel (ngw_lean.inc): per-action micro-op table, NGW_LEAN_DW dwords per action, held one action per lane and
+ * fetched with ds_bpermute.  A step evaluates a per-lane vector of condition bits NGW_CB_* once; an action names the two
+ * conditions that make it fail (outcome s = 1 if A holds, else 2 if B holds, else 0 = success) and carries, per outcome,
+ * the message / message argument / cost code, plus what a success does (move, turn, front-cell write, one inventory slot
+ * delta, select, reward).  No per-kind code is left in the kernel.
+ *   e0 = kind | n_inputs<<4 | needs_table<<7 | arg<<8 | argconst<<16 | is_break<<24
+ *   e1 = recipe input item ids (4 bytes, dict order)         e2 = recipe input quantities (4 bytes, 0 beyond n_inputs)
+ *   e3 = const slot | cell value<<8 | (int16) slot delta<<16
+ *   e4 = A bit | B bit<<4 | msg[0..2]<<8 (4 bits each) | argsel[0..2]<<20 (2 bits each: 0 none, 1 block in front, 2 argconst,
+ *        3 recipe<<8|missing mask) | move<<26 (1 front, 2 two ahead) | turn<<28 (1 left, 2 right) | cell write<<30 | select<<31
+ *   e5 = reward const (int8) | reward condition bit<<8 | slot select<<12 (0 none, 1 block in front, 2 const slot) | cost[0..2]<<14 (6 bits each)
+ * An all-zero entry is a no-op (what an out-of-range action id fetches). */
+#define NGW_LEAN_DW 6
+enum { NGW_CB_FALSE = 0, NGW_CB_FRONT_NZ = 1, NGW_CB_JUMP_BLOCKED = 2, NGW_CB_NOT_BRK = 3, NGW_CB_NO_PLACE_ITEM = 4, NGW_CB_NOT_SRC = 5,
+       NGW_CB_NOT_NEAR = 6, NGW_CB_MISSING = 7, NGW_CB_NEED_TABLE = 8, NGW_CB_NO_ARG_ITEM = 9, NGW_CB_NEED_AXE = 10,
+       NGW_CB_NEAR_PLACE = 11, NGW_CB_BRK_REWARD = 12, NGW_CB_TRUE = 13 };
 
 /* Prepared next episodes (ngw_set_reset_prefetch): shadow buffers holding, for env e, the first state of episode
  * nx.episode[e]; a reset whose new episode number matches copies it instead of running the placement loop.  All null
@@ -130,9 +148,7 @@ struct NgwDevSpec {
     uint8_t place_seq[NGW_MAX_PLACE];   /* item id of the n-th placement of a reset (items_quantity flattened in order) */
     /* --- */
     int32_t n_place;
-    /* lean per-launch step kernel (ngw_lean.inc): one entry per action, read with ds_bpermute from the lane that holds it.
-     *   e0 = kind | n_inputs<<4 | needs_table<<7 | arg<<8 | base cost code<<16      e1..e4 = d1..d4 of act_desc */
-    uint32_t act_lean[NGW_MAX_ACTIONS * NGW_ACT_DW];
+    uint32_t act_lean[NGW_MAX_ACTIONS * NGW_LEAN_DW];   /* lean step kernel: micro-op table, see NGW_LEAN_DW */
     NgwLaunch lp;                /* launch prototype (layout + buffer pointers): the lean kernel's cold reset path reads it from here */
     ngw_spec sp;                 /* full spec: the (cold) reset path reads it with scalar loads */
     NgwExtU x;
