@@ -19,6 +19,7 @@ import bench  # noqa: E402
 from gym_novel_gridworlds_amd import VecNovelGridworld, _cabi, apply_novelty, make_spec  # noqa: E402
 
 NAMES = ['entry', 'loads issued', 'landed in LDS', 'scalars ready', 'step done', 'outputs issued', 'stores acked']
+LEAN = ['entry', 'loads issued', 'landed in LDS', 'LDS reads back', 'outcome known', 'step done', 'outputs issued', 'stores acked']
 
 
 def main():
@@ -46,17 +47,19 @@ def main():
         st = stamps.cpu().numpy()
         rt, cy = st[:, :8].astype(np.float64), st[:, 8:].astype(np.float64)
         t0 = rt[:, 0].min()
+        names = LEAN if rt[:, 7].max() > 0 else NAMES           # the lean kernel fills all eight slots
         print('== %s: %s; %d waves; event time per launch %.2f us' % (wl, desc, grid, ms / 40 * 1e3))
         print('%-16s %8s %8s %8s %8s %8s   (us after the first wave entered)' % ('stamp', 'min', 'p10', 'median', 'p90', 'max'))
-        for i, nm in enumerate(NAMES):
+        for i, nm in enumerate(names):
             x = (rt[:, i] - t0) * 0.01
             print('%-16s %8.2f %8.2f %8.2f %8.2f %8.2f' % (nm, x.min(), np.percentile(x, 10), np.median(x), np.percentile(x, 90), x.max()))
         print('per-wave shader cycles between stamps (median / p90):')
-        for i in range(1, 7):
+        last = len(names) - 1
+        for i in range(1, last + 1):
             d = cy[:, i] - cy[:, i - 1]
-            print('  %-16s -> %-16s %8.0f %8.0f' % (NAMES[i - 1], NAMES[i], np.median(d), np.percentile(d, 90)))
-        life = cy[:, 6] - cy[:, 0]
-        print('  wave life %.0f cycles median; clock ~%.2f GHz' % (np.median(life), np.median(life / np.maximum((rt[:, 6] - rt[:, 0]) * 10.0, 1.0))))
+            print('  %-16s -> %-16s %8.0f %8.0f' % (names[i - 1], names[i], np.median(d), np.percentile(d, 90)))
+        life = cy[:, last] - cy[:, 0]
+        print('  wave life %.0f cycles median; clock ~%.2f GHz' % (np.median(life), np.median(life / np.maximum((rt[:, last] - rt[:, 0]) * 10.0, 1.0))))
         _cabi.check(L.ngw_debug_set_stamps(v._h, None))
         v.close()
 
