@@ -6,18 +6,30 @@
 A "step" is ONE batched env step over the whole resident batch: the step kernel advances every env, resets the ones
 whose episode ended (done, or horizon H = 100) and writes the new observation batch.  Inputs (state + int32 actions)
 are resident in HBM when the timed region starts.  Default workload C2 = BASELINE.json configs[1]:
-NovelGridworld-Pogostick-v1, 65 536 envs per GPU, 10x10 map.  N > 1: one process per GPU (torchrun), envs sharded by
-global env index, no data-path collective (envs are independent) -> weak scaling.
+NovelGridworld-Pogostick-v1, 65 536 envs per GPU, 10x10 map.
 
-The JSON line also carries
-  roofline      algorithmic bytes per env-step (2*S*S + 12*K + 45) * envs per launch / the step
-                kernel's average duration measured with HIP events on the kernel's own stream, vs 8 TB/s HBM peak
-  cpu_baseline  the CPU oracle (oracle/ngw_oracle.c, a port - the Python reference cannot travel to the GPU box)
-                timed on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+N > 1: one process per GPU, envs sharded by global env index, no data-path collective (envs are independent) -> weak
+scaling.  Called as plain `python bench.py --gpus N` this script STARTS ITS OWN RANKS (python -m torch.distributed.run,
+rendezvous on 127.0.0.1) before it touches a GPU and relays rank 0's JSON line; launched under torchrun by someone
+else it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
+
+The JSON line carries, besides the contract's fields,
+  roofline        algorithmic bytes per env-step (2*S*S + 12*K + 45) * envs per launch / the step kernel's
+                  average launch duration, measured with a HIP event pair on the kernel's own stream, vs 8 TB/s HBM peak
+  resets_in_timed_region   the timed launches always contain auto-reset work: when K < H the episodes are started so
+                  that every env reaches the horizon in the middle of the timed region
+  gather          (N > 1) the one collective of the path: per-rank pack launch + torch.distributed.gather of the packed
+                  observation (RCCL over xGMI) + unpack launch on rank 0, timed separately from the steps
+  fused_rollout   the T-steps-per-launch mode (issue-bound, not an HBM figure), api_mode (PCIe-inclusive host loop),
+                  c1_single_env (BASELINE configs[0]: the gym.Env adapter), staggered_resets
+  cpu_baseline    the CPU oracle (oracle/ngw_oracle.c, a port - the Python reference cannot travel to the GPU box)
+                  timed on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,20 +53,26 @@ def algorithmic_bytes(S, K):
     return 2 * S * S + 12 * K + 45
 
 
-def cpu_baseline(spec, budget_s=12.0):
-    """Oracle timed on the host cores: same workload shape (uniform actions, autoreset, H = 100), bounded sample."""
-    from oracle import ngw_oracle as orc
+def cpu_share():
+    """Host threads this process may really use: affinity, capped by the cgroup CPU quota (more only oversubscribes)."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
-    try:                                                    # the box's CPU SHARE (cgroup quota), not the host's thread count:
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]     # more threads than that only oversubscribe
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
         if quota != 'max':
             cores = max(1, min(cores, -(-int(quota) // int(period))))
     except (OSError, ValueError):
         pass
+    return cores
+
+
+def cpu_baseline(spec, budget_s=12.0):
+    """Oracle timed on the host cores: same workload shape (uniform actions, autoreset, H = 100), bounded sample."""
+    from oracle import ngw_oracle as orc
+    cores = cpu_share()
     out = {}
     for label, threads in (('1core', 1), ('allcores', cores)):
         used = orc.set_threads(threads)
@@ -73,6 +91,48 @@ def cpu_baseline(spec, budget_s=12.0):
     return out
 
 
+def c1_single_env(budget_s=2.0):
+    """BASELINE configs[0]: the gym.Env adapter (N = 1) in the shape of the reference's tests/random_action.py:51-64 loop
+    (reset every 10 steps with map_size in [10, 20)), without render / print, plus a steady-state variant (reset every 100)."""
+    import numpy as np
+    import gym_novel_gridworlds_amd as G
+    out = {}
+    for label, every, resize in (('random_action_loop', 10, True), ('steady_state', 100, False)):
+        env = G.make(POGO)
+        env.reset()
+        rs = np.random.RandomState(0)
+        A = env.action_space.n
+        for _ in range(30):
+            env.step(int(rs.randint(A)))
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s / 2:
+            for i in range(50):
+                env.step(int(rs.randint(A)))
+                n += 1
+                if (i + 1) % every == 0:
+                    if resize:
+                        env.map_size = int(rs.randint(10, 20))
+                    env.reset()
+        dt = time.perf_counter() - t0
+        out[label] = {'value': round(n / dt, 1), 'unit': 'env-steps/s', 'us_per_step': round(dt / n * 1e6, 2), 'steps': n}
+        env.close()
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as CHILD processes (this process has not touched the
+    GPU and never will), relay their output, exit with their code."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL / device-tensor sharing across processes
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -85,21 +145,23 @@ def main():
                     help='step mode: replay the K step launches from one hipGraph (default) or launch them one by one')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stagger', action='store_true', help='skip the staggered-episode-ends side measurement')
+    ap.add_argument('--no-side', action='store_true', help='skip every side measurement (fused rollout, API mode, C1, stagger): tuning runs')
+    ap.add_argument('--reset-prefetch', default='auto', help="prepared next episodes: 'auto' (the library default), 0 = off, N = refill cadence")
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo + --single-device: rehearse the N > 1 code path on a one-GPU box (every rank on cuda:0)')
     ap.add_argument('--single-device', action='store_true')
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        self_launch(args)                                   # does not return
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -110,23 +172,37 @@ def main():
         else:
             dist.init_process_group('gloo')
 
-    from gym_novel_gridworlds_amd import VecNovelGridworld, apply_novelty, make_spec
+    from gym_novel_gridworlds_amd import apply_novelty, make_spec
+    from gym_novel_gridworlds_amd.dist import ShardedVecNovelGridworld
     env_id, S, nov, n_default, desc = WORKLOADS[args.workload]
     n = args.envs or n_default
     spec = make_spec(env_id, S)
     if nov:
         apply_novelty(spec, *nov)
     K, A = len(spec.items_id), len(spec.actions_id)
-    # headline: every env hits the horizon in the same step, where preparing next episodes ahead buys nothing (the refill
-    # launch costs what the inline resets cost); the staggered side measurement below switches it on
-    v = VecNovelGridworld(spec=spec, num_envs=n, device=local_rank, seed=0, autoreset=True, horizon=HORIZON,
-                          env_index_base=rank * n, reset_prefetch=0)
-    v.reset()
+    prefetch = args.reset_prefetch if args.reset_prefetch == 'auto' else int(args.reset_prefetch)
+    sv = ShardedVecNovelGridworld(spec=spec, global_num_envs=n * world, seed=0, autoreset=True, horizon=HORIZON,
+                                  device=local_rank, reset_prefetch=prefetch)
+    v = sv.local                                          # this rank's envs [rank * n, (rank + 1) * n)
     steps, warmup = args.steps, args.warmup
 
+    def start_episodes():
+        """reset(), then start every episode so that the timed region holds auto-reset work whatever K is: with K < H the
+        horizon falls in the middle of the timed launches (synchronized over the batch: BASELINE's loop resets all envs together)."""
+        v.reset()
+        hit = warmup + max(1, steps // 2)                  # 1-based batched step at which step_count reaches H
+        s0 = (HORIZON - hit) % HORIZON if steps < HORIZON else 0
+        if s0:
+            v.set_state(0, step_count=np.full(n, s0, np.int32))
+
+    def episode0():
+        return int(v.get_state(0, 1)['episode'][0])
+
+    start_episodes()
     GRAPH_MAX = 2048                      # kernel nodes per graph; longer runs replay it (its action rows repeat)
     use_graph = args.mode == 'step' and args.launch == 'graph' and steps >= 2
-    if args.mode == 'step':
+    ptrs = []
+    if args.mode == 'step' or not args.no_side:
         # i.i.d. uniform int32 actions over len(actions_id), seed 1234 (+rank), resident in HBM before the timed region
         g = torch.Generator(device='cuda')
         g.manual_seed(ACTION_SEED + rank)
@@ -160,11 +236,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def reduce_max(vals):
+        if world == 1:
+            return vals
+        t = torch.tensor(vals, dtype=torch.float64, device='cuda' if args.dist_backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.tolist()]
+
     if args.mode == 'rollout':
         if warmup > 0:
             v.rollout(warmup, ACTION_SEED, 0)
     else:
         run_eager(warmup, -1)
+    fence()
+    ep_before = episode0()
     fence()
     v.timing_begin()                      # HIP event pair on the kernel's own stream, around the timed launches
     t0 = time.perf_counter()
@@ -173,10 +258,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     assert v.error_flags() == 0
-    if world > 1:
-        t = torch.tensor([dt, dev_ms], dtype=torch.float64, device='cuda' if args.dist_backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dev_ms = float(t[0].item()), float(t[1].item())
+    resets_timed = episode0() - ep_before
+    dt, dev_ms = reduce_max([dt, dev_ms])
 
     # roofline: algorithmic bytes per launch / average launch duration (device time of the timed region / launches)
     launches = 1 if args.mode == 'rollout' else steps
@@ -184,26 +267,39 @@ def main():
     launch_ms = dev_ms / launches
     B = algorithmic_bytes(S, K)
     achieved = B * n * steps_per_launch / (launch_ms * 1e-3) / 1e9
-    roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel': 'ngw_kernel',
-                'kernel_ms_avg': round(launch_ms, 6), 'launches_timed': launches,
-                'algorithmic_bytes_per_env_step': B, 'env_steps_per_launch': n * steps_per_launch,
-                'timing': 'HIP event pair on the kernel stream around the timed launches (includes inter-launch gaps)'}
     pmc_file = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     pmc = json.load(open(pmc_file)) if os.path.exists(pmc_file) else {}
 
-    def add_traffic(rf, mode, env_steps_per_launch):
-        """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process)."""
+    def traffic_of(mode, env_steps_per_launch):
+        """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process): a
+        constant of the kernel, measured on this configuration (profiles/), not re-measured in this run."""
         rec = pmc.get('%s_%s' % (args.workload, mode))
-        if rec and n == 65536 or (rec and args.workload == 'C4' and n == 32768):
-            rf['traffic'] = round(rec['hbm_bytes_per_env_step'] * env_steps_per_launch)
-            rf['traffic_source'] = rec['source']
+        if rec and n == n_default:
+            return round(rec['hbm_bytes_per_env_step'] * env_steps_per_launch), rec['source']
+        return None, None
 
-    add_traffic(roofline, args.mode, n * steps_per_launch)
+    if args.mode == 'step':
+        roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel': 'ngw_step_lean',
+                    'kernel_ms_avg': round(launch_ms, 6), 'launches_timed': launches,
+                    'algorithmic_bytes_per_env_step': B, 'env_steps_per_launch': n * steps_per_launch,
+                    'timing': 'HIP event pair on the kernel stream around the timed launches (includes inter-launch gaps and the reset launches)'}
+        tr, src = traffic_of('step', n)
+        if tr:
+            roofline['traffic'], roofline['traffic_source'] = tr, src
+            roofline['frac_of_peak_on_measured_traffic'] = round(tr / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    else:
+        # T steps per launch keep the state on chip: HBM sees a few bytes per env-step, the kernel is bound by instruction issue
+        roofline = {'bound': 'issue', 'achieved': None, 'peak': None, 'unit': None, 'frac': None, 'traffic': None, 'kernel': 'ngw_kernel<., ROLLOUT>',
+                    'kernel_ms': round(dev_ms, 4), 'note': 'fused rollout: state stays in LDS, no HBM roofline applies (see profiles/)'}
+        tr, src = traffic_of('rollout', n * steps)
+        if tr:
+            roofline['traffic'], roofline['traffic_source'] = tr, src
 
+    side = world == 1 and not args.no_side
     # the other mode of the same workload, reported beside the headline (fused T-step rollout: SURVEY.md §8(d))
     fused = None
-    if args.mode == 'step' and world == 1:
+    if args.mode == 'step' and side:
         if warmup > 0:
             v.rollout(warmup, ACTION_SEED, 10 ** 6)
         fence()
@@ -213,17 +309,16 @@ def main():
         f_ms = v.timing_end()
         fence()
         f_dt = time.perf_counter() - t1
-        f_ach = B * n * steps / (f_ms * 1e-3) / 1e9
-        obs_bytes = S * S + 4 * K + 12 + 9            # what the fused kernel must write per env-step (state stays on chip)
-        fused = {'value': round(n * steps / f_dt, 1), 'unit': 'env-steps/s', 'ms_per_step': round(f_dt / steps * 1e3, 6),
-                 'what': 'ngw_rollout: all %d steps in ONE launch, uniform actions generated in-kernel, state kept in LDS, '
-                         'observation batch written to HBM every step' % steps,
-                 'roofline': {'bound': 'hbm', 'achieved': round(f_ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                              'frac': round(f_ach / HBM_PEAK_GBS, 4), 'kernel_ms': round(f_ms, 4),
-                              'algorithmic_bytes_per_env_step': B, 'min_hbm_bytes_per_env_step': obs_bytes,
-                              'frac_of_peak_on_min_bytes': round(obs_bytes * n * steps / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                              'traffic': None}}
-        add_traffic(fused['roofline'], 'rollout', n * steps)
+        fused = {'value': round(n * steps / f_dt, 1), 'unit': 'env-steps/s', 'ms_per_step': round(f_dt / steps * 1e3, 6), 'kernel_ms': round(f_ms, 4),
+                 'bound': 'issue',
+                 'what': 'ngw_rollout: all %d steps in ONE launch, uniform actions generated in-kernel, state kept in LDS, only the bytes '
+                         'a step changes are written through to the observation buffers (instruction-issue bound; not an HBM figure)' % steps}
+        tr, src = traffic_of('rollout', n * steps)
+        if tr:
+            fused['hbm_traffic_bytes'], fused['traffic_source'] = tr, src
+        sq = pmc.get('%s_rollout_sq' % args.workload)
+        if sq:
+            fused['issue'] = sq
         # the same fused launch taking the caller's action rows from HBM (ngw_rollout_actions) instead of the in-kernel policy
         rows_a = min(steps, len(ptrs) - warmup)
         if rows_a >= 2:
@@ -240,17 +335,20 @@ def main():
 
     # side measurement: the SAME workload with episode ends spread over the batch (step_count offset e * 7919 % H: about
     # n / H envs reset in every batched step, a few per wavefront) - the regime of a training loop; inline placement
-    # loops vs prepared next episodes (ngw_set_reset_prefetch).  Not the headline: BASELINE's loop resets all envs together.
+    # loops vs prepared next episodes (ngw_set_reset_prefetch, the library's default for autoreset).
     stag = None
-    if args.mode == 'step' and world == 1 and use_graph and not args.no_stagger:
-        import numpy as np
+    if args.mode == 'step' and side and use_graph and not args.no_stagger:
+        stag_acts = None
         stag = {'what': 'episode ends staggered over the batch (~%d of %d envs reset per batched step), hipGraph replay' % (n // HORIZON, n)}
         for key, every in (('inline_resets', 0), ('prepared_next_episodes_every_32', 32)):
             v.set_reset_prefetch(every)
             v.reset()
             v.set_state(0, step_count=(np.arange(n) * 7919 % HORIZON).astype(np.int32))
-            gs = max(2, min(64, len(ptrs) - warmup))          # the action rows resident in HBM bound the captured graph
-            v.graph_build(ptrs[warmup], n, gs)
+            gs = 64                                           # two refill periods per replay
+            if stag_acts is None:
+                stag_acts = torch.randint(0, A, (gs, n), dtype=torch.int32, device='cuda', generator=g)
+                torch.cuda.synchronize()
+            v.graph_build(stag_acts.data_ptr(), n, gs)
             v.graph_launch(max(1, 256 // gs))
             fence()
             v.timing_begin()
@@ -258,8 +356,43 @@ def main():
             s_ms = v.timing_end() / (max(1, 512 // gs) * gs)
             fence()
             stag[key] = {'ms_per_step': round(s_ms, 6), 'value': round(n / (s_ms * 1e-3), 1), 'unit': 'env-steps/s'}
-        v.set_reset_prefetch(0)
+        stag['default'] = 'prepared_next_episodes_every_32 (VecNovelGridworld / ngw_set_autoreset switch it on)'
         assert v.error_flags() == 0
+
+    # PCIe-inclusive host loop (the drop-in API mode of SURVEY.md §8(d)): never `value`
+    api = None
+    if side:
+        rs = np.random.RandomState(ACTION_SEED)
+        ha = rs.randint(0, A, size=(8, n)).astype(np.int32)
+        for i in range(3):
+            v.step(ha[i % 8])
+        ka = 20
+        t2 = time.perf_counter()
+        for i in range(ka):
+            v.step(ha[i % 8])
+        a_dt = time.perf_counter() - t2
+        api = {'value': round(n * ka / a_dt, 1), 'unit': 'env-steps/s', 'ms_per_step': round(a_dt / ka * 1e3, 4), 'steps': ka,
+               'what': 'VecNovelGridworld.step(): int32 actions from host memory, the Dict observation (%d B per env) + reward / done / info '
+                       'back to page-locked host arrays every step (ngw_step_host: one call, one synchronisation); PCIe-inclusive' % (S * S + 12 + 4 * K)}
+
+    # the one collective of the path, timed on its own: pack launch per rank + gather to rank 0 + unpack launch there
+    gather = None
+    if world > 1 or not args.no_side:
+        offs = sv.payload_layout()
+        sv.gather_observation(dst=0)                          # allocates the payload / receive / global buffers
+        fence()
+        kg = 20
+        t3 = time.perf_counter()
+        for _ in range(kg):
+            sv.gather_observation(dst=0)
+        fence()
+        g_dt = reduce_max([(time.perf_counter() - t3) / kg])[0]
+        gather = {'ms': round(g_dt * 1e3, 4), 'payload_bytes_per_rank': offs[7], 'bytes_per_env': round(offs[7] / n, 1),
+                  'GBps_into_root': round(offs[7] * world / g_dt / 1e9, 2), 'ranks': world, 'backend': args.dist_backend if world > 1 else 'none (one rank: pack + unpack launches only)',
+                  'what': 'ngw_pack_obs (one launch: 7 SoA arrays -> one payload) on every rank, torch.distributed.gather to rank 0, '
+                          'ngw_unpack_obs (one launch) into global arrays; outside the step path'}
+
+    c1 = c1_single_env() if side and rank == 0 else None
 
     if rank == 0:
         total = n * world * steps
@@ -268,16 +401,24 @@ def main():
             'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 6), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8/int32', 'data': 'synthetic',
             'config': {'workload': desc, 'name': args.workload, 'envs_per_gpu': n, 'global_envs': n * world,
-                       'map_size': S, 'n_items': K, 'n_actions': A, 'horizon': HORIZON, 'autoreset': 'same-step', 'reset_prefetch': 0,
+                       'map_size': S, 'n_items': K, 'n_actions': A, 'horizon': HORIZON, 'autoreset': 'same-step',
+                       'reset_prefetch': v.reset_prefetch,
                        'mode': ('one launch per batched step (%s), actions in HBM' % ('hipGraph replay' if use_graph else 'eager')) if args.mode == 'step'
                                else 'fused rollout: all steps in one launch, actions generated in-kernel',
-                       'parallelism': 'envs sharded x%d, no collective' % world},
+                       'parallelism': 'envs sharded x%d, no collective in the step path' % world},
+            'resets_in_timed_region': resets_timed,
             'roofline': roofline,
         }
+        if gather:
+            line['gather'] = gather
         if fused:
             line['fused_rollout'] = fused
         if stag:
             line['staggered_resets'] = stag
+        if api:
+            line['api_mode'] = api
+        if c1:
+            line['c1_single_env'] = c1
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(spec)
             line['cpu_baseline'] = {'value': round(cb['allcores']['value'], 1), 'unit': 'env-steps/s',
@@ -286,6 +427,7 @@ def main():
         print(json.dumps(line), flush=True)
     v.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -21,7 +21,8 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_out_device_ptrs', 'ngw_sync', 'ngw_error_flags', 'ngw_timing_begin', 'ngw_timing_end',
            'ngw_graph_build', 'ngw_graph_launch', 'ngw_lidar_configure', 'ngw_lidar', 'ngw_lidar_fuse',
            'ngw_get_lidar', 'ngw_lidar_device_ptr', 'ngw_host_alloc', 'ngw_host_free', 'ngw_agent_view',
-           'ngw_get_agent_view', 'ngw_agent_view_device_ptr', 'ngw_set_reset_prefetch', 'ngw_step_host', 'ngw_lidar_set_output', 'ngw_rollout_actions']
+           'ngw_get_agent_view', 'ngw_agent_view_device_ptr', 'ngw_set_reset_prefetch', 'ngw_step_host', 'ngw_lidar_set_output', 'ngw_rollout_actions',
+           'ngw_pack_layout', 'ngw_pack_obs', 'ngw_unpack_obs']
 
 _lib = None
 
@@ -108,6 +109,10 @@ def lib():
     L.ngw_agent_view.argtypes = [vp, C.c_int]
     L.ngw_get_agent_view.argtypes = [vp, vp]
     L.ngw_agent_view_device_ptr.argtypes = [vp, C.POINTER(vp)]
+    if hasattr(L, 'ngw_pack_obs'):
+        L.ngw_pack_layout.argtypes = [vp, C.POINTER(u64)]
+        L.ngw_pack_obs.argtypes = [vp, vp]
+        L.ngw_unpack_obs.argtypes = [vp, vp, i32] + [vp] * 7
     L.ngw_host_alloc.argtypes = [u64]
     L.ngw_host_alloc.restype = vp
     L.ngw_host_free.argtypes = [vp]

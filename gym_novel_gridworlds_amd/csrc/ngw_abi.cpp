@@ -230,6 +230,20 @@ int upload_reset_u(ngw_handle* h) {
     return NGW_OK;
 }
 
+// Prepared next episodes: one launch re-prepares the shadow rows that resets have consumed since the last one.
+int launch_refill(ngw_handle* h) {
+    h->since_refill = 0;
+    NgwLaunch rf = h->proto;
+    rf.b = NgwBufs{};
+    rf.b.map = h->nx.map; rf.b.loc = h->nx.loc; rf.b.facing = h->nx.facing; rf.b.inv = h->nx.inv; rf.b.episode = h->nx.episode;
+    rf.b.flags = h->b.flags; rf.b.perm = h->b.perm;
+    rf.mode = NGW_MODE_REFILL; rf.n_steps = 1;
+    rf.actions = reinterpret_cast<const int32_t*>(h->b.episode);
+    rf.reset_mask = nullptr; rf.autoreset = 0; rf.horizon = 0; rf.action_seed = 0; rf.t0 = 0;
+    HIP_TRY(ngw_launch(h->dspec, &rf, h->map_mode, 0, (unsigned)(h->n_pad / NGW_EPB), h->lds_bytes, h->stream));
+    return NGW_OK;
+}
+
 int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, const uint8_t* mask_dev, uint64_t action_seed, int64_t t0) {
     NgwLaunch a = h->proto;
     a.b = h->b;
@@ -247,17 +261,7 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
         // Prepared next episodes: every `prefetch_every` batched steps (and right after an explicit reset) one more launch
         // refills the shadow rows that resets have consumed since.  Same stream, so it is ordered between the steps.
         h->since_refill += mode == NGW_MODE_RESET ? h->prefetch_every : n_steps;
-        if (h->since_refill >= h->prefetch_every) {
-            h->since_refill = 0;
-            NgwLaunch rf = h->proto;
-            rf.b = NgwBufs{};
-            rf.b.map = h->nx.map; rf.b.loc = h->nx.loc; rf.b.facing = h->nx.facing; rf.b.inv = h->nx.inv; rf.b.episode = h->nx.episode;
-            rf.b.flags = h->b.flags; rf.b.perm = h->b.perm;
-            rf.mode = NGW_MODE_REFILL; rf.n_steps = 1;
-            rf.actions = reinterpret_cast<const int32_t*>(h->b.episode);
-            rf.reset_mask = nullptr; rf.autoreset = 0; rf.horizon = 0; rf.action_seed = 0; rf.t0 = 0;
-            HIP_TRY(ngw_launch(h->dspec, &rf, h->map_mode, 0, grid, h->lds_bytes, h->stream));
-        }
+        if (h->since_refill >= h->prefetch_every) return launch_refill(h);
     }
     return NGW_OK;
 }
@@ -668,11 +672,10 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
         if (int rc = launch(h, NGW_MODE_STEP, 1, reinterpret_cast<const int32_t*>(h->zc_dev), nullptr, 0, 0)) return rc;
         NgwPack p = {};
         size_t off = (n * sizeof(int32_t) + 255) & ~(size_t)255, offs[NOUT] = {0};
-        p.dst = h->zc_dev;
         for (int r = 0; r < NOUT; r++)
             if (outs[r].host) {
                 p.src[p.n_regions] = static_cast<const uint8_t*>(outs[r].dev);
-                p.off[p.n_regions] = (uint32_t)off; p.nbytes[p.n_regions] = (uint32_t)outs[r].bytes; p.n_regions++;
+                p.dst[p.n_regions] = h->zc_dev + off; p.nbytes[p.n_regions] = outs[r].bytes; p.n_regions++;
                 offs[r] = off; off += (outs[r].bytes + 255) & ~(size_t)255;
             }
         if (p.n_regions) HIP_TRY(ngw_pack_launch(&p, h->stream));
@@ -702,6 +705,61 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
             if (msg_code) msg_code[i] = (uint16_t)NGW_INFO_MSG(w);
             if (msg_arg) msg_arg[i] = (uint16_t)NGW_INFO_ARG(w);
         }
+    return NGW_OK;
+}
+
+/* Payload of the multi-GPU observation gather: the seven SoA arrays back to back, each section padded to 16 bytes. */
+namespace {
+struct PackSection { const void* dev; uint64_t bytes; };
+int pack_sections(const ngw_handle* h, PackSection sec[7], uint64_t offs[8]) {
+    const uint64_t n = (uint64_t)h->n, S2 = (uint64_t)h->proto.S2, K = (uint64_t)h->proto.K;
+    const PackSection s[7] = {{h->b.map, n * S2}, {h->b.loc, n * 8}, {h->b.facing, n * 4}, {h->b.inv, n * K * 4},
+                              {h->b.reward, n * 4}, {h->b.done, n}, {h->b.info, n * 4}};
+    uint64_t off = 0;
+    for (int i = 0; i < 7; i++) { sec[i] = s[i]; offs[i] = off; off += (s[i].bytes + 15) & ~(uint64_t)15; }
+    offs[7] = off;
+    return NGW_OK;
+}
+}  // namespace
+
+int ngw_pack_layout(ngw_handle* h, uint64_t* offsets8) {
+    if (!h || !offsets8) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    PackSection sec[7];
+    return pack_sections(h, sec, offsets8);
+}
+
+int ngw_pack_obs(ngw_handle* h, void* payload_dev) {
+    if (!h || !payload_dev) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    if ((uintptr_t)payload_dev & 15u) return fail(NGW_E_INVALID_ARG, "payload must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(h->device));
+    PackSection sec[7]; uint64_t offs[8];
+    pack_sections(h, sec, offs);
+    NgwPack p = {};
+    for (int i = 0; i < 7; i++) {
+        p.src[i] = static_cast<const uint8_t*>(sec[i].dev); p.dst[i] = static_cast<uint8_t*>(payload_dev) + offs[i]; p.nbytes[i] = sec[i].bytes;
+    }
+    p.n_regions = 7;
+    HIP_TRY(ngw_pack_launch(&p, h->stream));
+    return NGW_OK;
+}
+
+int ngw_unpack_obs(ngw_handle* h, const void* payloads_dev, int32_t world, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv,
+                   int32_t* reward, uint8_t* done, uint32_t* info) {
+    if (!h || !payloads_dev) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    if (world < 1 || world * 7 > NGW_PACK_MAX) return fail(NGW_E_INVALID_ARG, "world %d outside [1, %d]", world, NGW_PACK_MAX / 7);
+    HIP_TRY(hipSetDevice(h->device));
+    PackSection sec[7]; uint64_t offs[8];
+    pack_sections(h, sec, offs);
+    uint8_t* const dsts[7] = {reinterpret_cast<uint8_t*>(map), reinterpret_cast<uint8_t*>(loc), reinterpret_cast<uint8_t*>(facing),
+                              reinterpret_cast<uint8_t*>(inv), reinterpret_cast<uint8_t*>(reward), done, reinterpret_cast<uint8_t*>(info)};
+    NgwPack p = {};
+    for (int r = 0; r < world; r++)
+        for (int i = 0; i < 7; i++) {
+            if (!dsts[i]) continue;
+            p.src[p.n_regions] = static_cast<const uint8_t*>(payloads_dev) + (uint64_t)r * offs[7] + offs[i];
+            p.dst[p.n_regions] = dsts[i] + (uint64_t)r * sec[i].bytes; p.nbytes[p.n_regions] = sec[i].bytes; p.n_regions++;
+        }
+    HIP_TRY(ngw_pack_launch(&p, h->stream));
     return NGW_OK;
 }
 
@@ -971,6 +1029,12 @@ int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stri
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     int rc = NGW_OK;
     for (int i = 0; i < n_steps && !rc; i++) rc = launch(h, NGW_MODE_STEP, 1, actions_dev + (int64_t)i * step_stride, nullptr, 0, 0);
+    // every replay must leave the refill cadence where it found it: a graph shorter than (or not a multiple of) the cadence
+    // ends with one more refill, otherwise a replayed graph would never re-prepare the episodes its steps consume
+    if (!rc && h->prefetch_every > 0 && h->since_refill > 0) {
+        h->since_refill = h->prefetch_every;
+        rc = launch_refill(h);
+    }
     hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
     if (rc) { drop_graph(h); return rc; }
     if (e != hipSuccess) { drop_graph(h); return fail(NGW_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e)); }

@@ -173,13 +173,15 @@ struct NgwLidarDev {
 #ifdef __cplusplus
 extern "C"
 #endif
-/* Small-batch host step: copy up to 12 device regions into ONE page-locked host buffer the GPU can address (region r:
- * nbytes[r] bytes from src[r] to dst + off[r], off[r] 16-byte aligned); replaces seven hipMemcpyAsync calls whose fixed
- * cost dominates at small batch sizes. */
+/* Region copies in ONE launch (the "pack" kernel): region r = nbytes[r] bytes from src[r] to dst[r], coalesced 16-byte pieces
+ * when both ends are 16-byte aligned.  Three users: the small-batch host step (device regions -> one page-locked host buffer
+ * the GPU addresses directly, replacing seven hipMemcpyAsync calls), ngw_pack_obs (the SoA observation / output arrays ->
+ * one contiguous payload for the multi-GPU gather) and ngw_unpack_obs (the gathered payloads -> global arrays on the root). */
+#define NGW_PACK_MAX 64
 struct NgwPack {
-    const uint8_t* src[12];
-    uint8_t* dst;
-    uint32_t off[12], nbytes[12];
+    const uint8_t* src[NGW_PACK_MAX];
+    uint8_t* dst[NGW_PACK_MAX];
+    uint64_t nbytes[NGW_PACK_MAX];
     int32_t n_regions;
 };
 #ifdef __cplusplus

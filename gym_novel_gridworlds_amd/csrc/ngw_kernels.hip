@@ -1112,15 +1112,21 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const NgwLidarDev* _
                 a.l_i16 != 0, tid);   // out is padded to n_pad rows
 }
 
-// Host-step pack: region blockIdx.y, 16 bytes per thread (a region's tail bytes go one by one); the destination is host memory mapped into the GPU's address space, so the stores travel over PCIe.
+// Region copies (NgwPack): region blockIdx.y, grid-stride over 16-byte pieces; tails and unaligned regions go by bytes.
+// The destination may be host memory mapped into the GPU's address space (the stores then travel over PCIe).
 __global__ __launch_bounds__(256) void ngw_pack_kernel(const NgwPack p) {
     const int r = blockIdx.y;
-    const uint32_t nb = p.nbytes[r], i = (blockIdx.x * 256u + threadIdx.x) * 16u;     // sources and offsets are 16-byte aligned
-    if (i >= nb) return;
-    const uint8_t* s = p.src[r] + i;
-    uint8_t* d = p.dst + p.off[r] + i;
-    if (i + 16u <= nb) *reinterpret_cast<u32x4*>(d) = *reinterpret_cast<const u32x4*>(s);
-    else for (uint32_t j = 0; i + j < nb; j++) d[j] = s[j];
+    const uint64_t nb = p.nbytes[r];
+    const uint8_t* s = p.src[r];
+    uint8_t* d = p.dst[r];
+    const uint64_t stride = (uint64_t)gridDim.x * 256u, t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if ((((uintptr_t)s | (uintptr_t)d) & 15u) == 0) {
+        const uint64_t n16 = nb >> 4;
+        for (uint64_t i = t; i < n16; i += stride) reinterpret_cast<u32x4*>(d)[i] = reinterpret_cast<const u32x4*>(s)[i];
+        for (uint64_t i = (n16 << 4) + t; i < nb; i += stride) d[i] = s[i];
+    } else {
+        for (uint64_t i = t; i < nb; i += stride) d[i] = s[i];
+    }
 }
 
 // AgentMap (reference observation_wrappers.py:104-121): the (2V+1) x (2V+1) window of the map centred on the agent, 0 outside
@@ -1151,9 +1157,13 @@ __global__ __launch_bounds__(256) void ngw_agent_view_kernel(const int8_t* __res
 }  // namespace
 
 extern "C" hipError_t ngw_pack_launch(const NgwPack* p, hipStream_t stream) {
-    uint32_t most = 0;
+    if (p->n_regions < 1) return hipSuccess;
+    uint64_t most = 0;
     for (int r = 0; r < p->n_regions; r++) most = p->nbytes[r] > most ? p->nbytes[r] : most;
-    hipLaunchKernelGGL(ngw_pack_kernel, dim3((most / 16u + 256u) / 256u, (unsigned)p->n_regions), dim3(256), 0, stream, *p);
+    uint64_t blocks = (most / 16u + 255u) / 256u;                          // one 16-byte piece per thread, up to 2048 blocks per region
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ngw_pack_kernel, dim3((unsigned)blocks, (unsigned)p->n_regions), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
 

@@ -40,6 +40,7 @@ class ShardedVecNovelGridworld:
             self.local = VecNovelGridworld(env_id=env_id, map_size=map_size, novelty=novelty, spec=spec, device=dev,
                                            reset_prefetch=reset_prefetch, **kw)
         self.spec = self.local.spec
+        self._payload = self._recv = self._global = None        # gather buffers, allocated on first use
 
     # step / reset are purely local
     def reset(self, mask=None):
@@ -61,41 +62,86 @@ class ShardedVecNovelGridworld:
         return self.local.close()
 
     # ------------------------------------------------------------------ the one collective
-    def packed_observation(self):
-        """[n_local, S*S + 12 + 4K + 9] uint8: map | agent_location | agent_facing_id | inventory | reward | done | info."""
-        import torch
-        o, out = self.local.device_observation(), self.local.device_outputs()
-        n = self.num_envs
-        parts = [o['map'].reshape(n, -1).view(torch.uint8), o['agent_location'].reshape(n, 2).view(torch.uint8),
-                 o['agent_facing_id'].reshape(n, 1).view(torch.uint8), o['inventory_items_quantity'].view(torch.uint8),
-                 out['reward'].reshape(n, 1).view(torch.uint8), out['done'].reshape(n, 1).view(torch.uint8),
-                 out['info'].reshape(n, 1).view(torch.uint8)]
-        return torch.cat([p.reshape(n, -1) for p in parts], dim=1).contiguous()
+    FIELDS = ('map', 'agent_location', 'agent_facing_id', 'inventory_items_quantity', 'reward', 'done', 'info')
 
-    def unpack(self, packed):
+    def payload_layout(self):
+        """Byte offsets of the seven sections of one rank's payload + its size (mirror of ngw_pack_layout, include/ngw.h):
+        the SoA arrays back to back, each padded to 16 bytes - every section is a straight coalesced copy."""
+        if hasattr(self.local, 'pack_layout'):
+            return self.local.pack_layout()
+        n, S, K = self.num_envs, self.spec.map_size, len(self.spec.items_id)
+        offs = [0]
+        for w in (S * S, 8, 4, 4 * K, 4, 1, 4):
+            offs.append(offs[-1] + ((n * w + 15) & ~15))
+        return offs
+
+    def _field_shapes(self, n):
         import torch
         S, K = self.spec.map_size, len(self.spec.items_id)
-        n = packed.shape[0]
-        ofs = [0]
-        for w in (S * S, 8, 4, 4 * K, 4, 1, 4):
-            ofs.append(ofs[-1] + w)
-        cut = [packed[:, ofs[i]:ofs[i + 1]].contiguous() for i in range(7)]
-        return {'map': cut[0].view(torch.int8).reshape(n, S, S), 'agent_location': cut[1].view(torch.int32).reshape(n, 2),
-                'agent_facing_id': cut[2].view(torch.int32).reshape(n),
-                'inventory_items_quantity': cut[3].view(torch.int32).reshape(n, K),
-                'reward': cut[4].view(torch.int32).reshape(n), 'done': cut[5].reshape(n).bool(),
-                'info': cut[6].view(torch.int32).reshape(n)}
+        return [((n, S, S), torch.int8), ((n, 2), torch.int32), ((n,), torch.int32), ((n, K), torch.int32),
+                ((n,), torch.int32), ((n,), torch.uint8), ((n,), torch.int32)]
+
+    def packed_observation(self):
+        """This rank's payload: uint8 [payload_bytes] on the env's device, filled by ONE kernel launch (ngw_pack_obs) into a
+        buffer allocated once.  (The CPU stand-in of the tests builds the same bytes on the host.)"""
+        import torch
+        offs = self.payload_layout()
+        if hasattr(self.local, 'pack_obs'):
+            if self._payload is None:
+                self._payload = torch.empty(offs[7], dtype=torch.uint8, device='cuda:%d' % self.local.device)
+            self.local.pack_obs(self._payload.data_ptr())
+            self.local.sync()                               # the collective runs on torch's stream, the pack on the handle's
+            return self._payload
+        o, out = self.local.device_observation(), self.local.device_outputs()
+        buf = torch.zeros(offs[7], dtype=torch.uint8)
+        parts = [o['map'], o['agent_location'], o['agent_facing_id'], o['inventory_items_quantity'], out['reward'], out['done'], out['info']]
+        for off, t in zip(offs, parts):
+            b = t.contiguous().reshape(-1).view(torch.uint8)
+            buf[off:off + b.numel()] = b
+        return buf
+
+    def unpack(self, payloads, world=None):
+        """`world` payloads back to back (uint8 [world * payload_bytes]) -> dict of global arrays, rank r's envs at
+        [r * n, (r + 1) * n).  One kernel launch (ngw_unpack_obs) into tensors allocated once; the done flags come back as bool."""
+        import torch
+        world = self.world if world is None else world
+        n, offs = self.num_envs, self.payload_layout()
+        shapes = self._field_shapes(n * world)
+        if hasattr(self.local, 'unpack_obs'):
+            if self._global is None:
+                self._global = [torch.empty(sh, dtype=dt, device=payloads.device) for sh, dt in shapes]
+            self.local.unpack_obs(payloads.data_ptr(), world, [t.data_ptr() for t in self._global])
+            self.local.sync()
+            out = dict(zip(self.FIELDS, self._global))
+        else:
+            pl = payloads.reshape(world, offs[7])
+            out = {}
+            for name, off, (sh, dt), (sh1, _) in zip(self.FIELDS, offs, shapes, self._field_shapes(n)):
+                nbytes = int(torch.tensor([], dtype=dt).element_size())
+                for d in sh1:
+                    nbytes *= d
+                out[name] = pl[:, off:off + nbytes].contiguous().view(dt).reshape(sh)
+        out = dict(out)
+        out['done'] = out['done'].bool()
+        return out
 
     def gather_observation(self, dst=0):
-        """Stack every rank's packed observation on rank `dst` (global env order).  Returns the unpacked dict of
-        [global_num_envs, ...] tensors on `dst`, None elsewhere."""
+        """Stack every rank's payload on rank `dst` (global env order): one pack launch per rank, ONE collective
+        (torch.distributed.gather: RCCL over xGMI for device tensors, gloo on host copies), one unpack launch on `dst`.
+        Returns the dict of [global_num_envs, ...] tensors on `dst`, None elsewhere."""
         import torch
-        self.local.sync()
         mine = self.packed_observation()
         if self.world == 1:
-            return self.unpack(mine)
-        bufs = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == dst else None
-        self.dist.gather(mine, bufs, dst=dst, group=self.group)
+            return self.unpack(mine, 1)
+        host_side = self.dist.get_backend(self.group) == 'gloo' and mine.is_cuda          # gloo gathers host tensors
+        send = mine.cpu() if host_side else mine
+        recv = None
+        if self.rank == dst:
+            if self._recv is None or self._recv.device != send.device:
+                self._recv = torch.empty((self.world, send.numel()), dtype=torch.uint8, device=send.device)
+            recv = [self._recv[r] for r in range(self.world)]
+        self.dist.gather(send, recv, dst=dst, group=self.group)
         if self.rank != dst:
             return None
-        return self.unpack(torch.cat(bufs, dim=0))
+        stacked = self._recv.to(mine.device) if host_side else self._recv
+        return self.unpack(stacked.reshape(-1))

@@ -231,6 +231,22 @@ class VecNovelGridworld:
                 'done': torch.as_tensor(_DevArray(p[1].value, (N,), '|u1'), device=dev),
                 'info': torch.as_tensor(_DevArray(p[2].value, (N,), '<i4'), device=dev)}
 
+    # ------------------------------------------------------------------ multi-GPU observation stack (dist.py)
+    def pack_layout(self):
+        """Byte offsets of the seven payload sections + the payload size (include/ngw.h ngw_pack_layout)."""
+        offs = (C.c_uint64 * 8)()
+        _cabi.check(_cabi.lib().ngw_pack_layout(self._h, offs))
+        return [int(x) for x in offs]
+
+    def pack_obs(self, payload_ptr):
+        """One launch: observation + step outputs -> the contiguous device payload at `payload_ptr` (16-byte aligned)."""
+        _cabi.check(_cabi.lib().ngw_pack_obs(self._h, C.c_void_p(int(payload_ptr))))
+
+    def unpack_obs(self, payloads_ptr, world, dst_ptrs):
+        """Root side: `world` payloads back to back -> the global arrays at dst_ptrs (map, loc, facing, inv, reward, done, info)."""
+        _cabi.check(_cabi.lib().ngw_unpack_obs(self._h, C.c_void_p(int(payloads_ptr)), int(world),
+                                               *[C.c_void_p(int(x)) if x else None for x in dst_ptrs]))
+
     # ------------------------------------------------------------------ LidarInFront observation (SURVEY §8(f) row 1)
     def lidar_configure(self, lidar_config=None, num_beams=8, fused=False, dtype=np.int32):
         """Enable the LidarInFront observation (reference observation_wrappers.py:10-80).  `lidar_config` fixes the lidar

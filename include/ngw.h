@@ -268,6 +268,21 @@ int ngw_timing_end(ngw_handle* h, double* elapsed_ms);
 int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps);
 int ngw_graph_launch(ngw_handle* h, int32_t reps);
 
+/* Multi-GPU observation stack (the only collective of the path, outside step()).  One process per GPU,
+ * each with its own handle; per step (or whenever the host wants the whole batch) every rank packs its observation and
+ * step outputs into ONE contiguous device payload, the ranks gather the payloads on a root (RCCL gather over xGMI through
+ * torch.distributed) and the root scatters them into global arrays.
+ *   ngw_pack_layout  byte offsets of the seven sections (map i8 [n][S*S] | agent_location i32 [n][2] | agent_facing_id i32 [n] |
+ *                    inventory i32 [n][K] | reward i32 [n] | done u8 [n] | info u32 [n]; each padded to 16 bytes) and, in
+ *                    offsets8[7], the payload size.  Equal for every rank that holds the same number of envs.
+ *   ngw_pack_obs     one kernel launch on the handle's stream: the seven SoA arrays -> payload_dev (16-byte aligned).
+ *   ngw_unpack_obs   root side: `world` payloads back to back at payloads_dev -> global arrays (rank r's envs at [r*n, (r+1)*n));
+ *                    any destination may be NULL.  One launch on the handle's stream. */
+int ngw_pack_layout(ngw_handle* h, uint64_t* offsets8);
+int ngw_pack_obs(ngw_handle* h, void* payload_dev);
+int ngw_unpack_obs(ngw_handle* h, const void* payloads_dev, int32_t world, int8_t* map, int32_t* loc, int32_t* facing,
+                   int32_t* inv, int32_t* reward, uint8_t* done, uint32_t* info);
+
 /* LidarInFront: configure once, then ngw_lidar() computes the observation of the CURRENT state of every env into an
  * int32 [N][num_beams * n_chan + n_inv] device buffer (enqueued on the handle's stream, after the steps before it). */
 int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg);

@@ -1,0 +1,100 @@
+"""The N > 1 path on real hardware, rehearsed on ONE GPU: two ranks (gloo rendezvous on 127.0.0.1, both on cuda:0), envs
+sharded by global index, HIP step kernels on each rank, the observation stack through ngw_pack_obs -> gather ->
+ngw_unpack_obs, checked against one unsharded oracle batch; and `python bench.py --gpus 2` started as the driver starts
+it (plain python: it launches its own ranks)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import ngw_testlib as T
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N, STEPS = 192, 45
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, cfg, q):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    import torch
+    import torch.distributed as dist
+    from gym_novel_gridworlds_amd.dist import ShardedVecNovelGridworld, shard_range
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        spec = T.build_spec(cfg)
+        env = ShardedVecNovelGridworld(global_num_envs=N, spec=spec, seed=3, autoreset=True, horizon=12, device=0)
+        assert (env.first, env.num_envs) == shard_range(N, world, rank)
+        env.reset()
+        rs = np.random.RandomState(0)
+        for t in range(STEPS):
+            a = rs.randint(0, len(spec.actions_id), size=N).astype(np.int32)      # same global action batch on every rank
+            env.step(a[env.first:env.first + env.num_envs])
+        got = env.gather_observation(dst=0)
+        got2 = env.gather_observation(dst=0)                                       # buffers are reused: same answer
+        if rank == 0:
+            assert all((got[k] == got2[k]).all() for k in got)
+            q.put({k: v.cpu().numpy() for k, v in got.items()})
+        else:
+            assert got is None
+        dist.barrier()
+        env.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('cfg', ['pogo10', 'axe10', 'bow20'])
+def test_two_ranks_on_one_gpu_match_one_oracle_batch(cfg):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    spec = T.build_spec(cfg)
+    ref = T.OracleVec(spec, N, seed=3, autoreset=True, horizon=12)
+    ref.reset()
+    rs = np.random.RandomState(0)
+    for t in range(STEPS):
+        ref.step(rs.randint(0, len(spec.actions_id), size=N).astype(np.int32))
+    st = ref.o.st
+    S = spec.map_size
+    assert (got['map'] == st.map.reshape(N, S, S)).all() and (got['agent_location'] == st.loc).all()
+    assert (got['agent_facing_id'] == st.facing).all() and (got['inventory_items_quantity'] == st.inv).all()
+    assert (got['reward'] == ref.o.reward).all() and (got['done'] == ref.o.done.astype(bool)).all()
+    assert (got['info'].view(np.uint32) == ref.o.info).all()
+    assert st.episode.max() >= 3
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` outside torchrun: the parent spawns the ranks before it touches a GPU; rank 0's line
+    reports both ranks, resets inside the timed region and the gather leg."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dist-backend', 'gloo', '--single-device', '--workload', 'C4',
+           '--steps', '40', '--warmup', '5', '--no-cpu-baseline', '--no-side']
+    env = dict(os.environ)
+    env.pop('RANK', None)
+    env.pop('WORLD_SIZE', None)
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['global_envs'] == 2 * 32768
+    assert line['resets_in_timed_region'] >= 1
+    assert line['gather']['ranks'] == 2 and line['gather']['ms'] > 0 and line['gather']['payload_bytes_per_rank'] >= 32768 * (152 + 9)
+    assert line['value'] > 0 and 0 < line['roofline']['frac'] < 1

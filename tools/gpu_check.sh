@@ -12,12 +12,12 @@ if [ -f gym_novel_gridworlds_amd/libngw_hip_stamps.so ]; then
 fi
 for W in $WL; do
   for L in 1 0; do
-    NGW_LEAN=$L timeout -k 10 200 python bench.py --workload $W --no-cpu-baseline --no-stagger --steps 1000 > $OUT/bench_${W}_lean$L.log 2>&1
+    NGW_LEAN=$L timeout -k 10 200 python bench.py --workload $W --no-cpu-baseline --no-side --steps 1000 > $OUT/bench_${W}_lean$L.log 2>&1
     python - <<PY
 import json
 try:
     d = json.loads([l for l in open("$OUT/bench_${W}_lean$L.log") if l.startswith("{")][-1])
-    print("$W lean=$L %.2f G  %.2f us/step  frac %.3f | fused %.1f G" % (d["value"] / 1e9, d["ms_per_step"] * 1000, d["roofline"]["frac"], d["fused_rollout"]["value"] / 1e9))
+    print("$W lean=$L %.2f G  %.2f us/step  frac %.3f resets %d" % (d["value"] / 1e9, d["ms_per_step"] * 1000, d["roofline"]["frac"], d["resets_in_timed_region"]))
 except Exception as ex:
     print("$W lean=$L FAILED", ex); print(open("$OUT/bench_${W}_lean$L.log").read()[-1500:])
 PY
