@@ -162,6 +162,32 @@ extern "C"
 #endif
 hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int feat /* 1 = fused lidar, 2 = EXT */, unsigned grid, size_t lds_bytes,
                       hipStream_t stream);
+/* Arguments of the dedicated new-episode kernel (ngw_reset.inc: explicit resets and prepared next episodes of the plain and
+ * AddItem / Crate configurations). */
+struct NgwResetFast {            // kernel arguments (by value)
+    NgwBufs main;                // the handle's state (episode counters; RESET destination)
+    NgwNx nx;                    // shadow rows (REFILL destination)
+    const uint8_t* reset_mask;   // RESET: device mask or nullptr (all)
+    const double* pctq;          // AddItem: pct / 100.0 table of the host
+    int64_t n, env_base;
+    uint64_t seed;
+    uint32_t* flags;
+    int32_t mode;                // NGW_MODE_RESET / NGW_MODE_REFILL
+    int32_t S, S2, K, CW, n_place, wall_item;
+    int32_t additem_item, additem_span;
+    int32_t n_inv_start;
+    uint32_t inv_start_items, inv_start_qtys;   // 4 bytes each
+    uint32_t magicW;             // ceil(2^32 / (S-4))
+    uint32_t magicS2;            // ceil(2^32 / S2): chunk byte offset / S2
+    uint32_t off_ring, off_masks, off_placed, off_tmpl, off_perm;    // LDS dword offsets
+    uint64_t* stamps;            // diagnostics builds (-DNGW_STAMPS), or nullptr
+};
+#ifdef __cplusplus
+extern "C"
+#endif
+hipError_t ngw_reset_fast_launch(const NgwDevSpec* dspec, const struct NgwResetFast* a, int nw, int additem, unsigned grid, size_t lds_bytes,
+                                 hipStream_t stream);
+
 /* Device-side lidar tables, built by ngw_lidar_configure from ngw_lidar_cfg: flat cell offsets dr * S + dc. */
 struct NgwLidarDev {
     int16_t off[4][NGW_LIDAR_MAX_BEAMS][NGW_LIDAR_MAX_RANGE];   /* [facing][beam][range-1], 8 KiB */

@@ -69,8 +69,10 @@ __device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t 
                                              uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a mul_hi / mul_lo pair: integer multiplies are
+        // quarter-rate, they are what a block costs
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
@@ -1036,6 +1038,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
 }
 
 #include "ngw_lean.inc"
+#include "ngw_reset.inc"
 
 // ---------------------------------------------------------------- LidarInFront observation kernel
 // observation_wrappers.py:32-80.  Same wave = 64 envs decomposition and the same coalesced map staging as the step
@@ -1246,6 +1249,21 @@ static hipError_t launch_feat(const NgwDevSpec* dspec, const NgwLaunch* a, int f
 __global__ void ngw_nop_kernel(const NgwDevSpec* dspec, const NgwLaunch a) {}
 
 }  // namespace
+
+extern "C" hipError_t ngw_reset_fast_launch(const NgwDevSpec* dspec, const NgwResetFast* a, int nw, int additem, unsigned grid, size_t lds_bytes,
+                                            hipStream_t stream) {
+    const void* fn = nullptr;
+#define NGW_RF(NWV, AV) if (nw == NWV && additem == AV) fn = reinterpret_cast<const void*>(ngw_reset_fast<NWV, AV != 0>)
+    NGW_RF(2, 0); NGW_RF(2, 1); NGW_RF(8, 0); NGW_RF(8, 1); NGW_RF(0, 0); NGW_RF(0, 1);
+#undef NGW_RF
+    if (!fn) return hipErrorInvalidValue;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    void* args[] = {const_cast<NgwDevSpec**>(&dspec), const_cast<NgwResetFast*>(a)};
+    return hipLaunchKernel(fn, dim3(grid), dim3(NGW_EPB), args, lds_bytes, stream);
+}
 
 extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int feat, unsigned grid,
                                  size_t lds_bytes, hipStream_t stream) {
