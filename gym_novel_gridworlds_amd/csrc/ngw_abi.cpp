@@ -70,6 +70,9 @@ struct ngw_handle {
     NgwResetFast rf{};                    // its arguments, laid out once (layout_reset_fast)
     int rf_nw = -1, rf_additem = 0;       // rf_nw < 0: not applicable to this spec / layout
     size_t rf_lds = 0;
+    int nostage = 0;                      // lean kernel without map staging (S*S >= 256, or NGW_NOSTAGE=<min S*S>; 0 = never)
+    NgwLaunch ns_proto{};                 // its launch prototype (small LDS layout)
+    size_t ns_lds = 0;
     int lean = 1;                         // plain configurations step through ngw_step_lean (NGW_LEAN=0 in the environment: general kernel, A/B)
     int ext = 0;                          // spec uses FireWall / FenceRestriction / Crate step predicates -> EXT kernels
     int8_t* view_out = nullptr;           // AgentMap windows
@@ -85,7 +88,7 @@ int check_spec(const ngw_spec* s) {
     if (!s) return fail(NGW_E_INVALID_ARG, "spec is NULL");
     if (s->abi_version != NGW_ABI_VERSION) return fail(NGW_E_INVALID_ARG, "spec abi_version %d != %d", s->abi_version, NGW_ABI_VERSION);
     if (s->map_size < 5 || s->map_size > NGW_MAX_MAP_SIZE) return fail(NGW_E_INVALID_ARG, "map_size %d outside [5, %d]", s->map_size, NGW_MAX_MAP_SIZE);
-    if (s->n_items < 2 || s->n_items > NGW_MAX_ITEMS) return fail(NGW_E_INVALID_ARG, "n_items %d out of range", s->n_items);
+    if (s->n_items < 4 || s->n_items > NGW_MAX_ITEMS) return fail(NGW_E_INVALID_ARG, "n_items %d outside [4, %d] (air, wall, a crafting table and a goal item at least)", s->n_items, NGW_MAX_ITEMS);
     if (s->n_actions < 1 || s->n_actions > NGW_MAX_ACTIONS) return fail(NGW_E_INVALID_ARG, "n_actions %d out of range", s->n_actions);
     if (s->n_recipes < 0 || s->n_recipes > NGW_MAX_RECIPES) return fail(NGW_E_INVALID_ARG, "n_recipes %d out of range", s->n_recipes);
     if (s->n_start > NGW_MAX_START_ITEMS) return fail(NGW_E_INVALID_ARG, "n_start %d out of range", s->n_start);
@@ -230,6 +233,15 @@ int upload_reset_u(ngw_handle* h) {
     NgwLaunch lp = h->proto;                                   // what the lean kernel's cold path reads instead of its kernarg
     lp.b = h->b;
     HIP_TRY(hipMemcpyAsync(&h->dspec->lp, &lp, sizeof(lp), hipMemcpyHostToDevice, h->stream));
+    {   // no-stage lean kernel: inventory rows | candidate masks | placement sequence
+        NgwLaunch& q = h->ns_proto;
+        q = h->proto;
+        q.b = h->b;
+        q.off_map = 0; q.off_inv = 0; q.off_cand = (uint32_t)(q.KP * NGW_EPB); q.off_act = q.off_cand + (uint32_t)(q.CW * NGW_EPB);
+        q.perm_lds = 0; q.off_perm = 0; q.lcfg = nullptr; q.lout = nullptr;
+        h->ns_lds = (size_t)(q.off_act + NGW_MAX_PLACE / 4) * 4;
+        HIP_TRY(hipMemcpyAsync(&h->dspec->lp_ns, &q, sizeof(q), hipMemcpyHostToDevice, h->stream));
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
     return NGW_OK;
 }
@@ -316,6 +328,12 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     const unsigned grid = (unsigned)(h->n_pad / NGW_EPB);
     bool taken = false;
     if (mode == NGW_MODE_RESET) { if (int rc = launch_reset_fast(h, NGW_MODE_RESET, mask_dev, &taken)) return rc; }
+    if (!taken && mode == NGW_MODE_STEP && h->lean && h->nostage && !h->lidar_fused && !h->ext) {   // big maps: no-stage lean kernel
+        NgwLaunch q = h->ns_proto;
+        q.b = h->b; q.mode = mode; q.n_steps = 1; q.actions = actions_dev; q.autoreset = h->autoreset; q.horizon = h->horizon; q.stamps = h->proto.stamps;
+        HIP_TRY(ngw_launch(h->dspec, &q, h->map_mode, 4 | 8, grid, h->ns_lds, h->stream));
+        taken = true;
+    }
     if (!taken)
         HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, (h->lidar_fused ? 1 : 0) | (h->ext ? 2 : 0) | (h->lean ? 4 : 0), grid, h->lds_bytes, h->stream));
     if (h->prefetch_every > 0 && (mode == NGW_MODE_STEP || mode == NGW_MODE_RESET || mode == NGW_MODE_ROLLOUT || mode == NGW_MODE_ROLLOUT_ACT)) {
@@ -372,6 +390,11 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     h->own_stream = true;
     if (const char* v = getenv("NGW_LEAN")) h->lean = atoi(v) != 0;
     if (const char* v = getenv("NGW_FAST_RESET")) h->fast_reset = atoi(v);
+    {
+        int min_s2 = 256;                                  // 16 x 16 and larger (measured: see DESIGN.md)
+        if (const char* v = getenv("NGW_NOSTAGE")) min_s2 = atoi(v);
+        h->nostage = min_s2 > 0 && spec->map_size * spec->map_size >= min_s2;
+    }
 
     const int S = spec->map_size, S2 = S * S, K = spec->n_items;
     const size_t np = (size_t)h->n_pad;

@@ -150,6 +150,7 @@ struct NgwDevSpec {
     int32_t n_place;
     uint32_t act_lean[NGW_MAX_ACTIONS * NGW_LEAN_DW];   /* lean step kernel: micro-op table, see NGW_LEAN_DW */
     NgwLaunch lp;                /* launch prototype (layout + buffer pointers): the lean kernel's cold reset path reads it from here */
+    NgwLaunch lp_ns;             /* the same for the no-stage lean kernel (its own, small LDS layout: inventory rows | candidate masks | placement sequence) */
     ngw_spec sp;                 /* full spec: the (cold) reset path reads it with scalar loads */
     NgwExtU x;
     NgwNx nx;

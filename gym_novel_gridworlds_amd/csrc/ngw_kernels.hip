@@ -175,8 +175,8 @@ struct ResetArgs {
 // The shuffled-subset reset passes - AddItem.reset (novelty_wrappers.py:1017-1028), ReplaceItem.reset (:1131-1144),
 // Fence.reset (:871-884) - on a shuffle array `perm` with element stride `ps`: np.where(<predicate>) in row-major order,
 // np.random.shuffle (Fisher-Yates from the top), percent = randint(lo, hi), edit the first ceil(len * (percent / 100)).
-template <int KIND, typename P, class RNG>
-__device__ __forceinline__ void subset_pass(P perm, int64_t ps, RNG& px, LDS_AS int8_t* mp, int S, int S2, int agent, int match,
+template <int KIND, typename P, class RNG, typename MP>
+__device__ __forceinline__ void subset_pass(P perm, int64_t ps, RNG& px, MP mp, int S, int S2, int agent, int match,
                                             int item, int pct_span, const GLOBAL_AS double* pctq) {
     int n = 0;
     for (int i = 0; i < S2; i++) {
@@ -203,8 +203,8 @@ __device__ __forceinline__ void subset_pass(P perm, int64_t ps, RNG& px, LDS_AS 
     }
 }
 
-template <int KIND, class RNG>
-__device__ __forceinline__ void run_pass(const ResetArgs& a, LDS_AS uint16_t* perm_lds, int64_t env_local, RNG& px, LDS_AS int8_t* mp,
+template <int KIND, class RNG, typename MP>
+__device__ __forceinline__ void run_pass(const ResetArgs& a, LDS_AS uint16_t* perm_lds, int64_t env_local, RNG& px, MP mp,
                                          int agent, int match, int item, int pct_span) {
     const GLOBAL_AS double* pctq = (const GLOBAL_AS double*)a.dspec->pctq[KIND];
     if (a.perm_lds) {
@@ -220,8 +220,10 @@ __device__ __forceinline__ void run_pass(const ResetArgs& a, LDS_AS uint16_t* pe
 
 // (LDS / global pointers carry their address space: across a real call generic pointers would turn every access
 //  into a flat_* instruction)
-template <class RNG>
-__device__ __forceinline__ uint32_t reset_lane(const ResetArgs a, LDS_AS int8_t* mp, LDS_AS int32_t* inv, LDS_AS uint32_t* cand,
+// MP = the lane's map: LDS_AS int8_t* (staged kernels) or GLOBAL_AS int8_t* (the no-stage step kernel's fallback, which has
+// no map in LDS and runs the same loop straight on the env's map row in HBM - slow, and only when no prepared episode exists).
+template <class RNG, typename MP>
+__device__ __forceinline__ uint32_t reset_lane(const ResetArgs a, MP mp, LDS_AS int32_t* inv, LDS_AS uint32_t* cand,
                                             const LDS_AS uint8_t* place_seq, LDS_AS uint16_t* perm_lds, LDS_AS uint32_t* rng_ring,
                                             uint64_t env_global, int64_t env_local, uint32_t episode) {
     // the spec bytes this path needs arrived with the call's other uniform arguments (no dependent spec loads in here)
@@ -1273,10 +1275,11 @@ extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, in
         return hipGetLastError();
     }
     if ((feat & 4) && a->mode == NGW_MODE_STEP && !(feat & 3)) {    // plain configuration, one step: the lean kernel
+        if (feat & 8) return launch_lean<NGW_MAP_STRAIGHT, false>(dspec, a, grid, lds_bytes, stream);   // no-stage (big maps)
         switch (map_mode) {
-        case NGW_MAP_STRAIGHT: return launch_lean<NGW_MAP_STRAIGHT>(dspec, a, grid, lds_bytes, stream);
-        case NGW_MAP_DWORD: return launch_lean<NGW_MAP_DWORD>(dspec, a, grid, lds_bytes, stream);
-        default: return launch_lean<NGW_MAP_BYTE>(dspec, a, grid, lds_bytes, stream);
+        case NGW_MAP_STRAIGHT: return launch_lean<NGW_MAP_STRAIGHT, true>(dspec, a, grid, lds_bytes, stream);
+        case NGW_MAP_DWORD: return launch_lean<NGW_MAP_DWORD, true>(dspec, a, grid, lds_bytes, stream);
+        default: return launch_lean<NGW_MAP_BYTE, true>(dspec, a, grid, lds_bytes, stream);
         }
     }
     switch (map_mode) {
