@@ -123,27 +123,24 @@ def lib():
 
 
 def pinned_array(shape, dtype):
-    """numpy array over page-locked host memory (freed with the array); falls back to np.zeros if pinning fails."""
+    """numpy array over page-locked host memory; falls back to np.zeros if pinning fails.  The memory is freed when the LAST
+    array that uses it goes away: numpy collapses the `.base` of every view (slices, reshapes) to the one frombuffer array
+    created here, so the finalizer hangs on that array, not on the reshaped view handed out."""
+    import weakref
     dt = np.dtype(dtype)
     n = int(np.prod(shape)) * dt.itemsize
     p = lib().ngw_host_alloc(n)
     if not p:
         return np.zeros(shape, dt)
     buf = (C.c_char * max(n, 1)).from_address(p)
-    arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
-    _PINNED[id(buf)] = (buf, p)
-    import weakref
-    weakref.finalize(arr, _free_pinned, id(buf))
-    return arr
+    flat = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape)))      # the ultimate owner every view's .base points at
+    weakref.finalize(flat, _free_pinned, int(p))
+    return flat.reshape(shape)
 
 
-_PINNED = {}
-
-
-def _free_pinned(key):
-    ent = _PINNED.pop(key, None)
-    if ent is not None and _lib is not None:
-        _lib.ngw_host_free(C.c_void_p(ent[1]))
+def _free_pinned(addr):
+    if _lib is not None:
+        _lib.ngw_host_free(C.c_void_p(addr))
 
 
 def last_error():

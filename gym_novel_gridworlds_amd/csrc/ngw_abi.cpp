@@ -58,7 +58,7 @@ struct ngw_handle {
     // LidarInFront observation
     NgwLidarDev* lidar_cfg = nullptr;     // device tables
     int32_t* lidar_out = nullptr;
-    int lidar_len = 0;
+    int lidar_len = 0, lidar_cap = 0;         // lidar_cap: row length lidar_out was allocated for
     int lidar_bits = 32;                  // element width of the lidar observation (ngw_lidar_set_output)
     uint32_t lidar_magic = 0, lidar_off_tab = 0, lidar_off_tile = 0, lidar_off_map = 0;
     int lidar_fused = 0, lidar_range = 0, lidar_beams = 0, lidar_chan = 0, lidar_ninv = 0;
@@ -77,6 +77,7 @@ struct ngw_handle {
     int ext = 0;                          // spec uses FireWall / FenceRestriction / Crate step predicates -> EXT kernels
     int8_t* view_out = nullptr;           // AgentMap windows
     int view_size = 0;
+    size_t view_cap = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_steps = 0;
@@ -146,6 +147,12 @@ int check_spec(const ngw_spec* s) {
     if (s->ext_flags > 3 || s->fire_skip_recipe > s->n_recipes) return fail(NGW_E_INVALID_ARG, "ext_flags / fire_skip_recipe out of range");
     if ((1 << s->pass_order[0] | 1 << s->pass_order[1] | 1 << s->pass_order[2]) != 0xE)
         return fail(NGW_E_INVALID_ARG, "pass_order must be a permutation of {1, 2, 3}");
+    if (s->fence_item && s->replace_to && s->replace_from == s->wall_item) {
+        int at_replace = 0, at_fence = 0;
+        for (int j = 0; j < 3; j++) { if (s->pass_order[j] == 2) at_replace = j; if (s->pass_order[j] == 3) at_fence = j; }
+        if (at_replace < at_fence)      /* the fence pass would fence border cells: add_fence_around leaves the map (reference: IndexError) */
+            return fail(NGW_E_INVALID_ARG, "fence pass after a wall-replacing pass edits cells outside the map");
+    }
     return NGW_OK;
 }
 
@@ -158,6 +165,12 @@ int dev_alloc(ngw_handle* h, T** p, size_t count) {
     h->allocs.push_back(q);
     *p = static_cast<T*>(q);
     return NGW_OK;
+}
+
+void dev_free(ngw_handle* h, void* p) {
+    for (size_t i = 0; i < h->allocs.size(); i++)
+        if (h->allocs[i] == p) { h->allocs.erase(h->allocs.begin() + (long)i); break; }
+    (void)hipFree(p);
 }
 
 // LDS carve-up of the step kernel (dword offsets).  With the lidar epilogue fused the maps sit behind a guard (ray
@@ -894,6 +907,9 @@ int ngw_set_state(ngw_handle* h, int64_t first, int64_t count, const int8_t* map
     if (facing)
         for (size_t i = 0; i < n; i++)
             if (facing[i] < 0 || facing[i] > 3) return fail(NGW_E_INVALID_ARG, "agent_facing_id %d outside [0, 3]", facing[i]);
+    if (inv)
+        for (size_t i = 0; i < n * (size_t)K; i++)
+            if (inv[i] < 0) return fail(NGW_E_INVALID_ARG, "inventory quantity %d is negative", inv[i]);
     std::vector<uint8_t> sel;
     if (selected) {
         sel.resize(n);
@@ -961,6 +977,12 @@ int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg) {
     for (int i = 0; i < NGW_MAX_ITEMS; i++)
         if (cfg->chan_of_item[i] > cfg->n_chan || (i < cfg->n_inv && cfg->inv_item[i] >= K))
             return fail(NGW_E_INVALID_ARG, "lidar item table out of range");
+    for (int f = 0; f < 4; f++)                           /* ray offsets beyond the guard band would read outside the wave's LDS */
+        for (int b = 0; b < cfg->num_beams; b++)
+            for (int k = 0; k < cfg->max_range; k++)
+                if (cfg->dr[f][b][k] > cfg->max_range || cfg->dr[f][b][k] < -cfg->max_range || cfg->dc[f][b][k] > cfg->max_range ||
+                    cfg->dc[f][b][k] < -cfg->max_range)
+                    return fail(NGW_E_INVALID_ARG, "lidar ray offset (%d, %d) beyond max_range %d", cfg->dr[f][b][k], cfg->dc[f][b][k], cfg->max_range);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     const int L = cfg->num_beams * cfg->n_chan + cfg->n_inv;
@@ -975,7 +997,12 @@ int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg) {
     const uint32_t off_map = off; off += (uint32_t)(NGW_EPB * h->proto.MS / 4) + guard;
     if ((size_t)off * 4 > 160 * 1024) return fail(NGW_E_INVALID_ARG, "lidar observation of %d values needs %zu B of LDS (> 160 KiB)", L, (size_t)off * 4);
     if (!h->lidar_cfg) { if (int rc = dev_alloc(h, &h->lidar_cfg, 1)) return rc; }
-    if (L != h->lidar_len) { if (int rc = dev_alloc(h, &h->lidar_out, (size_t)h->n_pad * L)) return rc; }
+    if (L > h->lidar_cap) {                              /* grow only: a smaller observation reuses the buffer */
+        if (h->lidar_out) dev_free(h, h->lidar_out);
+        h->lidar_out = nullptr; h->lidar_cap = 0;
+        if (int rc = dev_alloc(h, &h->lidar_out, (size_t)h->n_pad * L)) return rc;
+        h->lidar_cap = L;
+    }
     {
         static thread_local NgwLidarDev hd;
         memset(&hd, 0, sizeof(hd));
@@ -1060,7 +1087,12 @@ int ngw_agent_view(ngw_handle* h, int view_size) {
     HIP_TRY(hipSetDevice(h->device));
     if (view_size != h->view_size) {
         h->view_size = 0;
-        if (int rc = dev_alloc(h, &h->view_out, (bytes + 3) / 4 * 4)) return rc;
+        if (bytes > h->view_cap) {
+            if (h->view_out) dev_free(h, h->view_out);
+            h->view_out = nullptr; h->view_cap = 0;
+            if (int rc = dev_alloc(h, &h->view_out, (bytes + 3) / 4 * 4)) return rc;
+            h->view_cap = bytes;
+        }
         h->view_size = view_size;
     }
     HIP_TRY(ngw_agent_view_launch(h->b.map, h->b.loc, reinterpret_cast<uint32_t*>(h->view_out), (uint32_t)((bytes + 3) / 4),

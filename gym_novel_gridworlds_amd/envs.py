@@ -36,6 +36,8 @@ class _NovelGridworldEnv(_EnvBase):
         self._spec = EnvSpec(self.ENV_ID, 10)
         self._vec = None
         self._vec_key = None
+        self._vec_fp = None
+        self._vec_cache = {}                                 # compiled-spec key -> device handle (most recently used last)
         self._seed = None
         self._episode_base = 0
         sp = self._spec
@@ -77,7 +79,7 @@ class _NovelGridworldEnv(_EnvBase):
         self.reward_intermediate = sp.reward_intermediate
         self.reward_done = sp.reward_done
         self.last_done = False
-        self._dev_state, self._dev_state_of = None, None     # what the device is known to hold (envs.py _push)
+        self._known, self._dev_state_of = None, None         # what the device is known to hold (envs.py _push)
 
     # ------------------------------------------------------------------ backend
     def _make_backend(self, spec, seed):
@@ -100,71 +102,103 @@ class _NovelGridworldEnv(_EnvBase):
         sp.reward_intermediate, sp.reward_done = self.reward_intermediate, self.reward_done
         return sp
 
-    def _backend(self):
-        sp = self._sync_spec()
-        # callers may REBIND the public tables (env.items_quantity = {...}); the spec follows the env's attributes
-        sp.items, sp.items_id, sp.items_quantity, sp.entities = self.items, self.items_id, self.items_quantity, self.entities
-        sp.actions_id, sp.recipes, sp.unbreakable_items = self.actions_id, self.recipes, self.unbreakable_items
-        sp.goal_item_to_craft = self.goal_item_to_craft
-        sp.map_size = int(self.map_size)
-        sp.reward_intermediate, sp.reward_done = self.reward_intermediate, self.reward_done
+    def _fingerprint(self):
+        """Cheap per-step check that the compiled spec still matches the env's public tables: identities and sizes of the
+        tables (callers rebind or grow them), the values of the small ones, and the spec's edit counter (novelty injection).
+        The full key is only rebuilt when this changes - and on every reset()."""
+        sp = self._spec
+        return (int(self.map_size), id(self.items_id), len(self.items_id), id(self.actions_id), len(self.actions_id), id(self.items_quantity),
+                tuple(self.items_quantity.values()), id(self.entities), len(self.entities), id(self.recipes), len(self.recipes),
+                id(self.unbreakable_items), len(self.unbreakable_items), self.goal_item_to_craft, self.reward_done, self.reward_intermediate,
+                len(sp.novelties), id(sp.axe), id(sp.additem), id(sp.replace), id(sp.fence), id(sp.crate), sp.fire_wall, sp.break_increase)
+
+    def _backend(self, full_check=False):
+        fp = self._fingerprint()
+        if self._vec is not None and fp == self._vec_fp and not full_check:
+            return self._vec
+        sp = self._sync_spec()      # callers may REBIND the public tables (env.items_quantity = {...}): the spec follows the env's attributes
         key = (sp.map_size, tuple(sp.items_id.items()), tuple(sp.actions_id.items()), tuple(sp.items_quantity.items()),
                tuple(sorted(sp.entities)), repr(sp.axe), repr(sp.additem), repr(sp.start_inventory), sp.reward_done,
                sp.reward_intermediate, repr(sp.replace), repr(sp.fence), repr(sp.fire_wall), repr(sp.crate),
                tuple(sorted(sp.unbreakable_items)), repr(sp.recipes), repr(sp.break_increase))
         if self._vec is None or key != self._vec_key:
-            self._close_backend()
+            # a handle per compiled spec, kept: the reference's own loop (tests/random_action.py:51-64) changes map_size every
+            # ten steps, and building a device handle costs milliseconds.  The episode counter travels with the env, not
+            # the handle, so no (seed, episode) stream is ever replayed.
+            if self._vec is not None:
+                self._episode_base = int(self._vec.get_state(0, 1)['episode'][0])
             if self._seed is None:                          # reproducible under np.random.seed(), like the reference
                 self._seed = int(np.random.randint(0, 2 ** 31 - 1))
-            self._vec = self._make_backend(sp, self._seed)
-            self._vec_key = key
+            vec = self._vec_cache.pop(key, None)
+            if vec is None:
+                import copy as _copy
+                vec = self._make_backend(_copy.deepcopy(sp), self._seed)
+                while len(self._vec_cache) >= self._VEC_CACHE:     # oldest out
+                    self._vec_cache.pop(next(iter(self._vec_cache))).close()
+            self._vec_cache[key] = vec                          # (re-inserted: most recently used last)
+            self._vec, self._vec_key = vec, key
+            self._dev_state_of = None
             if self._episode_base:
-                self._vec.set_state(0, episode=np.array([self._episode_base], np.uint32))
+                vec.set_state(0, episode=np.array([self._episode_base], np.uint32))
+        self._vec_fp = fp
         return self._vec
+
+    _VEC_CACHE = 16
 
     def _close_backend(self):
         if self._vec is not None:
             self._episode_base = int(self._vec.get_state(0, 1)['episode'][0])
-            self._vec.close()
-            self._vec = None
+        for vec in self._vec_cache.values():
+            vec.close()
+        self._vec_cache.clear()
+        self._vec = None
+        self._vec_fp = None
 
     def _push(self, vec):
-        """host attributes -> device state"""
+        """host attributes -> device state.  The caller may have edited any attribute since the last pull - or nothing at all
+        (the usual case in a step loop): what the device is known to hold is remembered as plain Python values and one int8
+        map copy, so the unchanged case costs a handful of comparisons and no array is built."""
+        sel = self.selected_item
+        k = self._known
+        if (self._dev_state_of is vec and k is not None and k[0] == self.agent_location and k[1] == self.agent_facing_id and k[2] == sel
+                and k[3] == self.step_count and k[4] == self.inventory_items_quantity and self.map.shape == k[5].shape
+                and (self.map == k[5]).all()):
+            return
         ids, S, K = self.items_id, self.map_size, len(self.items_id)
         inv = np.zeros((1, K), np.int32)
         for name, q in self.inventory_items_quantity.items():
             inv[0, ids[name]] = q                            # KeyError for an unknown item name, like the reference
         m = np.ascontiguousarray(np.asarray(self.map).reshape(1, S * S), np.int8)
-        st = dict(map=m, loc=np.array([self.agent_location], np.int32), facing=np.array([self.agent_facing_id], np.int32), inv=inv,
-                  selected=np.array([ids[self.selected_item] if self.selected_item else 0], np.int32),
-                  step_count=np.array([self.step_count], np.int32))
-        # the caller may have edited any attribute since the last pull - or nothing at all (the usual case in a step loop):
-        # then the device already holds exactly this state and the six copies are skipped
-        known = self._dev_state if self._dev_state_of is vec else None
-        if known is not None and all(np.array_equal(st[k], known[k]) for k in st):
-            return
-        vec.set_state(0, **st)
-        self._dev_state, self._dev_state_of = st, vec
+        vec.set_state(0, map=m, loc=np.array([self.agent_location], np.int32), facing=np.array([self.agent_facing_id], np.int32), inv=inv,
+                      selected=np.array([ids[sel] if sel else 0], np.int32), step_count=np.array([self.step_count], np.int32))
+        self._remember(vec)
+
+    def _remember(self, vec):
+        self._known = (tuple(self.agent_location), self.agent_facing_id, self.selected_item, self.step_count,
+                       dict(self.inventory_items_quantity), np.array(self.map, np.int8))
+        self._dev_state_of = vec
 
     def _pull(self, vec, st=None):
         """device state -> host attributes (the map array object is kept: observations alias it)"""
         if st is None:
             st = vec.get_state(0, 1)
-        self._dev_state = {k: np.array(st[k], dtype=(np.int8 if k == 'map' else np.int32)).reshape(1, -1) if k in ('map', 'inv', 'loc')
-                           else np.array(st[k], np.int32).reshape(1) for k in ('map', 'loc', 'facing', 'inv', 'selected', 'step_count')}
-        self._dev_state_of = vec
         S = self.map_size
         if self.map.shape != (S, S):
             self.map = np.zeros((S, S), dtype=int)
-        self.map[...] = st['map'][0].reshape(S, S)
-        self.agent_location = (int(st['loc'][0, 0]), int(st['loc'][0, 1]))
+        m8 = np.array(st['map'][0], np.int8).reshape(S, S)
+        self.map[...] = m8
+        loc = st['loc'][0]
+        self.agent_location = (int(loc[0]), int(loc[1]))
         self.set_agent_facing(DIRECTION_STR[int(st['facing'][0])])
         names = self._spec.item_names
-        for i, name in enumerate(names):
-            self.inventory_items_quantity[name] = int(st['inv'][0, i])
+        inv = self.inventory_items_quantity
+        for name, q in zip(names, st['inv'][0].tolist()):
+            inv[name] = q
         sel = int(st['selected'][0])
         self.selected_item = names[sel] if sel else ''
         self.step_count = int(st['step_count'][0])
+        self._known = (self.agent_location, self.agent_facing_id, self.selected_item, self.step_count, dict(inv), m8)
+        self._dev_state_of = vec
 
     # ------------------------------------------------------------------ reference API
     def reset(self, map_size=None, items_id=None, items_quantity=None):
@@ -202,7 +236,7 @@ class _NovelGridworldEnv(_EnvBase):
         self.last_step_cost = 0
         self.last_reward = 0
         self.last_done = False
-        vec = self._backend()
+        vec = self._backend(full_check=True)
         vec.reset()                                          # AssertionError(PLACEMENT_MESSAGE) when items do not fit
         self._pull(vec)
         obs = self.get_observation()
@@ -214,14 +248,19 @@ class _NovelGridworldEnv(_EnvBase):
         self.last_action = list(self.actions_id.keys())[list(self.actions_id.values()).index(action_id)]
         vec = self._backend()
         self._push(vec)
-        _, reward, done, info = vec.step(np.array([action_id], np.int32))
-        self._pull(vec, vec.last_state() if hasattr(vec, 'last_state') else None)   # the step() call already brought it back
+        step1 = getattr(vec, 'step1', None)
+        if step1 is not None:                                # device handle: one C-ABI call, scalars back (no per-step arrays)
+            reward, done, result, cost_code, msg_code, msg_arg = step1(action_id)
+            self._pull(vec, vec.last_state())                # the call already brought the state back
+        else:                                                # oracle-backed stand-in of the CPU tests
+            _, rw, dn, info = vec.step(np.array([action_id], np.int32))
+            self._pull(vec, vec.last_state() if hasattr(vec, 'last_state') else None)
+            reward, done, result = int(rw[0]), info_done(dn), bool(info['result'][0])
+            cost_code, msg_code, msg_arg = int(info['step_cost_code'][0]), int(info['message_code'][0]), int(info['message_arg'][0])
         obs = self.get_observation()
         self.update_block_in_front()
-        reward, done = int(reward[0]), bool(info_done(done))
-        step_cost = STEP_COSTS[int(info['step_cost_code'][0])]
-        message = self._spec.format_message(int(action_id), int(info['message_code'][0]), int(info['message_arg'][0]))
-        out_info = {'result': bool(info['result'][0]), 'step_cost': step_cost, 'message': message}
+        step_cost = STEP_COSTS[cost_code]
+        out_info = {'result': result, 'step_cost': step_cost, 'message': self._spec.format_message(int(action_id), msg_code, msg_arg)}
         self.last_step_cost = step_cost
         self.last_reward = reward
         self.last_done = done

@@ -101,6 +101,12 @@ def apply_novelty(spec, novelty_name, difficulty='hard', novelty_arg1='', novelt
     if kind:                              # reset passes run innermost wrapper first = injection order (Wrapper.reset calls env.reset() first)
         if kind in spec.reset_passes:
             raise NotImplementedError("two %s-type reset passes in one stack are outside this build's scope" % kind)
+        if kind == 'fence' and 'replace' in spec.reset_passes and spec.replace and spec.replace['src'] == 'wall':
+            # the fence pass would pick cells of the (replaced) border ring, and add_fence_around (pogostick_v1_env.py:524-536)
+            # then indexes row / column -1 and S: numpy wraps the first around and raises IndexError on the second - not a
+            # behaviour to reproduce; refuse the stack instead of editing cells outside the map
+            raise IndexError("fence after a wall-replacing novelty (%s): the reference's add_fence_around indexes outside the map"
+                             % ', '.join(n[0] for n in spec.novelties if n[0] in ('firewall', 'replaceitem')))
         spec.reset_passes.append(kind)
     spec.novelties.append((novelty_name, difficulty, novelty_arg1, novelty_arg2))
     return spec

@@ -39,6 +39,7 @@ class VecNovelGridworld:
         self.num_envs = int(num_envs)
         self.device = int(device)
         self.seed = int(seed)
+        self.env_index_base = int(env_index_base)
         self.map_size = spec.map_size
         self.n_items = len(spec.items_id)
         self.items_id = dict(spec.items_id)
@@ -136,6 +137,27 @@ class VecNovelGridworld:
         if self._flags_word.value:
             self._raise_flags()
         return obs, reward, done, info
+
+    def step1(self, action):
+        """step() of a one-env handle for the gym.Env adapter: same C-ABI call, but the argument list is built once and the
+        outputs come back as Python scalars: (reward, done, result, cost code, message code, message arg)."""
+        args = self.__dict__.get('_step1_args')
+        if args is None:
+            assert self.num_envs == 1
+            o, p = self._obs, _cabi._ptr
+            args = self._step1_args = (
+                self._h, p(self._act_pinned, np.int32), p(o['map'], np.int8), p(o['agent_location'], np.int32),
+                p(o['agent_facing_id'], np.int32), p(o['inventory_items_quantity'], np.int32), p(self._reward, np.int32),
+                p(self._done, np.uint8), p(self._result, np.uint8), p(self._cost, np.uint8), p(self._msg, np.uint16), p(self._arg, np.uint16),
+                C.byref(self._flags_word), p(self._sel_host, np.uint8), p(self._steps_host, np.int32))
+            self._step1_fn = _cabi.lib().ngw_step_host
+        self._act_pinned[0] = action
+        rc = self._step1_fn(*args)
+        if rc:
+            _cabi.check(rc)
+        if self._flags_word.value:
+            self._raise_flags()
+        return (int(self._reward[0]), bool(self._done[0]), bool(self._result[0]), int(self._cost[0]), int(self._msg[0]), int(self._arg[0]))
 
     def last_state(self):
         """State after the last step() as get_state() would return it, from the host buffers that call filled (no device

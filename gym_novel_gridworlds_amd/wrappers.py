@@ -82,5 +82,8 @@ def limit_actions_vec(venv, limited_actions):
     spec.craft_actions_id = {a: i for a, i in limited.items() if a.startswith('Craft_')}
     spec.select_actions_id = {a: i for a, i in limited.items() if a.startswith('Select_')}
     spec.action_space_n = len(limited)
-    return VecNovelGridworld(spec=spec, num_envs=venv.num_envs, device=venv.device, seed=venv.seed,
-                             autoreset=venv.autoreset, horizon=venv.horizon)
+    new = VecNovelGridworld(spec=spec, num_envs=venv.num_envs, device=venv.device, seed=venv.seed, autoreset=venv.autoreset,
+                            horizon=venv.horizon, env_index_base=venv.env_index_base, reset_prefetch=venv.reset_prefetch)
+    if venv.lidar is not None:                              # the observation setup travels with the env
+        new.lidar_configure(venv.lidar, fused=venv.lidar_fused, dtype=venv.lidar_dtype)
+    return new

@@ -32,6 +32,10 @@ def _create(cspec, n=64):
     (lambda s: (setattr(s, 'n_inv_start', 1), s.inv_start_item.__setitem__(0, 0)), 'inv_start_item'),
     (lambda s: setattr(s, 'map_size', 3), 'map_size'),
     (lambda s: setattr(s, 'abi_version', 99), 'abi'),
+    (lambda s: setattr(s, 'n_items', 3), 'n_items'),                       # rows move as 16-byte chunks: at least four items
+    (lambda s: (setattr(s, 'replace_from', s.wall_item), setattr(s, 'replace_to', 3), setattr(s, 'replace_pct_lo', 10), setattr(s, 'replace_pct_hi', 20),
+                setattr(s, 'fence_item', 4), setattr(s, 'fence_pct_lo', 10), setattr(s, 'fence_pct_hi', 20),
+                s.pass_order.__setitem__(0, 2), s.pass_order.__setitem__(1, 3), s.pass_order.__setitem__(2, 1)), 'outside the map'),
 ])
 def test_malformed_spec_is_rejected(edit, needle):
     cs = make_spec(T.POGO, 10).compile()
@@ -56,7 +60,7 @@ def test_state_and_call_validation():
     L = _cabi.lib()
     for key, bad, needle in (('loc', np.array([[0, 3]], np.int32), 'walled interior'), ('loc', np.array([[4, 9]], np.int32), 'walled interior'),
                              ('facing', np.array([4], np.int32), 'agent_facing_id'), ('selected', np.array([9], np.int32), 'selected item'),
-                             ('map', np.full((1, 100), 9, np.int8), 'map cell value')):
+                             ('map', np.full((1, 100), 9, np.int8), 'map cell value'), ('inv', np.full((1, 9), -1, np.int32), 'negative')):
         with pytest.raises(ValueError) as ei:
             v.set_state(5, **{key: bad})
         assert needle in str(ei.value), ei.value
@@ -68,6 +72,22 @@ def test_state_and_call_validation():
                  lambda: v.set_reset_prefetch(-1), lambda: _cabi.check(L.ngw_set_autoreset(v._h, 1, -5))):
         with pytest.raises(ValueError):
             call()
+    from gym_novel_gridworlds_amd.lidar import LidarConfig
+    lc = LidarConfig(v.spec, 8).compile(v.spec)
+    lc.dr[0][0][0] = 120                                                   # a ray offset far beyond max_range would leave the LDS guard band
+    assert L.ngw_lidar_configure(v._h, C.byref(lc)) == _cabi.E_INVALID_ARG and 'max_range' in _cabi.last_error()
     assert L.ngw_reset(None, None) == _cabi.E_INVALID_ARG and 'NULL' in _cabi.last_error()
     v.step(np.zeros(100, np.int32))                                       # the handle is still usable
     assert v.error_flags() == 0
+
+
+def test_limited_actions_env_keeps_shard_and_observation_setup():
+    """limit_actions_vec rebuilds the batched env: global env index base, prepared-episode cadence and the lidar setup travel along."""
+    from gym_novel_gridworlds_amd import limit_actions_vec
+    v = VecNovelGridworld(num_envs=128, seed=3, autoreset=True, horizon=100, env_index_base=4096, reset_prefetch=16)
+    v.lidar_configure(num_beams=8, fused=True, dtype=np.int16)
+    w = limit_actions_vec(v, {'Forward', 'Left', 'Right', 'Break', 'Craft_plank'})
+    assert (w.env_index_base, w.reset_prefetch, w.lidar_fused, w.lidar_dtype) == (4096, 16, True, np.dtype(np.int16))
+    ref = VecNovelGridworld(num_envs=128, seed=3, autoreset=True, horizon=100, env_index_base=4096)
+    w.reset(); ref.reset()
+    assert all((w.get_state()[k] == ref.get_state()[k]).all() for k in ('map', 'loc', 'facing'))   # same episodes as the shard it came from

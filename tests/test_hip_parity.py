@@ -513,9 +513,10 @@ def test_extreme_map_sizes_match_oracle(env_id, S):
         assert not ok
         return
     v.rollout(75, action_seed=5)
-    o.rollout(75, 5, 0)
-    if o.st.episode.max() > 1 and S <= 9:
-        return                                      # tiny maps may exhaust placement on a later reset: flags differ only
+    oflags = o.rollout(75, 5, 0)
+    # tiny maps may exhaust placement on a later (auto)reset: both sides must then raise the same sticky flag, and the state is
+    # compared either way (a failed placement leaves the same partial map on both sides)
+    assert v.error_flags() == oflags
     assert_state_equal(v, o, '%s S=%d' % (env_id, S))
 
 

@@ -193,3 +193,19 @@ def test_novelty_over_limit_actions_asserts_like_reference():
     env = limited(['Forward', 'Left', 'Right', 'Break'], ('axe', 'medium', 'wooden'))        # requirement met: steps go through
     obs, reward, done, info = env.step(env.limited_actions_id['Break'])
     assert info['step_cost'] == 3600.0
+
+
+def test_fence_after_a_wall_replacing_novelty_is_refused():
+    """firewall / replaceitem(wall -> X) below fence / fencerestriction: the reference's add_fence_around indexes outside the map
+    (numpy wraps row -1 around and raises IndexError on row S); the stack is refused when it is built, nothing is launched."""
+    from gym_novel_gridworlds_amd import apply_novelty, make_spec
+    for first in (('firewall', 'hard', '', ''), ('replaceitem', 'medium', 'wall', 'brick')):
+        for second in (('fence', 'hard', 'oak', ''), ('fencerestriction', 'medium', 'oak', '')):
+            spec = make_spec('NovelGridworld-Pogostick-v1', 10)
+            apply_novelty(spec, *first)
+            with pytest.raises(IndexError):
+                apply_novelty(spec, *second)
+    spec = make_spec('NovelGridworld-Pogostick-v1', 10)                      # the other order is fine (fences first: no border cell is fenced)
+    apply_novelty(spec, 'fence', 'hard', 'oak', '')
+    apply_novelty(spec, 'firewall', 'hard', '', '')
+    spec.compile()
