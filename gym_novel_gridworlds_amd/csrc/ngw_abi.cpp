@@ -54,6 +54,8 @@ struct ngw_handle {
     uint8_t* zc_host = nullptr;       // small batches: actions + packed outputs in host memory the GPU addresses directly
     uint8_t* zc_dev = nullptr;
     std::vector<void*> allocs;
+    std::vector<void*> host_allocs;       // state of a single-wavefront handle kept in GPU-addressable host memory (hostres)
+    int hostres = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing pair
     // LidarInFront observation
     NgwLidarDev* lidar_cfg = nullptr;     // device tables
@@ -167,6 +169,24 @@ int dev_alloc(ngw_handle* h, T** p, size_t count) {
     return NGW_OK;
 }
 
+// State array of a handle: device memory, or - for handles of at most one wavefront (the gym.Env adapter: n = 1) - page-locked
+// host memory the GPU addresses directly.  Such a handle steps with NO copy call and no pack launch: the kernel reads and
+// writes the few hundred bytes it touches across PCIe and the host reads the result in place after one synchronisation.
+template <typename T>
+int state_alloc(ngw_handle* h, T** p, size_t count) {
+    if (!h->hostres) return dev_alloc(h, p, count);
+    void* q = nullptr;
+    const size_t bytes = count * sizeof(T);
+    HIP_TRY(hipHostMalloc(&q, bytes ? bytes : 1, hipHostMallocMapped));
+    memset(q, 0, bytes);
+    h->host_allocs.push_back(q);
+    void* d = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&d, q, 0));
+    if (d != q) return fail(NGW_E_HIP, "host-resident state needs unified addressing");
+    *p = static_cast<T*>(q);
+    return NGW_OK;
+}
+
 void dev_free(ngw_handle* h, void* p) {
     for (size_t i = 0; i < h->allocs.size(); i++)
         if (h->allocs[i] == p) { h->allocs.erase(h->allocs.begin() + (long)i); break; }
@@ -242,10 +262,10 @@ int upload_reset_u(ngw_handle* h) {
     ru.n_inv_start = s.n_inv_start;
     for (int j = 0; j < 3; j++) ru.pass_order[j] = s.pass_order[j];
     for (int j = 0; j < NGW_MAX_INV_START; j++) { ru.inv_start_item[j] = s.inv_start_item[j]; ru.inv_start_qty[j] = s.inv_start_qty[j]; }
-    HIP_TRY(hipMemcpyAsync(&h->dspec->ru, &ru, sizeof(ru), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(&h->dspec->ru, &ru, sizeof(ru), hipMemcpyDefault, h->stream));
     NgwLaunch lp = h->proto;                                   // what the lean kernel's cold path reads instead of its kernarg
     lp.b = h->b;
-    HIP_TRY(hipMemcpyAsync(&h->dspec->lp, &lp, sizeof(lp), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(&h->dspec->lp, &lp, sizeof(lp), hipMemcpyDefault, h->stream));
     {   // no-stage lean kernel: inventory rows | candidate masks | placement sequence
         NgwLaunch& q = h->ns_proto;
         q = h->proto;
@@ -253,7 +273,7 @@ int upload_reset_u(ngw_handle* h) {
         q.off_map = 0; q.off_inv = 0; q.off_cand = (uint32_t)(q.KP * NGW_EPB); q.off_act = q.off_cand + (uint32_t)(q.CW * NGW_EPB);
         q.perm_lds = 0; q.off_perm = 0; q.lcfg = nullptr; q.lout = nullptr;
         h->ns_lds = (size_t)(q.off_act + NGW_MAX_PLACE / 4) * 4;
-        HIP_TRY(hipMemcpyAsync(&h->dspec->lp_ns, &q, sizeof(q), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(&h->dspec->lp_ns, &q, sizeof(q), hipMemcpyDefault, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     return NGW_OK;
@@ -411,18 +431,23 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
 
     const int S = spec->map_size, S2 = S * S, K = spec->n_items;
     const size_t np = (size_t)h->n_pad;
+    {
+        const char* v = getenv("NGW_HOST_STATE");
+        h->hostres = h->n_pad == NGW_EPB && !(v && atoi(v) == 0);
+    }
     int rc = NGW_OK;
-    if (!rc) rc = dev_alloc(h, &h->b.map, np * S2);
-    if (!rc) rc = dev_alloc(h, &h->b.loc, np * 2);
-    if (!rc) rc = dev_alloc(h, &h->b.facing, np);
-    if (!rc) rc = dev_alloc(h, &h->b.inv, np * K);
-    if (!rc) rc = dev_alloc(h, &h->b.selected, np);
-    if (!rc) rc = dev_alloc(h, &h->b.step_count, np);
-    if (!rc) rc = dev_alloc(h, &h->b.episode, np);
-    if (!rc) rc = dev_alloc(h, &h->b.reward, np);
-    if (!rc) rc = dev_alloc(h, &h->b.done, np);
-    if (!rc) rc = dev_alloc(h, &h->b.info, np);
+    if (!rc) rc = state_alloc(h, &h->b.map, np * S2);
+    if (!rc) rc = state_alloc(h, &h->b.loc, np * 2);
+    if (!rc) rc = state_alloc(h, &h->b.facing, np);
+    if (!rc) rc = state_alloc(h, &h->b.inv, np * K);
+    if (!rc) rc = state_alloc(h, &h->b.selected, np);
+    if (!rc) rc = state_alloc(h, &h->b.step_count, np);
+    if (!rc) rc = state_alloc(h, &h->b.episode, np);
+    if (!rc) rc = state_alloc(h, &h->b.reward, np);
+    if (!rc) rc = state_alloc(h, &h->b.done, np);
+    if (!rc) rc = state_alloc(h, &h->b.info, np);
     if (!rc) rc = dev_alloc(h, &h->b.flags, 1);
+    if (!rc && h->hostres) rc = state_alloc(h, &h->b.flags_host, 1);
     if (!rc) rc = dev_alloc(h, &h->actions_dev, np);
     if (!rc) rc = dev_alloc(h, &h->mask_dev, np);
     if (!rc && (spec->additem_item || spec->replace_to || spec->fence_item)) rc = dev_alloc(h, &h->b.perm, np * S2);   // HBM fallback for maps too big for the LDS shuffle
@@ -536,7 +561,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
                 l[5] = (uint32_t)(uint8_t)(int8_t)rewc | (rbit << 8) | (slotsel << 12) | ((cost[0] & 63u) << 14) | ((cost[1] & 63u) << 20) | ((cost[2] & 63u) << 26);
             }
         }
-        if (hipMemcpyAsync(h->dspec, &hs, sizeof(hs), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        if (hipMemcpyAsync(h->dspec, &hs, sizeof(hs), hipMemcpyDefault, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess)
             return bail(fail(NGW_E_HIP, "spec upload failed"));
     }
@@ -567,6 +592,7 @@ int ngw_destroy(ngw_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) (void)hipFree(p);
+    for (void* p : h->host_allocs) (void)hipHostFree(p);
     drop_graph(h);
     if (h->info_host) (void)hipHostFree(h->info_host);
     if (h->zc_host) (void)hipHostFree(h->zc_host);
@@ -601,7 +627,7 @@ int ngw_set_reset_prefetch(ngw_handle* h, int32_t every_n_steps) {
         if (rc) { h->nx = NgwNx{}; return rc; }
     }
     const NgwNx on_device = every_n_steps > 0 ? h->nx : NgwNx{};      // null pointers switch the consume path off
-    HIP_TRY(hipMemcpyAsync(&h->dspec->nx, &on_device, sizeof(NgwNx), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(&h->dspec->nx, &on_device, sizeof(NgwNx), hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->prefetch_every = every_n_steps;
     h->since_refill = every_n_steps;                 // the next launch is followed by a refill
@@ -628,7 +654,7 @@ int ngw_reset(ngw_handle* h, const uint8_t* mask_host) {
     HIP_TRY(hipSetDevice(h->device));
     const uint8_t* m = nullptr;
     if (mask_host) {
-        HIP_TRY(hipMemcpyAsync(h->mask_dev, mask_host, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->mask_dev, mask_host, (size_t)h->n, hipMemcpyDefault, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));   // mask_host may be pageable and reused by the caller
         m = h->mask_dev;
     }
@@ -642,7 +668,7 @@ int ngw_step(ngw_handle* h, const int32_t* actions_host) {
         if (actions_host[i] < 0 || actions_host[i] >= A)
             return fail(NGW_E_INVALID_ACTION, "%d is not in list", (int)actions_host[i]);   // pogostick_v1_env.py:236
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpyAsync(h->actions_dev, actions_host, (size_t)h->n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->actions_dev, actions_host, (size_t)h->n * sizeof(int32_t), hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return launch(h, NGW_MODE_STEP, 1, h->actions_dev, nullptr, 0, 0);
 }
@@ -698,7 +724,7 @@ constexpr size_t NGW_ZERO_COPY_BYTES = 1u << 20;   // ngw_step_host: up to here 
 
 #define D2H(dst, src, bytes)                                                                             \
     do {                                                                                                 \
-        if (dst) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, h->stream));        \
+        if (dst) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDefault, h->stream));        \
     } while (0)
 
 int ngw_get_obs(ngw_handle* h, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv) {
@@ -723,7 +749,7 @@ int ngw_get_step_out(ngw_handle* h, int32_t* reward, uint8_t* done, uint8_t* res
     const bool want_info = result || cost_code || msg_code || msg_arg;
     if (want_info) {
         info.resize(n);
-        HIP_TRY(hipMemcpyAsync(info.data(), h->b.info, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(info.data(), h->b.info, n * sizeof(uint32_t), hipMemcpyDefault, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (want_info)
@@ -758,7 +784,21 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
                             {want_info ? (void*)h : nullptr, h->b.info, n * 4}};
     size_t total = 0;
     for (const Out& o : outs) if (o.host) total += (o.bytes + 255) & ~(size_t)255;
-    if (total <= NGW_ZERO_COPY_BYTES) {
+    if (h->hostres) {
+        // State in GPU-addressable host memory: actions in, ONE launch, one synchronisation, results read in place.
+        if (!h->zc_host) {
+            h->zc_host = static_cast<uint8_t*>(ngw_host_alloc(NGW_EPB * sizeof(int32_t)));
+            if (!h->zc_host) return NGW_E_HIP;
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zc_dev), h->zc_host, 0));
+        }
+        memcpy(h->zc_host, actions_host, n * sizeof(int32_t));
+        if (int rc = launch(h, NGW_MODE_STEP, 1, reinterpret_cast<const int32_t*>(h->zc_dev), nullptr, 0, 0)) return rc;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int r = 0; r < INFO; r++)
+            if (outs[r].host && r != 6) memcpy(outs[r].host, outs[r].dev, outs[r].bytes);
+        if (error_flags) *error_flags = *h->b.flags_host;             // sticky: ngw_error_flags reads and clears it (with the device word)
+        if (want_info) info_words = h->b.info;
+    } else if (total <= NGW_ZERO_COPY_BYTES) {
         // Small batch: no copy calls at all.  The kernel reads the actions from, and a pack kernel writes every output into,
         // page-locked host memory that is mapped into the GPU's address space; one synchronisation, then plain memcpys.
         if (!h->zc_host) {
@@ -783,7 +823,7 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
         if (want_info) info_words = reinterpret_cast<const uint32_t*>(h->zc_host + offs[INFO]);
     } else {
         // actions in, launch, everything out, ONE synchronisation (ngw_step + ngw_get_obs + ngw_get_step_out take three)
-        HIP_TRY(hipMemcpyAsync(h->actions_dev, actions_host, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->actions_dev, actions_host, n * sizeof(int32_t), hipMemcpyDefault, h->stream));
         if (int rc = launch(h, NGW_MODE_STEP, 1, h->actions_dev, nullptr, 0, 0)) return rc;
         for (int r = 0; r < INFO; r++) D2H(outs[r].host, outs[r].dev, outs[r].bytes);
         if (want_info) {
@@ -791,7 +831,7 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
                 h->info_host = static_cast<uint32_t*>(ngw_host_alloc(n * sizeof(uint32_t)));
                 if (!h->info_host) return NGW_E_HIP;
             }
-            HIP_TRY(hipMemcpyAsync(h->info_host, h->b.info, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->info_host, h->b.info, n * sizeof(uint32_t), hipMemcpyDefault, h->stream));
             info_words = h->info_host;
         }
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -877,7 +917,7 @@ int ngw_get_state(ngw_handle* h, int64_t first, int64_t count, int8_t* map, int3
     std::vector<uint8_t> sel;
     if (selected) {
         sel.resize(n);
-        HIP_TRY(hipMemcpyAsync(sel.data(), h->b.selected + f, n, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(sel.data(), h->b.selected + f, n, hipMemcpyDefault, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (selected)
@@ -887,7 +927,7 @@ int ngw_get_state(ngw_handle* h, int64_t first, int64_t count, int8_t* map, int3
 
 #define H2D(dst, src, bytes)                                                                             \
     do {                                                                                                 \
-        if (src) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, h->stream));        \
+        if (src) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDefault, h->stream));        \
     } while (0)
 
 int ngw_set_state(ngw_handle* h, int64_t first, int64_t count, const int8_t* map, const int32_t* loc, const int32_t* facing,
@@ -925,7 +965,7 @@ int ngw_set_state(ngw_handle* h, int64_t first, int64_t count, const int8_t* map
     H2D(h->b.inv + f * K, inv, n * K * sizeof(int32_t));
     H2D(h->b.step_count + f, step_count, n * sizeof(int32_t));
     H2D(h->b.episode + f, episode, n * sizeof(uint32_t));
-    if (selected) HIP_TRY(hipMemcpyAsync(h->b.selected + f, sel.data(), n, hipMemcpyHostToDevice, h->stream));
+    if (selected) HIP_TRY(hipMemcpyAsync(h->b.selected + f, sel.data(), n, hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return NGW_OK;
 }
@@ -962,9 +1002,10 @@ int ngw_out_device_ptrs(ngw_handle* h, void** reward, void** done, void** info) 
 int ngw_error_flags(ngw_handle* h, uint32_t* flags) {
     if (!h || !flags) return fail(NGW_E_INVALID_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpyAsync(flags, h->b.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(flags, h->b.flags, sizeof(uint32_t), hipMemcpyDefault, h->stream));
     HIP_TRY(hipMemsetAsync(h->b.flags, 0, sizeof(uint32_t), h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->b.flags_host) { *flags |= *h->b.flags_host; *h->b.flags_host = 0; }
     return NGW_OK;
 }
 
@@ -1016,7 +1057,7 @@ int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg) {
         memcpy(hd.chan_of_item, cfg->chan_of_item, NGW_MAX_ITEMS);
         memcpy(hd.inv_item, cfg->inv_item, NGW_MAX_ITEMS);
         hd.num_beams = cfg->num_beams; hd.max_range = cfg->max_range; hd.n_chan = cfg->n_chan; hd.n_inv = cfg->n_inv;
-        HIP_TRY(hipMemcpyAsync(h->lidar_cfg, &hd, sizeof(hd), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->lidar_cfg, &hd, sizeof(hd), hipMemcpyDefault, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     h->lidar_len = L;
@@ -1068,7 +1109,7 @@ int ngw_get_lidar(ngw_handle* h, void* out_host) {
     if (!h || !out_host) return fail(NGW_E_INVALID_ARG, "NULL argument");
     if (!h->lidar_len) return fail(NGW_E_INVALID_ARG, "ngw_get_lidar before ngw_lidar_configure");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpyAsync(out_host, h->lidar_out, (size_t)h->n * h->lidar_len * (h->lidar_bits / 8), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(out_host, h->lidar_out, (size_t)h->n * h->lidar_len * (h->lidar_bits / 8), hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return NGW_OK;
 }
@@ -1105,7 +1146,7 @@ int ngw_get_agent_view(ngw_handle* h, int8_t* out_host) {
     if (!h->view_size) return fail(NGW_E_INVALID_ARG, "ngw_get_agent_view before ngw_agent_view");
     HIP_TRY(hipSetDevice(h->device));
     const size_t W = 2 * (size_t)h->view_size + 1;
-    HIP_TRY(hipMemcpyAsync(out_host, h->view_out, (size_t)h->n * W * W, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(out_host, h->view_out, (size_t)h->n * W * W, hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return NGW_OK;
 }

@@ -32,6 +32,7 @@ struct NgwBufs {
     uint8_t* done;        /* [n_pad] */
     uint32_t* info;       /* [n_pad] packed, see NGW_INFO_* */
     uint32_t* flags;      /* [1] sticky NGW_F_* */
+    uint32_t* flags_host; /* single-wavefront handles whose state lives in GPU-addressable host memory: the same word there, or nullptr */
     uint16_t* perm;       /* [S*S][n_pad] shuffle scratch of the subset reset passes, or nullptr */
 };
 

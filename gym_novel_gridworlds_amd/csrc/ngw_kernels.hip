@@ -154,6 +154,17 @@ __device__ __forceinline__ int nth_set_bit(uint32_t x, int n) {
     return bit;
 }
 
+// Handles of at most one wavefront may keep their state in GPU-addressable HOST memory (ngw_abi.cpp: the single-env gym.Env
+// adapter steps without a single copy call); their sticky error word lives there too and is updated by lane 0 with the
+// wave's OR (one wave per launch, launches ordered by the stream: no atomic needed across PCIe).
+__device__ __forceinline__ void raise_host_flags(uint32_t* flags_host, uint32_t flags) {
+    if (flags_host) {
+        uint32_t wf = flags;
+        for (int o = 32; o >= 1; o >>= 1) wf |= (uint32_t)__shfl_xor((int)wf, o);
+        if (threadIdx.x == 0 && wf) *flags_host |= wf;
+    }
+}
+
 // ---------------------------------------------------------------- per-lane reset on the LDS map
 // pogostick_v1_env.py:86-157 + add_item_to_map :159-181 (+ AddItem.reset, AxeEasy.reset).  `mp` = this lane's map
 // in LDS, `inv` = this lane's inventory row, `cand` = candidate bitmask column (stride EPB).
@@ -1031,6 +1042,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
         a.b.episode[e] = episode;
     }
     if (flags) atomicOr(a.b.flags, flags);
+    raise_host_flags(a.b.flags_host, flags);
 #ifdef NGW_STAMPS
     STAMP(5);
     __builtin_amdgcn_s_waitcnt(0);                                                 // every store acknowledged

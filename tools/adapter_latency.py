@@ -15,3 +15,7 @@ print('adapter step() %.1f us -> %.0f env-steps/s' % (dt / len(acts) * 1e6, len(
 t = time.perf_counter()
 for i in range(200): env.reset()
 print('adapter reset() %.1f us' % ((time.perf_counter() - t) / 200 * 1e6))
+vec = env._backend()
+t = time.perf_counter()
+for a in acts: vec.step1(int(a))
+print('  of which the C-ABI call (ngw_step_host through ctypes) %.1f us' % ((time.perf_counter() - t) / len(acts) * 1e6))
