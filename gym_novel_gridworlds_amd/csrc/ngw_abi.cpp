@@ -67,6 +67,11 @@ struct ngw_handle {
     size_t lidar_lds = 0;
     NgwNx nx = {};                        // prepared next episodes (ngw_set_reset_prefetch); all null = off
     int prefetch_every = 0, since_refill = 0;
+    int prefetch_user = 0;                // the caller chose the cadence (ngw_set_reset_prefetch): ngw_set_autoreset leaves it alone
+    int32_t* row_reward = nullptr;        // fused rollouts: the caller's output rows (ngw_rollout_outputs)
+    uint8_t* row_done = nullptr;
+    int64_t row_stride = 0;
+    int32_t* acc = nullptr;               // [4][n_pad] episode accumulators of the fused rollouts
     uint32_t off_rng = 0;                 // LDS dword offset of the reset path's Philox ring
     int fast_reset = 1;                   // dedicated new-episode kernel where it applies (NGW_FAST_RESET=0: general kernel, A/B)
     NgwResetFast rf{};                    // its arguments, laid out once (layout_reset_fast)
@@ -378,6 +383,24 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     return NGW_OK;
 }
 
+// A fused rollout as launches of at most `prefetch_every` steps with the refill launches between them: with prepared next
+// episodes on, an env's reset inside the launch copies its prepared row - but only the first one, the shadow rows are
+// re-prepared between launches.  Same action stream (keyed by the absolute step), same results as one launch.
+int rollout_chunks(ngw_handle* h, int mode, int32_t n_steps, const int32_t* actions_dev, uint64_t action_seed, int64_t t0, int64_t step_stride) {
+    const int32_t chunk = h->prefetch_every > 0 ? h->prefetch_every : n_steps;
+    for (int32_t done = 0; done < n_steps; done += chunk) {
+        const int32_t k = n_steps - done < chunk ? n_steps - done : chunk;
+        h->proto.row_reward = h->row_reward ? h->row_reward + (int64_t)done * h->row_stride : nullptr;
+        h->proto.row_done = h->row_done ? h->row_done + (int64_t)done * h->row_stride : nullptr;
+        h->proto.row_stride = h->row_stride; h->proto.acc = h->acc;
+        const int rc = mode == NGW_MODE_ROLLOUT ? launch(h, mode, k, nullptr, nullptr, action_seed, t0 + done)
+                                                : launch(h, mode, k, actions_dev + (int64_t)done * step_stride, nullptr, 0, step_stride);
+        h->proto.row_reward = nullptr; h->proto.row_done = nullptr; h->proto.acc = nullptr;
+        if (rc) return rc;
+    }
+    return NGW_OK;
+}
+
 void drop_graph(ngw_handle* h) {
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
@@ -608,6 +631,12 @@ int ngw_set_autoreset(ngw_handle* h, int autoreset, int horizon) {
     if (horizon < 0) return fail(NGW_E_INVALID_ARG, "horizon must be >= 0");
     h->autoreset = autoreset ? 1 : 0;
     h->horizon = horizon;
+    if (!h->prefetch_user) {
+        // Prepared next episodes are the default under autoreset (bit-identical results; a batch whose episode ends are spread
+        // over the steps runs ~3x faster), unless the episodes are too short for a refill every 32 steps to keep up
+        const int every = (h->autoreset && (horizon == 0 || horizon >= 64)) ? 32 : 0;
+        if (every != h->prefetch_every) { const int rc = ngw_set_reset_prefetch(h, every); h->prefetch_user = 0; return rc; }
+    }
     return NGW_OK;
 }
 
@@ -630,6 +659,7 @@ int ngw_set_reset_prefetch(ngw_handle* h, int32_t every_n_steps) {
     HIP_TRY(hipMemcpyAsync(&h->dspec->nx, &on_device, sizeof(NgwNx), hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->prefetch_every = every_n_steps;
+    h->prefetch_user = 1;
     h->since_refill = every_n_steps;                 // the next launch is followed by a refill
     return NGW_OK;
 }
@@ -683,7 +713,7 @@ int ngw_rollout(ngw_handle* h, int32_t n_steps, uint64_t action_seed, int64_t t0
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     if (n_steps < 1) return fail(NGW_E_INVALID_ARG, "n_steps must be >= 1");
     HIP_TRY(hipSetDevice(h->device));
-    return launch(h, NGW_MODE_ROLLOUT, n_steps, nullptr, nullptr, action_seed, t0);
+    return rollout_chunks(h, NGW_MODE_ROLLOUT, n_steps, nullptr, action_seed, t0, 0);
 }
 
 int ngw_rollout_actions(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps) {
@@ -691,7 +721,31 @@ int ngw_rollout_actions(ngw_handle* h, const int32_t* actions_dev, int64_t step_
     if (n_steps < 1) return fail(NGW_E_INVALID_ARG, "n_steps must be >= 1");
     if (step_stride < h->n) return fail(NGW_E_INVALID_ARG, "step_stride %lld is smaller than n_envs", (long long)step_stride);
     HIP_TRY(hipSetDevice(h->device));
-    return launch(h, NGW_MODE_ROLLOUT_ACT, n_steps, actions_dev, nullptr, 0, step_stride);
+    return rollout_chunks(h, NGW_MODE_ROLLOUT_ACT, n_steps, actions_dev, 0, 0, step_stride);
+}
+
+int ngw_rollout_outputs(ngw_handle* h, int32_t* reward_rows_dev, uint8_t* done_rows_dev, int64_t row_stride, int accumulate) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if ((reward_rows_dev || done_rows_dev) && row_stride < h->n) return fail(NGW_E_INVALID_ARG, "row_stride %lld is smaller than n_envs", (long long)row_stride);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->row_reward = reward_rows_dev; h->row_done = done_rows_dev; h->row_stride = row_stride;
+    if (accumulate && !h->acc) { if (int rc = dev_alloc(h, &h->acc, (size_t)h->n_pad * 4)) return rc; }
+    if (!accumulate && h->acc) { dev_free(h, h->acc); h->acc = nullptr; }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NGW_OK;
+}
+
+int ngw_episode_stats(ngw_handle* h, int32_t* run_return, int32_t* run_length, int32_t* sum_return, int32_t* n_episodes, int clear) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (!h->acc) return fail(NGW_E_INVALID_ARG, "ngw_episode_stats before ngw_rollout_outputs(..., accumulate = 1)");
+    HIP_TRY(hipSetDevice(h->device));
+    int32_t* const dst[4] = {run_return, run_length, sum_return, n_episodes};
+    for (int i = 0; i < 4; i++)
+        if (dst[i]) HIP_TRY(hipMemcpyAsync(dst[i], h->acc + (size_t)i * h->n_pad, (size_t)h->n * sizeof(int32_t), hipMemcpyDefault, h->stream));
+    if (clear) HIP_TRY(hipMemsetAsync(h->acc, 0, (size_t)h->n_pad * 4 * sizeof(int32_t), h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NGW_OK;
 }
 
 /* Diagnostics builds (-DNGW_STAMPS): device buffer [grid][16] uint64 the kernels write their clock stamps to; NULL = off. */

@@ -58,6 +58,11 @@ struct NgwLaunch {
     uint32_t magicS;             /* ceil(2^32 / S): cell / S */
     uint32_t off_inv, off_cand, off_act;    /* LDS dword offsets */
     uint64_t* stamps;            /* diagnostics builds (-DNGW_STAMPS): [grid][16] in-kernel clock stamps, or nullptr */
+    /* fused rollouts: per-step output rows and per-env episode accumulators (ngw_rollout_outputs), any of them nullptr */
+    int32_t* row_reward;         /* [n_steps][row_stride]: reward of step t of env e at [t * row_stride + e] */
+    uint8_t* row_done;           /* [n_steps][row_stride]: 1 where the step ended an episode (done, or the horizon under autoreset) */
+    int64_t row_stride;
+    int32_t* acc;                /* [4][n_pad]: return / length of the running episode, sum of returns / count of the finished ones */
 };
 
 /* Uniform step parameters: every lane uses the same value, so the kernel reads them with SCALAR loads straight

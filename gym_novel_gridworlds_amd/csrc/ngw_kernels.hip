@@ -766,6 +766,10 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
         PIN_S(crate_a0); PIN_S(crate_a1); PIN_S(crate_a2);
     }
 
+    // fused rollouts: per-step rows and episode accumulators for whoever consumes the rollout (a learner, an evaluator)
+    const bool rolling = MODE == NGW_MODE_ROLLOUT || MODE == NGW_MODE_ROLLOUT_ACT;
+    int acc_ret = 0, acc_len = 0, acc_sum = 0, acc_eps = 0;
+    if (rolling && a.acc && live) { acc_ret = a.acc[e]; acc_len = a.acc[a.n_pad + e]; acc_sum = a.acc[2 * a.n_pad + e]; acc_eps = a.acc[3 * a.n_pad + e]; }
     STAMP(3);
     for (int t = 0; t < n_steps; t++, tt++) {
         bool do_reset = false;
@@ -1014,6 +1018,12 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                 *gdone = (uint8_t)ended;
                 *ginfo = info;
             }
+            if (rolling) {
+                if (a.row_reward) a.row_reward[(int64_t)t * a.row_stride + e] = reward;
+                if (a.row_done) a.row_done[(int64_t)t * a.row_stride + e] = (uint8_t)ended;
+                acc_ret += reward; acc_len += 1;
+                if (ended) { acc_sum += acc_ret; acc_eps += 1; acc_ret = 0; acc_len = 0; }
+            }
         }
         if (LIDAR) {
             // ---- fused LidarInFront observation of the state this step produced (observation_wrappers.py:67-78)
@@ -1040,6 +1050,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
             a.b.step_count[e] = steps;
         }
         a.b.episode[e] = episode;
+        if (rolling && a.acc) { a.acc[e] = acc_ret; a.acc[a.n_pad + e] = acc_len; a.acc[2 * a.n_pad + e] = acc_sum; a.acc[3 * a.n_pad + e] = acc_eps; }
     }
     if (flags) atomicOr(a.b.flags, flags);
     raise_host_flags(a.b.flags_host, flags);

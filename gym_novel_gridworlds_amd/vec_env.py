@@ -54,13 +54,11 @@ class VecNovelGridworld:
                                  C.byref(self._h)))
         self.autoreset, self.horizon = bool(autoreset), int(horizon)
         _cabi.check(L.ngw_set_autoreset(self._h, int(self.autoreset), self.horizon))
-        self.reset_prefetch = 0
-        if reset_prefetch == 'auto':
-            # autoreset users get prepared next episodes unless the episodes are too short for a refill every 32 steps to keep
-            # up (rows then go stale before they are needed and resets simply run inline, as without the feature)
-            reset_prefetch = 32 if self.autoreset and (self.horizon == 0 or self.horizon >= 64) else 0
         self.lidar, self.lidar_fused, self.lidar_len = None, False, 0      # set by lidar_configure()
-        if reset_prefetch:
+        # 'auto' = the library's own default: ngw_set_autoreset switched prepared next episodes on (a refill every 32 steps)
+        # unless the episodes are too short for that cadence to keep up (rows would go stale and resets simply run inline)
+        self.reset_prefetch = 32 if self.autoreset and (self.horizon == 0 or self.horizon >= 64) else 0
+        if reset_prefetch != 'auto':
             self.set_reset_prefetch(reset_prefetch)
         self._flags_word = C.c_uint32(0)
         self._host = None                                     # host mirrors of the host API: allocated on first use
@@ -99,6 +97,8 @@ class VecNovelGridworld:
     def set_autoreset(self, autoreset, horizon=0):
         self.autoreset, self.horizon = bool(autoreset), int(horizon)
         _cabi.check(_cabi.lib().ngw_set_autoreset(self._h, int(self.autoreset), self.horizon))
+        if not self.__dict__.get('_prefetch_user'):
+            self.reset_prefetch = 32 if self.autoreset and (self.horizon == 0 or self.horizon >= 64) else 0
 
     def set_stream(self, hip_stream_ptr):
         _cabi.check(_cabi.lib().ngw_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
@@ -207,6 +207,7 @@ class VecNovelGridworld:
         are spread over the batch (a few envs per step).  Bit-identical results; 0 switches it off."""
         _cabi.check(_cabi.lib().ngw_set_reset_prefetch(self._h, int(every_n_steps)))
         self.reset_prefetch = int(every_n_steps)
+        self._prefetch_user = True
 
     def rollout(self, n_steps, action_seed=1234, t0=0):
         """Fused mode: n_steps steps in one launch with on-device uniform actions."""
@@ -216,6 +217,19 @@ class VecNovelGridworld:
         """Fused mode with the caller's actions: n_steps steps in one launch, step t reads int32 actions at device address
         actions_ptr + 4 * t * step_stride (e.g. a [T, N] int32 tensor: data_ptr(), N, T)."""
         _cabi.check(_cabi.lib().ngw_rollout_actions(self._h, C.c_void_p(int(actions_ptr)), int(step_stride), int(n_steps)))
+
+    def rollout_outputs(self, reward_rows_ptr=0, done_rows_ptr=0, row_stride=0, accumulate=False):
+        """Per-step outputs of the fused rollouts (include/ngw.h ngw_rollout_outputs): int32 reward rows and uint8 done rows
+        [T, row_stride] in device memory (0 = off), and per-env episode accumulators kept across rollout calls."""
+        _cabi.check(_cabi.lib().ngw_rollout_outputs(self._h, C.c_void_p(int(reward_rows_ptr)) if reward_rows_ptr else None,
+                                                    C.c_void_p(int(done_rows_ptr)) if done_rows_ptr else None, int(row_stride), int(bool(accumulate))))
+
+    def episode_stats(self, clear=False):
+        """dict of int32 [N] host arrays: return / length of the running episodes, sum of returns / count of the finished ones."""
+        out = {k: np.zeros(self.num_envs, np.int32) for k in ('run_return', 'run_length', 'sum_return', 'n_episodes')}
+        _cabi.check(_cabi.lib().ngw_episode_stats(self._h, *[_cabi._ptr(out[k], np.int32) for k in ('run_return', 'run_length', 'sum_return', 'n_episodes')],
+                                                  int(bool(clear))))
+        return out
 
     def sync(self):
         _cabi.check(_cabi.lib().ngw_sync(self._h))

@@ -202,7 +202,10 @@ int ngw_set_autoreset(ngw_handle* h, int autoreset, int horizon);
  * whole launch waits for them.  With every_n_steps > 0 the library keeps, per env, the first state of its NEXT episode
  * in shadow buffers: a reset then copies that row (one memory round trip), and one extra launch every `every_n_steps`
  * batched steps (and after every ngw_reset) re-prepares the rows consumed since.  Results are bit-identical with the
- * feature on or off (the shadow row is the output of the same per-(env, episode) Philox stream).  0 = off (default). */
+ * feature on or off (the shadow row is the output of the same per-(env, episode) Philox stream).  0 = off.
+ * ngw_set_autoreset(h, 1, horizon) switches it ON by itself (a refill every 32 steps; not for horizons under 64 steps, where
+ * rows would go stale before they are needed) unless the caller has chosen a cadence with this call, before or after.
+ * Fused rollouts run as launches of at most every_n_steps steps with the refills between them. */
 int ngw_set_reset_prefetch(ngw_handle* h, int32_t every_n_steps);
 int ngw_set_stream(ngw_handle* h, void* hip_stream);
 
@@ -229,6 +232,16 @@ int ngw_rollout(ngw_handle* h, int32_t n_steps, uint64_t action_seed, int64_t t0
  * batched step t takes int32 actions_dev[t * step_stride + e] (device memory, step_stride >= n_envs).  An action outside
  * [0, n_actions) leaves that env untouched for that step and raises NGW_F_INVALID_ACTION, as in ngw_step_device. */
 int ngw_rollout_actions(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps);
+
+/* Per-step outputs of the fused rollouts, for whoever consumes them (the reference's loop sees (obs, reward, done, info) after
+ * every step: tests/random_action.py:51-64, tests/train.py:122-135).  With rows set, step t of a ngw_rollout /
+ * ngw_rollout_actions call also stores reward_rows_dev[t * row_stride + e] (int32) and done_rows_dev[t * row_stride + e]
+ * (uint8: 1 where the step ended an episode - done, or the horizon under autoreset); either pointer may be NULL, both NULL
+ * switches the rows off.  accumulate = 1 additionally keeps four per-env int32 counters across rollout calls: return and
+ * length of the running episode, sum of returns and number of the episodes finished so far (ngw_episode_stats reads them
+ * into host arrays, any of which may be NULL; clear = 1 zeroes them afterwards).  Device memory, row_stride >= n_envs. */
+int ngw_rollout_outputs(ngw_handle* h, int32_t* reward_rows_dev, uint8_t* done_rows_dev, int64_t row_stride, int accumulate);
+int ngw_episode_stats(ngw_handle* h, int32_t* run_return, int32_t* run_length, int32_t* sum_return, int32_t* n_episodes, int clear);
 
 /* get_observation(): pogostick_v1_env.py:214-228, batched: map i8 [N,S,S], agent_location i32 [N,2] (r,c),
  * agent_facing_id i32 [N], inventory_items_quantity i32 [N,K] in items_id order.  Any pointer may be NULL. */

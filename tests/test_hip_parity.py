@@ -523,3 +523,76 @@ def test_extreme_map_sizes_match_oracle(env_id, S):
 def test_map_size_beyond_lds_budget_is_rejected():
     with pytest.raises(ValueError, match='LDS'):
         VecNovelGridworld(num_envs=64, map_size=60)
+
+
+@pytest.mark.parametrize('cfg,n,T_,horizon,prefetch,supplied', [('pogo10', 2048, 150, 40, 0, False), ('axe10', 1000, 230, 100, 'auto', False),
+                                                               ('bow20', 512, 90, 30, 16, True), ('fire10h', 1024, 100, 25, 0, True)])
+def test_rollout_rows_and_episode_accumulators_match_oracle(cfg, n, T_, horizon, prefetch, supplied):
+    """ngw_rollout_outputs: every step of a fused rollout leaves its reward / done row, and the per-env accumulators (running
+    return / length, sum of returns / count of finished episodes) equal the oracle stepped one step at a time."""
+    import torch
+    spec = T.build_spec(cfg)
+    A = len(spec.actions_id)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=11, autoreset=True, horizon=horizon, reset_prefetch=prefetch)
+    o = Oracle(spec.compile(), n, seed=11, autoreset=True, horizon=horizon)
+    v.reset(); o.reset()
+    stride = n + 7
+    rew = torch.full((T_, stride), -99, dtype=torch.int32, device='cuda')
+    dn = torch.full((T_, stride), 9, dtype=torch.uint8, device='cuda')
+    acts = torch.randint(0, A, (T_, n), dtype=torch.int32, device='cuda')
+    torch.cuda.synchronize()
+    v.rollout_outputs(rew.data_ptr(), dn.data_ptr(), stride, accumulate=True)
+    want_r, want_d = np.zeros((T_, n), np.int32), np.zeros((T_, n), np.uint8)
+    run_ret, run_len, sum_ret, n_eps = (np.zeros(n, np.int64) for _ in range(4))
+    an = acts.cpu().numpy()
+    t = 0
+    for chunk in (1, 3, T_ - 4):                                        # the accumulators carry over rollout calls; rows restart at 0
+        if supplied:
+            v.rollout_actions(acts[t].data_ptr(), n, chunk)
+        else:
+            v.rollout(chunk, action_seed=5, t0=t)
+        for k in range(chunk):
+            if supplied:
+                o.step(an[t + k])
+            else:
+                o.rollout(1, 5, t + k)
+            want_r[t + k], want_d[t + k] = o.reward, o.done
+            run_ret += o.reward; run_len += 1
+            fin = o.done.astype(bool)
+            sum_ret[fin] += run_ret[fin]; n_eps[fin] += 1; run_ret[fin] = 0; run_len[fin] = 0
+        v.sync()
+        got_r, got_d = rew.cpu().numpy(), dn.cpu().numpy()
+        assert (got_r[:chunk, :n] == want_r[t:t + chunk]).all() and (got_d[:chunk, :n] == want_d[t:t + chunk]).all(), (cfg, t)
+        assert (got_r[:, n:] == -99).all() and (got_d[:, n:] == 9).all()             # nothing outside the rows' env columns
+        t += chunk
+    st = v.episode_stats(clear=True)
+    assert (st['run_return'] == run_ret).all() and (st['run_length'] == run_len).all()
+    assert (st['sum_return'] == sum_ret).all() and (st['n_episodes'] == n_eps).all() and n_eps.max() >= 2
+    assert all((x == 0).all() for x in v.episode_stats().values())
+    v.rollout_outputs()                                                  # off again: rollouts leave the rows alone
+    rew.fill_(-7); torch.cuda.synchronize()
+    v.rollout(5, action_seed=5, t0=t); o.rollout(5, 5, t)
+    v.sync()
+    assert (rew.cpu().numpy() == -7).all()
+    assert_state_equal(v, o, cfg + ' after the rows')
+
+
+def test_autoreset_switches_prepared_episodes_on_at_the_c_abi():
+    """ngw_set_autoreset alone (no ngw_set_reset_prefetch) prepares next episodes: staggered episode ends are served from the
+    shadow rows - visible as the refill launches' effect on the shadow tags - and a caller's own cadence (incl. 0) is kept."""
+    import ctypes as C
+    from gym_novel_gridworlds_amd import _cabi
+    v = VecNovelGridworld(num_envs=256, seed=1)                          # autoreset off: nothing prepared
+    L = _cabi.lib()
+    assert v.reset_prefetch == 0
+    _cabi.check(L.ngw_set_autoreset(v._h, 1, 100))
+    o = Oracle(v.spec.compile(), 256, seed=1, autoreset=True, horizon=100)
+    v.reset(); o.reset()
+    v.rollout(230, action_seed=3); o.rollout(230, 3, 0)
+    assert_state_equal(v, o, 'default cadence')
+    v.set_reset_prefetch(0)                                             # the caller's choice survives another ngw_set_autoreset
+    _cabi.check(L.ngw_set_autoreset(v._h, 1, 80))
+    o.horizon = 80
+    v.rollout(200, action_seed=3, t0=230); o.rollout(200, 3, 230)
+    assert_state_equal(v, o, 'caller cadence kept')
+    assert v.error_flags() == 0
