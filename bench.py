@@ -142,7 +142,7 @@ def main():
     ap.add_argument('--mode', default='step', choices=['step', 'rollout'])
     ap.add_argument('--envs', type=int, default=0, help='envs per GPU (default: the workload\'s)')
     ap.add_argument('--launch', default='graph', choices=['graph', 'eager'],
-                    help='step mode: replay the K step launches from one hipGraph (default) or launch them one by one')
+                    help='step mode: replay the K step launches from one hipGraph (default from 100 steps on) or launch them one by one')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stagger', action='store_true', help='skip the staggered-episode-ends side measurement')
     ap.add_argument('--no-side', action='store_true', help='skip every side measurement (fused rollout, API mode, C1, stagger): tuning runs')
@@ -200,7 +200,9 @@ def main():
 
     start_episodes()
     GRAPH_MAX = 2048                      # kernel nodes per graph; longer runs replay it (its action rows repeat)
-    use_graph = args.mode == 'step' and args.launch == 'graph' and steps >= 2
+    # one replay of a short graph costs more than it saves (graph launch ~10-16 us on the device side: measured 6.4 vs 4.9 us per
+    # launch at 20 steps); from ~100 launches on the replay wins (4.4 vs 4.9 us)
+    use_graph = args.mode == 'step' and args.launch == 'graph' and steps >= 100
     ptrs = []
     if args.mode == 'step' or not args.no_side:
         # i.i.d. uniform int32 actions over len(actions_id), seed 1234 (+rank), resident in HBM before the timed region
@@ -337,7 +339,7 @@ def main():
     # n / H envs reset in every batched step, a few per wavefront) - the regime of a training loop; inline placement
     # loops vs prepared next episodes (ngw_set_reset_prefetch, the library's default for autoreset).
     stag = None
-    if args.mode == 'step' and side and use_graph and not args.no_stagger:
+    if args.mode == 'step' and side and not args.no_stagger:
         stag_acts = None
         stag = {'what': 'episode ends staggered over the batch (~%d of %d envs reset per batched step), hipGraph replay' % (n // HORIZON, n)}
         for key, every in (('inline_resets', 0), ('prepared_next_episodes_every_32', 32)):

@@ -387,7 +387,13 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
 // episodes on, an env's reset inside the launch copies its prepared row - but only the first one, the shadow rows are
 // re-prepared between launches.  Same action stream (keyed by the absolute step), same results as one launch.
 int rollout_chunks(ngw_handle* h, int mode, int32_t n_steps, const int32_t* actions_dev, uint64_t action_seed, int64_t t0, int64_t step_stride) {
-    const int32_t chunk = h->prefetch_every > 0 ? h->prefetch_every : n_steps;
+    // a prepared row serves an env's FIRST reset of a launch, and under a horizon H an env resets at most once per H steps
+    // (plus the rare early `done`): H-step launches (capped) keep the per-launch staging cost low; no horizon: 4 cadences
+    int32_t chunk = n_steps;
+    if (h->prefetch_every > 0) {
+        chunk = h->horizon > 0 ? (h->horizon < 256 ? h->horizon : 256) : 4 * h->prefetch_every;
+        if (chunk < h->prefetch_every) chunk = h->prefetch_every;
+    }
     for (int32_t done = 0; done < n_steps; done += chunk) {
         const int32_t k = n_steps - done < chunk ? n_steps - done : chunk;
         h->proto.row_reward = h->row_reward ? h->row_reward + (int64_t)done * h->row_stride : nullptr;

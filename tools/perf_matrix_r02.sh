@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round-2 performance matrix: the default bench line of every workload (with its side measurements), the driver-style short
+# run, the 2-rank rehearsal of the multi-GPU leg on one GPU, reset launch times and the in-kernel timelines.
+OUT=gpurun_out/matrix_r02; rm -rf $OUT; mkdir -p $OUT
+for W in C2 C3 C4 C5; do
+  timeout -k 10 300 python bench.py --workload $W > $OUT/bench_$W.log 2>&1 || echo "bench $W failed"
+  grep '^{' $OUT/bench_$W.log | tail -1 > $OUT/bench_$W.json
+done
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_C2_driver_style.log 2>&1; grep '^{' $OUT/bench_C2_driver_style.log | tail -1 > $OUT/bench_C2_driver_style.json
+for W in C4 C5; do
+  timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --single-device --workload $W --no-cpu-baseline --steps 400 > $OUT/bench_2rank_$W.log 2>&1; grep '^{' $OUT/bench_2rank_$W.log | tail -1 > $OUT/bench_2rank_$W.json
+done
+timeout -k 10 300 python tools/reset_time.py > $OUT/reset_time.log 2>&1
+NGW_FAST_RESET=0 timeout -k 10 300 python tools/reset_time.py > $OUT/reset_time_general.log 2>&1
+timeout -k 10 100 python tools/adapter_latency.py > $OUT/adapter.log 2>&1
+timeout -k 10 200 python tools/api_latency.py > $OUT/api.log 2>&1
+if [ -f gym_novel_gridworlds_amd/libngw_hip_stamps.so ]; then
+  NGW_LIB=$PWD/gym_novel_gridworlds_amd/libngw_hip_stamps.so timeout -k 10 300 python tools/stamp_timeline.py C2 C3 C4 C5 > $OUT/stamps.log 2>&1
+  NGW_LIB=$PWD/gym_novel_gridworlds_amd/libngw_hip_stamps.so NGW_LEAN=0 timeout -k 10 300 python tools/stamp_timeline.py C2 > $OUT/stamps_general.log 2>&1
+fi
+echo matrix done

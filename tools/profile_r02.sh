@@ -1,0 +1,33 @@
+#!/bin/bash
+# Profiling recipe of round 2 (run on the GPU box through gpurun, from the repo root; ~6 minutes):
+#   1. rocprofv3 --kernel-trace --stats of the bench command, every workload (step mode) + the fused rollout at C2
+#   2. HBM traffic counters in SEPARATE passes (FETCH_SIZE, then WRITE_SIZE: the TCC slots do not fit both), step mode of
+#      every workload + the C2 rollout, and the same counters on the staging-only diagnostic kernel at 1 Mi envs whose byte
+#      count is known exactly (calibrates FETCH_SIZE: gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md §HBM)
+#   3. SQ counters (wave cycles, waiting, issue mix) of the C2 step kernel and of the C2 fused rollout
+# Outputs land in gpurun_out/prof_r02/ ; tools/parse_r02.py turns them into profiles/r02_*.md + profiles/pmc_traffic.json.
+OUT=gpurun_out/prof_r02
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+B="python3 bench.py --no-cpu-baseline --no-side --steps 400 --warmup 100"
+for W in C2 C3 C4 C5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -- $B --workload $W > $OUT/stats_$W.log 2>&1 || echo "stats $W failed"
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_C2_rollout -- $B --mode rollout > $OUT/stats_C2_rollout.log 2>&1 || echo "stats rollout failed"
+P="python3 bench.py --no-cpu-baseline --no-side --steps 60 --warmup 10 --launch eager"
+for c in FETCH_SIZE WRITE_SIZE; do
+  for W in C2 C3 C4 C5; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${W}_$c -- $P --workload $W > $OUT/pmc_${W}_$c.log 2>&1 || echo "pmc $W $c failed"
+  done
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_C2rollout_$c -- $P --mode rollout > $OUT/pmc_C2rollout_$c.log 2>&1 || echo "pmc rollout $c failed"
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_calib_$c -- python3 tools/dbg_launch.py calib > $OUT/pmc_calib_$c.log 2>&1 || echo "pmc calib $c failed"
+done
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/sq_step_$i -- $P > $OUT/sq_step_$i.log 2>&1 || echo "sq step $i failed"
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/sq_rollout_$i -- python3 bench.py --no-cpu-baseline --no-side --steps 200 --warmup 20 --mode rollout --reset-prefetch 0 > $OUT/sq_rollout_$i.log 2>&1 || echo "sq rollout $i failed"
+done
+find $OUT -name "*.db" -delete 2>/dev/null
+du -sh $OUT
+echo profile_r02 done
