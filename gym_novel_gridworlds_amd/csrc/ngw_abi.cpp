@@ -104,7 +104,7 @@ int check_spec(const ngw_spec* s) {
     auto item_ok = [&](int i) { return i >= 0 && i < K; };
     if (!item_ok(s->wall_item) || !item_ok(s->table_item) || !item_ok(s->goal_item) || !item_ok(s->place_item) ||
         !item_ok(s->place_near) || !item_ok(s->ext_src) || !item_ok(s->ext_near) || !item_ok(s->ext_out) ||
-        !item_ok(s->axe_item) || !item_ok(s->additem_item) || !item_ok(s->tap_item) ||
+        !item_ok(s->axe_item) || !item_ok(s->tap_item) ||
         !item_ok(s->tap_near))
         return fail(NGW_E_INVALID_ARG, "spec item id out of range");
     if (s->n_inv_start > NGW_MAX_INV_START) return fail(NGW_E_INVALID_ARG, "n_inv_start %d out of range", s->n_inv_start);
@@ -142,24 +142,24 @@ int check_spec(const ngw_spec* s) {
                 if (s->recipe_in_item[r][j] == s->recipe_in_item[r][k]) return fail(NGW_E_INVALID_ARG, "recipe %d lists an input twice", r);
         }
     auto pct_ok = [](int lo, int hi) { return lo < hi && hi - lo <= 64 && hi <= 100; };
-    if (s->additem_item && !pct_ok(s->additem_pct_lo, s->additem_pct_hi)) return fail(NGW_E_INVALID_ARG, "additem percent range invalid");
-    if (s->replace_to && !pct_ok(s->replace_pct_lo, s->replace_pct_hi)) return fail(NGW_E_INVALID_ARG, "replace percent range invalid");
-    if (s->fence_item && !pct_ok(s->fence_pct_lo, s->fence_pct_hi)) return fail(NGW_E_INVALID_ARG, "fence percent range invalid");
-    if (!item_ok(s->replace_from) || !item_ok(s->replace_to) || !item_ok(s->fence_item) || !item_ok(s->fire_item) ||
-        !item_ok(s->crate_item) || s->fence_mode > 2)
+    if (s->n_passes > NGW_MAX_PASSES) return fail(NGW_E_INVALID_ARG, "n_passes %d out of range", s->n_passes);
+    for (int j = 0; j < s->n_passes; j++) {
+        const int kind = s->pass_kind[j];
+        if (kind < NGW_PASS_ADDITEM || kind > NGW_PASS_FENCE) return fail(NGW_E_INVALID_ARG, "reset pass %d has unknown kind %d", j, kind);
+        if (!item_ok(s->pass_item[j]) || !s->pass_item[j] || !item_ok(s->pass_from[j])) return fail(NGW_E_INVALID_ARG, "reset pass %d: item id out of range", j);
+        if (!pct_ok(s->pass_pct_lo[j], s->pass_pct_hi[j]))
+            return fail(NGW_E_INVALID_ARG, "%s percent range invalid", kind == NGW_PASS_ADDITEM ? "additem" : kind == NGW_PASS_REPLACE ? "replace" : "fence");
+        if (kind == NGW_PASS_FENCE)     /* a fence pass after a wall-replacing pass would fence border cells: add_fence_around leaves the map (reference: IndexError) */
+            for (int i = 0; i < j; i++)
+                if (s->pass_kind[i] == NGW_PASS_REPLACE && s->pass_from[i] == s->wall_item)
+                    return fail(NGW_E_INVALID_ARG, "fence pass after a wall-replacing pass edits cells outside the map");
+    }
+    if (!item_ok(s->fence_item) || !item_ok(s->fire_item) || !item_ok(s->crate_item) || s->fence_mode > 2)
         return fail(NGW_E_INVALID_ARG, "novelty item id / fence_mode out of range");
     for (int i = 0; i < NGW_MAX_ITEMS; i++)
         if (s->crate_add[i] && (i >= K || !s->crate_item || s->crate_add[i] > 15)) return fail(NGW_E_INVALID_ARG, "crate_add[%d] invalid", i);
     if (s->fence_mode && !s->fence_item) return fail(NGW_E_INVALID_ARG, "fence_mode without fence_item");
     if (s->ext_flags > 3 || s->fire_skip_recipe > s->n_recipes) return fail(NGW_E_INVALID_ARG, "ext_flags / fire_skip_recipe out of range");
-    if ((1 << s->pass_order[0] | 1 << s->pass_order[1] | 1 << s->pass_order[2]) != 0xE)
-        return fail(NGW_E_INVALID_ARG, "pass_order must be a permutation of {1, 2, 3}");
-    if (s->fence_item && s->replace_to && s->replace_from == s->wall_item) {
-        int at_replace = 0, at_fence = 0;
-        for (int j = 0; j < 3; j++) { if (s->pass_order[j] == 2) at_replace = j; if (s->pass_order[j] == 3) at_fence = j; }
-        if (at_replace < at_fence)      /* the fence pass would fence border cells: add_fence_around leaves the map (reference: IndexError) */
-            return fail(NGW_E_INVALID_ARG, "fence pass after a wall-replacing pass edits cells outside the map");
-    }
     return NGW_OK;
 }
 
@@ -211,7 +211,7 @@ int layout_lds(ngw_handle* h) {
     p.off_cand = off; off += (uint32_t)(p.CW * NGW_EPB);
     p.off_act = off; off += (uint32_t)(NGW_MAX_ACTIONS * NGW_ACT_DW + NGW_MAX_PLACE / 4);
     p.perm_lds = 0; p.off_perm = off;
-    if (h->spec.additem_item || h->spec.replace_to || h->spec.fence_item) {
+    if (h->spec.n_passes) {
         // Shuffle array in LDS only while the wave's LDS stays small (<= 32 KiB, 5 waves/CU).  Measured at S = 32: the
         // extra 64 KiB halves the resident waves per CU and costs more (step 50 -> 115 us) than the HBM scratch column.
         const uint32_t perm_dw = (uint32_t)(S2 * 32 * 2 / 4);
@@ -233,7 +233,7 @@ int layout_lds(ngw_handle* h) {
     // The ring is used when the reset has no shuffled-subset pass (those draw hundreds of words per lane: register blocks,
     // PhiloxRegs) and when its LDS does not cost a resident wave per CU (C5: 76 KB + 8 KB would halve the occupancy).
     {
-        const bool passes = h->spec.additem_item || h->spec.replace_to || h->spec.fence_item;
+        const bool passes = h->spec.n_passes != 0;
         auto waves_per_cu = [](uint32_t dwords) { return (160u * 1024u) / (((dwords * 4u + 511u) / 512u) * 512u); };
         h->off_rng = 0xFFFFFFFFu;                                  // = PhiloxRegs
         if (!passes) {
@@ -261,11 +261,10 @@ int upload_reset_u(ngw_handle* h) {
     int n_place = 0;
     for (int j = 0; j < s.n_start; j++) n_place += s.start_qty[j];
     ru.n_place = (uint8_t)n_place;
-    ru.additem_item = s.additem_item; ru.additem_span = (uint8_t)(s.additem_pct_hi - s.additem_pct_lo);
-    ru.replace_from = s.replace_from; ru.replace_to = s.replace_to; ru.replace_span = (uint8_t)(s.replace_pct_hi - s.replace_pct_lo);
-    ru.fence_item = s.fence_item; ru.fence_span = (uint8_t)(s.fence_pct_hi - s.fence_pct_lo);
-    ru.n_inv_start = s.n_inv_start;
-    for (int j = 0; j < 3; j++) ru.pass_order[j] = s.pass_order[j];
+    ru.n_passes = s.n_passes; ru.n_inv_start = s.n_inv_start;
+    for (int j = 0; j < s.n_passes; j++)
+        ru.pass[j] = (uint32_t)s.pass_kind[j] | ((uint32_t)s.pass_item[j] << 8) | ((uint32_t)s.pass_from[j] << 16) |
+                     ((uint32_t)(s.pass_pct_hi[j] - s.pass_pct_lo[j]) << 24);
     for (int j = 0; j < NGW_MAX_INV_START; j++) { ru.inv_start_item[j] = s.inv_start_item[j]; ru.inv_start_qty[j] = s.inv_start_qty[j]; }
     HIP_TRY(hipMemcpyAsync(&h->dspec->ru, &ru, sizeof(ru), hipMemcpyDefault, h->stream));
     NgwLaunch lp = h->proto;                                   // what the lean kernel's cold path reads instead of its kernarg
@@ -288,11 +287,12 @@ int upload_reset_u(ngw_handle* h) {
 void layout_reset_fast(ngw_handle* h) {
     const ngw_spec& s = h->spec;
     h->rf_nw = -1;
-    if (!h->fast_reset || s.tap_item || s.replace_to || s.fence_item) return;     // other reset passes: general kernel
+    const bool additem_only = s.n_passes == 1 && s.pass_kind[0] == NGW_PASS_ADDITEM;
+    if (!h->fast_reset || s.tap_item || (s.n_passes && !additem_only)) return;    // other reset passes: general kernel
     const int S = s.map_size, S2 = S * S, CW = h->proto.CW;
     // measured (tools/reset_time.py, all 65 536 envs): 10 x 10 plain 26.8 us vs 23.6 us in the general kernel, 20 x 20 24.9 vs 37.4,
     // 32 x 32 + AddItem 1.65 vs 1.87 ms - small plain maps stay with the general kernel (NGW_FAST_RESET=2 forces this one)
-    if (CW <= 2 && !s.additem_item && h->fast_reset < 2) return;
+    if (CW <= 2 && !additem_only && h->fast_reset < 2) return;
     NgwResetFast& a = h->rf;
     a = NgwResetFast{};
     int n_place = 0;
@@ -305,15 +305,15 @@ void layout_reset_fast(ngw_handle* h) {
     a.off_tmpl = off; off += (uint32_t)((2 * S2 + 16 + NGW_MAX_PLACE + 3) / 4);
     off = (off + 3u) & ~3u;
     a.off_perm = off;
-    if (s.additem_item) off += (uint32_t)(((S - 2) * (S - 2) + 1) * NGW_EPB * 2 / 4);   // + one spare row (rejected / idle lanes store there)
+    if (additem_only) off += (uint32_t)(((S - 2) * (S - 2) + 1) * NGW_EPB * 2 / 4);   // + one spare row (rejected / idle lanes store there)
     if ((size_t)off * 4 > 160 * 1024) return;                                       // the shuffle array does not fit: general kernel
     h->rf_lds = (size_t)off * 4;
-    h->rf_nw = nw; h->rf_additem = s.additem_item ? 1 : 0;
+    h->rf_nw = nw; h->rf_additem = additem_only ? 1 : 0;
     a.main = h->b; a.nx = h->nx;
-    a.pctq = reinterpret_cast<const double*>(h->dspec->pctq[NGW_PASS_ADDITEM]);
+    a.pctq = reinterpret_cast<const double*>(h->dspec->pctq[0]);
     a.n = h->n; a.env_base = h->env_base; a.seed = h->seed; a.flags = h->b.flags;
     a.S = S; a.S2 = S2; a.K = s.n_items; a.CW = CW; a.n_place = n_place; a.wall_item = s.wall_item;
-    a.additem_item = s.additem_item; a.additem_span = s.additem_pct_hi - s.additem_pct_lo;
+    a.additem_item = additem_only ? s.pass_item[0] : 0; a.additem_span = additem_only ? s.pass_pct_hi[0] - s.pass_pct_lo[0] : 1;
     a.n_inv_start = s.n_inv_start;
     for (int j = 0; j < NGW_MAX_INV_START; j++) {
         a.inv_start_items |= (uint32_t)s.inv_start_item[j] << (8 * j);
@@ -479,7 +479,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     if (!rc && h->hostres) rc = state_alloc(h, &h->b.flags_host, 1);
     if (!rc) rc = dev_alloc(h, &h->actions_dev, np);
     if (!rc) rc = dev_alloc(h, &h->mask_dev, np);
-    if (!rc && (spec->additem_item || spec->replace_to || spec->fence_item)) rc = dev_alloc(h, &h->b.perm, np * S2);   // HBM fallback for maps too big for the LDS shuffle
+    if (!rc && spec->n_passes) rc = dev_alloc(h, &h->b.perm, np * S2);   // HBM fallback for maps too big for the LDS shuffle
     if (!rc) rc = dev_alloc(h, &h->dspec, 1);
     if (rc) return bail(rc);
     {
@@ -491,11 +491,8 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
         hs.x.nest = (uint32_t)spec->ext_flags | ((uint32_t)spec->fire_skip_recipe << 8);
         for (int i = 0; i < K; i++) hs.x.crate_add[i >> 3] |= (uint32_t)(spec->crate_add[i] & 15u) << (4 * (i & 7));
         h->ext = (spec->fire_item || spec->fence_mode || spec->crate_item) ? 1 : 0;
-        for (int i = 0; i < 64; i++) {
-            hs.pctq[NGW_PASS_ADDITEM][i] = (double)(spec->additem_pct_lo + i) / 100.0;
-            hs.pctq[NGW_PASS_REPLACE][i] = (double)(spec->replace_pct_lo + i) / 100.0;
-            hs.pctq[NGW_PASS_FENCE][i] = (double)(spec->fence_pct_lo + i) / 100.0;
-        }
+        for (int j = 0; j < spec->n_passes; j++)
+            for (int i = 0; i < 64; i++) hs.pctq[j][i] = (double)(spec->pass_pct_lo[j] + i) / 100.0;
         NgwStepU& u = hs.u;
         for (int i = 0; i < K; i++) {
             if (spec->breakable[i]) u.brk_mask |= 1u << i;

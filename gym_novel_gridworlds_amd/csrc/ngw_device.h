@@ -13,8 +13,6 @@ enum { NGW_MODE_STEP = 0, NGW_MODE_RESET = 1, NGW_MODE_ROLLOUT = 2,
        NGW_MODE_DBG_NOP = 8 /* exit at once: launch floor */, NGW_MODE_DBG_COPY = 9 /* stage in/out, no step logic */ };
 /* how a wave's map chunk is laid out in LDS: same image as HBM / odd-dword-padded rows / byte-granular (odd S) */
 enum { NGW_MAP_STRAIGHT = 0, NGW_MAP_DWORD = 1, NGW_MAP_BYTE = 2 };
-/* shuffled-subset reset passes: AddItem / Crate, ReplaceItem / FireWall, Fence / FenceRestriction */
-enum { NGW_PASS_ADDITEM = 0, NGW_PASS_REPLACE = 1, NGW_PASS_FENCE = 2 };
 
 /* Device buffers of one handle.  map/loc/facing/inv are the batched observation AND the state, updated IN PLACE:
  * a step writes through only the bytes it changes (a map cell, a few inventory slots, the agent pose); a reset
@@ -123,13 +121,12 @@ struct NgwResetU {
     int32_t S, S2, K, CW, perm_lds;
     uint32_t magicS;
     uint32_t off_rng;     /* LDS dword offset of the Philox word ring [32][64] of the reset path */
-    /* the bytes of ngw_spec the reset reads, packed (6 dwords): fetched together with the rest of this struct, so the
+    /* the bytes of ngw_spec the reset reads, packed (8 dwords): fetched together with the rest of this struct, so the
      * reset never waits on one more dependent load of the spec for each optional pass */
     uint8_t wall_item, tap_item, tap_near, n_place;
-    uint8_t additem_item, additem_span, replace_from, replace_to;
-    uint8_t replace_span, fence_item, fence_span, n_inv_start;
+    uint8_t n_passes, n_inv_start, _pad[2];
     uint8_t inv_start_item[NGW_MAX_INV_START], inv_start_qty[NGW_MAX_INV_START];
-    uint8_t pass_order[3], _pad[1];
+    uint32_t pass[NGW_MAX_PASSES];         /* kind | item << 8 | from << 16 | percent span << 24 of each shuffled-subset pass */
 };
 
 /* Uniform parameters of the step-time novelty predicates (kernel template flag EXT): FireWall, FenceRestriction, Crate */
@@ -161,7 +158,7 @@ struct NgwDevSpec {
     NgwExtU x;
     NgwNx nx;
     NgwResetU ru;
-    double pctq[3][64];          /* per reset pass (NGW_PASS_*): pct / 100.0 for pct in [pct_lo, pct_hi) as the host's IEEE double */
+    double pctq[NGW_MAX_PASSES][64];   /* per reset pass: pct / 100.0 for pct in [pct_lo, pct_hi) as the host's IEEE double */
 };
 
 #ifdef __cplusplus

@@ -27,6 +27,7 @@
 #include "../../include/ngw.h"
 #include "ngw_device.h"
 
+static_assert(NGW_MAX_PASSES == 4, "ResetArgs carries four pass words");
 static_assert(sizeof(NgwDevSpec) % 4 == 0, "the spec blob is copied to LDS by dwords");
 
 namespace {
@@ -179,8 +180,8 @@ struct ResetArgs {
     uint64_t seed;
     int S, S2, K, CW, perm_lds;
     uint32_t magicS;                // ceil(2^32 / S): cell / S for cell < S*S
-    uint32_t rs0, rs1, rs2, rs3, rs4, rs5;   // NgwResetU's packed spec bytes (rs5 = pass_order): wall|tap|tap_near|n_place, additem|span|repl_from|repl_to,
-                                        // repl_span|fence|fence_span|n_inv_start, inv_start_item[4], inv_start_qty[4]
+    uint32_t rs0, rs1, rs2, rs3;             // NgwResetU's packed spec bytes: wall|tap|tap_near|n_place, n_passes|n_inv_start, inv_start_item[4], inv_start_qty[4]
+    uint32_t pw0, pw1, pw2, pw3;              // shuffled-subset passes: kind | item << 8 | from << 16 | span << 24
 };
 
 // The shuffled-subset reset passes - AddItem.reset (novelty_wrappers.py:1017-1028), ReplaceItem.reset (:1131-1144),
@@ -215,9 +216,9 @@ __device__ __forceinline__ void subset_pass(P perm, int64_t ps, RNG& px, MP mp, 
 }
 
 template <int KIND, class RNG, typename MP>
-__device__ __forceinline__ void run_pass(const ResetArgs& a, LDS_AS uint16_t* perm_lds, int64_t env_local, RNG& px, MP mp,
+__device__ __forceinline__ void run_pass(const ResetArgs& a, int pass_index, LDS_AS uint16_t* perm_lds, int64_t env_local, RNG& px, MP mp,
                                          int agent, int match, int item, int pct_span) {
-    const GLOBAL_AS double* pctq = (const GLOBAL_AS double*)a.dspec->pctq[KIND];
+    const GLOBAL_AS double* pctq = (const GLOBAL_AS double*)a.dspec->pctq[pass_index];
     if (a.perm_lds) {
         // shuffle array in LDS, [i][32 lanes] u16: the two halves of the wave take turns (a wave executes divergent
         // halves one after the other and its LDS operations are in order, so they can share the region)
@@ -239,8 +240,7 @@ __device__ __forceinline__ uint32_t reset_lane(const ResetArgs a, MP mp, LDS_AS 
                                             uint64_t env_global, int64_t env_local, uint32_t episode) {
     // the spec bytes this path needs arrived with the call's other uniform arguments (no dependent spec loads in here)
     const int wall_item = a.rs0 & 255, tap_item = (a.rs0 >> 8) & 255, tap_near = (a.rs0 >> 16) & 255, n_place = a.rs0 >> 24;
-    const int additem_item = a.rs1 & 255, additem_span = (a.rs1 >> 8) & 255, replace_from = (a.rs1 >> 16) & 255, replace_to = a.rs1 >> 24;
-    const int replace_span = a.rs2 & 255, fence_item = (a.rs2 >> 8) & 255, fence_span = (a.rs2 >> 16) & 255, n_inv_start = a.rs2 >> 24;
+    const int n_passes = a.rs1 & 255, n_inv_start = (a.rs1 >> 8) & 255;
     int r_out, c_out, f_out;
     const int S = a.S, K = a.K, W = S - 4, ncand = W * W;
     const uint32_t magicW = (uint32_t)((0x100000000ull + (uint32_t)W - 1) / (uint32_t)W);   // pos / W == umulhi(pos, magicW), pos < 2^12
@@ -316,18 +316,19 @@ __device__ __forceinline__ uint32_t reset_lane(const ResetArgs a, MP mp, LDS_AS 
             }
         }
     }
-    if ((additem_item | replace_to | fence_item) && !flags)
-        for (int j = 0; j < 3; j++) {                                              // stacked wrappers reset innermost first
-            const int kind = (a.rs5 >> (8 * j)) & 255;
-            if (kind == 1 && additem_item)                                         // AddItem / Crate
-                run_pass<NGW_PASS_ADDITEM>(a, perm_lds, env_local, px, mp, agent, 0, additem_item, additem_span);
-            if (kind == 2 && replace_to)                                           // ReplaceItem / FireWall
-                run_pass<NGW_PASS_REPLACE>(a, perm_lds, env_local, px, mp, agent, replace_from, replace_to, replace_span);
-            if (kind == 3 && fence_item)                                           // Fence / FenceRestriction
-                run_pass<NGW_PASS_FENCE>(a, perm_lds, env_local, px, mp, agent, wall_item, fence_item, fence_span);
+    if (n_passes && !flags)
+        for (int j = 0; j < n_passes; j++) {                                       // stacked wrappers reset innermost first = injection order
+            const uint32_t w = j == 0 ? a.pw0 : (j == 1 ? a.pw1 : (j == 2 ? a.pw2 : a.pw3));
+            const int kind = w & 255, item = (w >> 8) & 255, from = (w >> 16) & 255, span = w >> 24;
+            if (kind == NGW_PASS_ADDITEM)                                          // AddItem / Crate
+                run_pass<NGW_PASS_ADDITEM>(a, j, perm_lds, env_local, px, mp, agent, 0, item, span);
+            else if (kind == NGW_PASS_REPLACE)                                     // ReplaceItem / FireWall
+                run_pass<NGW_PASS_REPLACE>(a, j, perm_lds, env_local, px, mp, agent, from, item, span);
+            else                                                                   // Fence / FenceRestriction
+                run_pass<NGW_PASS_FENCE>(a, j, perm_lds, env_local, px, mp, agent, wall_item, item, span);
         }
     if (!flags)                                                                    // AxeEasy.reset :33, AxetoBreakHard.reset :667-670
-        for (int j = 0; j < n_inv_start; j++) inv[(a.rs3 >> (8 * j)) & 255u] = (int)((a.rs4 >> (8 * j)) & 255u);
+        for (int j = 0; j < n_inv_start; j++) inv[(a.rs2 >> (8 * j)) & 255u] = (int)((a.rs3 >> (8 * j)) & 255u);
     return flags | ((uint32_t)r_out << 8) | ((uint32_t)c_out << 16) | ((uint32_t)f_out << 24);
 }
 
@@ -398,12 +399,12 @@ __device__ __noinline__ uint32_t new_episode(const NgwDevSpec* dspec, LDS_AS int
     ru.perm = rp->perm; ru.map = rp->map; ru.inv = rp->inv; ru.n_pad = rp->n_pad; ru.seed = rp->seed; ru.S = rp->S;
     ru.S2 = rp->S2; ru.K = rp->K; ru.CW = rp->CW; ru.perm_lds = rp->perm_lds; ru.magicS = rp->magicS; ru.off_rng = rp->off_rng;
     const GLOBAL_AS uint32_t* rsw = (const GLOBAL_AS uint32_t*)&rp->wall_item;
-    const uint32_t rs0 = rsw[0], rs1 = rsw[1], rs2 = rsw[2], rs3 = rsw[3], rs4 = rsw[4], rs5 = rsw[5];
+    const uint32_t rs0 = rsw[0], rs1 = rsw[1], rs2 = rsw[2], rs3 = rsw[3], pw0 = rsw[4], pw1 = rsw[5], pw2 = rsw[6], pw3 = rsw[7];
     nx.map = np->map; nx.loc = np->loc; nx.facing = np->facing; nx.inv = np->inv; nx.episode = np->episode;
     if (may_consume && nx.episode && ((const GLOBAL_AS uint32_t*)nx.episode)[env_local] == episode)
         return consume_lane(nx, mp, inv, (GLOBAL_AS int8_t*)ru.map + env_local * ru.S2, (GLOBAL_AS int32_t*)ru.inv + env_local * ru.K,
                             env_local, ru.S2, ru.K) | NGW_F_ROWS_STORED;
-    const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS, rs0, rs1, rs2, rs3, rs4, rs5};
+    const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS, rs0, rs1, rs2, rs3, pw0, pw1, pw2, pw3};
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_base[];            // the kernel's dynamic LDS (offset 0)
     if (ru.off_rng != 0xFFFFFFFFu)                                                 // which word source: decided with the LDS layout (ngw_abi.cpp)
         return reset_lane<PhiloxRing>(a, mp, inv, cand, place_seq, perm_lds, (LDS_AS uint32_t*)(lds_base + ru.off_rng + threadIdx.x),

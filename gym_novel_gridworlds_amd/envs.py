@@ -110,7 +110,7 @@ class _NovelGridworldEnv(_EnvBase):
         return (int(self.map_size), id(self.items_id), len(self.items_id), id(self.actions_id), len(self.actions_id), id(self.items_quantity),
                 tuple(self.items_quantity.values()), id(self.entities), len(self.entities), id(self.recipes), len(self.recipes),
                 id(self.unbreakable_items), len(self.unbreakable_items), self.goal_item_to_craft, self.reward_done, self.reward_intermediate,
-                len(sp.novelties), id(sp.axe), id(sp.additem), id(sp.replace), id(sp.fence), id(sp.crate), sp.fire_wall, sp.break_increase)
+                len(sp.novelties), id(sp.axe), id(sp.additem), id(sp.replace), id(sp.fence), id(sp.fence_pred), len(sp.reset_passes), id(sp.crate), sp.fire_wall, sp.break_increase)
 
     def _backend(self, full_check=False):
         fp = self._fingerprint()
@@ -119,7 +119,7 @@ class _NovelGridworldEnv(_EnvBase):
         sp = self._sync_spec()      # callers may REBIND the public tables (env.items_quantity = {...}): the spec follows the env's attributes
         key = (sp.map_size, tuple(sp.items_id.items()), tuple(sp.actions_id.items()), tuple(sp.items_quantity.items()),
                tuple(sorted(sp.entities)), repr(sp.axe), repr(sp.additem), repr(sp.start_inventory), sp.reward_done,
-               sp.reward_intermediate, repr(sp.replace), repr(sp.fence), repr(sp.fire_wall), repr(sp.crate),
+               sp.reward_intermediate, repr(sp.replace), repr(sp.fence), repr(sp.fence_pred), repr(sp.reset_passes), repr(sp.fire_wall), repr(sp.crate),
                tuple(sorted(sp.unbreakable_items)), repr(sp.recipes), repr(sp.break_increase))
         if self._vec is None or key != self._vec_key:
             # a handle per compiled spec, kept: the reference's own loop (tests/random_action.py:51-64) changes map_size every

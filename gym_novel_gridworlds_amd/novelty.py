@@ -16,6 +16,7 @@ NOVELTY_NAMES = ['addchop', 'additem', 'addjump', 'axe', 'axetobreak', 'breakinc
                  'fence', 'fencerestriction', 'firewall', 'remapaction', 'replaceitem']
 _NEEDS_DIFFICULTY = ['additem', 'axe', 'axetobreak', 'crate', 'fence', 'fencerestriction', 'firewall', 'remapaction',
                      'replaceitem']
+MAX_PASSES = 4                  # = include/ngw.h NGW_MAX_PASSES (spec.MAX_PASSES)
 ADDITEM_PERCENT_RANGE = {'easy': (1, 10), 'medium': (10, 20), 'hard': (20, 30)}     # novelty_wrappers.py:1006-1011
 
 
@@ -88,7 +89,7 @@ def apply_novelty(spec, novelty_name, difficulty='hard', novelty_arg1='', novelt
             "For fencerestriction novelty, novelty_arg1 (attribute of fence, e.g. oak, jungle) is needed"       # :1664
         # FenceRestriction.__init__ :901: the fences are ALWAYS laid out by Fence(env, 'medium', ...); the difficulty
         # only selects the Break predicate (:906, :927-941)
-        _fence(spec, 'medium', novelty_arg1, mode={'easy': 0, 'medium': 1, 'hard': 2}[difficulty])
+        _fence(spec, 'medium', novelty_arg1, mode={'easy': 0, 'medium': 1, 'hard': 2}[difficulty], restriction=True)
     elif novelty_name == 'firewall':
         _replace_item(spec, difficulty, 'wall', 'fire_wall')       # FireWall.__init__ :1159
         spec.fire_wall = 'fire_wall'
@@ -98,16 +99,18 @@ def apply_novelty(spec, novelty_name, difficulty='hard', novelty_arg1='', novelt
         _replace_item(spec, difficulty, novelty_arg1, novelty_arg2)
     kind = {'additem': 'additem', 'crate': 'additem', 'replaceitem': 'replace', 'firewall': 'replace', 'fence': 'fence',
             'fencerestriction': 'fence'}.get(novelty_name)
-    if kind:                              # reset passes run innermost wrapper first = injection order (Wrapper.reset calls env.reset() first)
-        if kind in spec.reset_passes:
-            raise NotImplementedError("two %s-type reset passes in one stack are outside this build's scope" % kind)
-        if kind == 'fence' and 'replace' in spec.reset_passes and spec.replace and spec.replace['src'] == 'wall':
+    if kind:        # reset passes run innermost wrapper first = injection order (Wrapper.reset calls env.reset() first); any number of
+                    # passes of one kind may be stacked (additem + crate, fence + fencerestriction, replaceitem + firewall)
+        if kind == 'fence' and any(ps['kind'] == 'replace' and ps['src'] == 'wall' for ps in spec.reset_passes):
             # the fence pass would pick cells of the (replaced) border ring, and add_fence_around (pogostick_v1_env.py:524-536)
             # then indexes row / column -1 and S: numpy wraps the first around and raises IndexError on the second - not a
             # behaviour to reproduce; refuse the stack instead of editing cells outside the map
             raise IndexError("fence after a wall-replacing novelty (%s): the reference's add_fence_around indexes outside the map"
                              % ', '.join(n[0] for n in spec.novelties if n[0] in ('firewall', 'replaceitem')))
-        spec.reset_passes.append(kind)
+        if len(spec.reset_passes) >= MAX_PASSES:
+            raise NotImplementedError("more than %d shuffled-subset reset passes in one stack" % MAX_PASSES)
+        src = {'additem': spec.additem, 'replace': spec.replace, 'fence': spec.fence}[kind]
+        spec.reset_passes.append(dict(kind=kind, item=src.get('dst', src.get('item')), src=src.get('src'), pct=tuple(src['pct'])))
     spec.novelties.append((novelty_name, difficulty, novelty_arg1, novelty_arg2))
     return spec
 
@@ -201,13 +204,15 @@ REPLACE_PERCENT_RANGE = {'easy': (5, 20), 'medium': (40, 90), 'hard': (99, 100)}
 CRATE_PERCENT_RANGE = {'easy': (99, 100), 'medium': (50, 90), 'hard': (10, 50)}     # :1047-1052
 
 
-def _fence(spec, difficulty, fence_material, mode):
+def _fence(spec, difficulty, fence_material, mode, restriction=False):
     """Fence.__init__ (novelty_wrappers.py:852-866): new item <material>_fence + its Select action; the fences appear in
     the reset pass (:867-889).  `mode` is FenceRestriction's Break predicate (0 = none)."""
     fence_name = fence_material + '_fence'
     spec.add_new_item(fence_name)
     spec.add_select_action(fence_name)
     spec.fence = dict(item=fence_name, pct=FENCE_PERCENT_RANGE[difficulty], mode=mode)
+    if restriction:                                              # the Break predicate belongs to the FenceRestriction wrapper and ITS fence item:
+        spec.fence_pred = dict(item=fence_name, mode=mode)        # a plain Fence wrapper stacked on top later does not touch it
 
 
 def _replace_item(spec, difficulty, item_to_replace, item_to_replace_with):

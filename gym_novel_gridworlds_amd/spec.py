@@ -18,7 +18,8 @@ import ctypes as C
 
 MAX_ITEMS, MAX_ACTIONS, MAX_RECIPES, MAX_RECIPE_INPUTS, MAX_START, MAX_INV_START = 24, 48, 8, 4, 8, 4
 MAX_MAP_SIZE = 64
-ABI_VERSION = 1
+MAX_PASSES = 4
+ABI_VERSION = 2
 
 # step_cost values with their Python types (SURVEY.md §8(a) "Distinct step_cost values")
 STEP_COSTS = [0, 24.0, 27.906975, 120.0, 300.0, 360.0, 480.0, 720.0, 840.0, 1200.0, 1800.0, 2400.0, 3600.0,
@@ -69,13 +70,13 @@ class NgwSpec(C.Structure):
         ('axe_required', C.c_uint8), ('_pad2', C.c_uint8 * 3),
         ('n_start', C.c_uint8), ('start_item', C.c_uint8 * MAX_START), ('start_qty', C.c_uint8 * MAX_START),
         ('tap_item', C.c_uint8), ('tap_near', C.c_uint8),
-        ('additem_item', C.c_uint8), ('additem_pct_lo', C.c_uint8), ('additem_pct_hi', C.c_uint8),
         ('n_inv_start', C.c_uint8), ('inv_start_item', C.c_uint8 * MAX_INV_START), ('inv_start_qty', C.c_uint8 * MAX_INV_START),
-        ('replace_from', C.c_uint8), ('replace_to', C.c_uint8), ('replace_pct_lo', C.c_uint8), ('replace_pct_hi', C.c_uint8),
-        ('fence_item', C.c_uint8), ('fence_pct_lo', C.c_uint8), ('fence_pct_hi', C.c_uint8), ('fence_mode', C.c_uint8),
+        ('n_passes', C.c_uint8), ('pass_kind', C.c_uint8 * MAX_PASSES), ('pass_item', C.c_uint8 * MAX_PASSES),
+        ('pass_from', C.c_uint8 * MAX_PASSES), ('pass_pct_lo', C.c_uint8 * MAX_PASSES), ('pass_pct_hi', C.c_uint8 * MAX_PASSES),
+        ('fence_item', C.c_uint8), ('fence_mode', C.c_uint8),
         ('fire_item', C.c_uint8), ('fire_reward', C.c_int8),
         ('crate_item', C.c_uint8), ('crate_add', C.c_uint8 * MAX_ITEMS),
-        ('pass_order', C.c_uint8 * 3), ('ext_flags', C.c_uint8), ('fire_skip_recipe', C.c_uint8),
+        ('ext_flags', C.c_uint8), ('fire_skip_recipe', C.c_uint8),
     ]
 
 
@@ -180,10 +181,12 @@ class EnvSpec:
         self.additem = None        # dict(item=name, pct=(lo, hi))
         self.replace = None        # ReplaceItem / FireWall: dict(src=name, dst=name, pct=(lo, hi))
         self.fence = None          # Fence / FenceRestriction: dict(item=name, pct=(lo, hi), mode=0|1|2)
+        self.fence_pred = None     # FenceRestriction's Break predicate: dict(item=name, mode=0|1|2)
         self.fire_wall = None      # FireWall: item name whose 4-neighbourhood kills the agent
         self.crate = None          # Crate: dict(item='crate', ingredients=[names drawn at injection])
         self.recipe_rewards = {}   # recipe -> reward of a successful craft when it differs from craft_reward (craftable axe)
-        self.reset_passes = []     # 'additem' / 'replace' / 'fence' in the order their wrappers were stacked (innermost first)
+        self.reset_passes = []     # the shuffled-subset reset passes in the order their wrappers were stacked (innermost first):
+                                   # dict(kind='additem'|'replace'|'fence', item=name, src=name or None, pct=(lo, hi))
         self.novelties = []
 
     # -- table edits used by inject_novelty ---------------------------------------------------
@@ -303,12 +306,14 @@ class EnvSpec:
             s.inv_start_item[j], s.inv_start_qty[j] = ids[item], q
         if self.tap_pass:
             s.tap_item, s.tap_near = ids[self.tap_pass['item']], ids[self.tap_pass['near']]
-        order = list(self.reset_passes) + [k for k in ('additem', 'replace', 'fence') if k not in self.reset_passes]
-        for j, k in enumerate(order):
-            s.pass_order[j] = {'additem': 1, 'replace': 2, 'fence': 3}[k]
-        if self.additem:
-            s.additem_item = ids[self.additem['item']]
-            s.additem_pct_lo, s.additem_pct_hi = self.additem['pct']
+        if len(self.reset_passes) > MAX_PASSES:
+            raise NotImplementedError("more than %d shuffled-subset reset passes in one stack" % MAX_PASSES)
+        s.n_passes = len(self.reset_passes)
+        for j, ps in enumerate(self.reset_passes):
+            s.pass_kind[j] = {'additem': 1, 'replace': 2, 'fence': 3}[ps['kind']]
+            s.pass_item[j] = ids[ps['item']]
+            s.pass_from[j] = ids[ps['src']] if ps.get('src') else 0
+            s.pass_pct_lo[j], s.pass_pct_hi[j] = ps['pct']
         # wrapper nesting of a stack (injection order = inner to outer), as far as the step can tell
         names = [nv[0] for nv in self.novelties]
         last = lambda pred: max([i for i, nv in enumerate(self.novelties) if pred(nv)], default=-1)
@@ -323,12 +328,9 @@ class EnvSpec:
             s.fire_skip_recipe = 1 + rnames.index(self.novelties[h][2] + '_axe')
         if crate_on and fence_on and c < f:
             s.ext_flags |= 2                                   # NGW_XF_CRATE_IN_FENCE
-        if self.replace:
-            s.replace_from, s.replace_to = ids[self.replace['src']], ids[self.replace['dst']]
-            s.replace_pct_lo, s.replace_pct_hi = self.replace['pct']
-        if self.fence:
-            s.fence_item, s.fence_mode = ids[self.fence['item']], (self.fence['mode'] if fence_on or f < 0 else 0)
-            s.fence_pct_lo, s.fence_pct_hi = self.fence['pct']
+        pred = self.fence_pred or self.fence                   # the FenceRestriction predicate looks for ITS fence item
+        if pred:
+            s.fence_item, s.fence_mode = ids[pred['item']], (pred['mode'] if fence_on or f < 0 else 0)
         if self.fire_wall:
             s.fire_item, s.fire_reward = ids[self.fire_wall], -self.reward_done // 2        # novelty_wrappers.py:1187
         if self.crate and crate_on:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NGW_ABI_VERSION 1
+#define NGW_ABI_VERSION 2
 
 #define NGW_MAX_ITEMS 24        /* reference asserts len(items) <= max_items = 20 (pogostick_v1_env.py:75,220) */
 #define NGW_MAX_ACTIONS 48
@@ -31,6 +31,7 @@ extern "C" {
 #define NGW_MAX_RECIPE_INPUTS 4  /* the reference's recipes have <= 3 inputs (pogostick_v1_env.py:56-59) */
 #define NGW_MAX_START_ITEMS 8
 #define NGW_MAX_INV_START 4
+#define NGW_MAX_PASSES 4          /* shuffled-subset reset passes of one stack of wrappers */
 #define NGW_MAX_MAP_SIZE 64     /* S; the LDS-resident kernel supports S*S <= 4096 */
 
 /* error codes */
@@ -52,6 +53,7 @@ enum { NGW_ACT_FORWARD = 0, NGW_ACT_LEFT = 1, NGW_ACT_RIGHT = 2, NGW_ACT_BREAK =
 
 /* info['message'] codes; the host formats the string (reference strings cited in spec.py) */
 enum { NGW_XF_FIRE_SKIP_BREAK = 1, NGW_XF_CRATE_IN_FENCE = 2 };
+enum { NGW_PASS_ADDITEM = 1, NGW_PASS_REPLACE = 2, NGW_PASS_FENCE = 3 };   /* ngw_spec.pass_kind */
 enum { NGW_MSG_NONE = 0, NGW_MSG_BLOCK_IN_PATH = 1, NGW_MSG_CANNOT_BREAK = 2 /* arg = item */,
        NGW_MSG_PLACED = 3 /* arg = item */, NGW_MSG_ALREADY_EXISTS = 4 /* arg = front item */,
        NGW_MSG_NOT_IN_INVENTORY = 5, NGW_MSG_EXTRACT_NO_SRC = 6, NGW_MSG_EXTRACT_NOT_NEAR = 7,
@@ -123,20 +125,23 @@ typedef struct ngw_spec {
     /* Pogostick-v0 reset pass (pogostick_v0_env.py:156-178): put one `tap_item` on a free 4-neighbour (random direction)
      * of a random `tap_near` block; tap_item = 0 -> disabled */
     uint8_t tap_item, tap_near;
-    /* AddItem second reset pass (novelty_wrappers.py:1013-1034); additem_item = 0 -> disabled */
-    uint8_t additem_item, additem_pct_lo, additem_pct_hi;
     /* items present in the inventory after every reset: AxeEasy / AxetoBreakEasy (novelty_wrappers.py:29-35, :456-462: the
      * axe), AxetoBreakHard (:663-672: the axe's ingredients) */
     uint8_t n_inv_start;
     uint8_t inv_start_item[NGW_MAX_INV_START], inv_start_qty[NGW_MAX_INV_START];
-    /* ReplaceItem / FireWall reset pass (novelty_wrappers.py:1129-1148): a shuffled randint(lo, hi) percent of the cells
-     * holding replace_from become replace_to (never the agent cell); replace_to = 0 -> disabled */
-    uint8_t replace_from, replace_to, replace_pct_lo, replace_pct_hi;
-    /* Fence reset pass (:867-889): a shuffled percent of the non-air, non-wall cells get fence_item on every free
-     * 8-neighbour (add_fence_around, pogostick_v1_env.py:524-536); fence_item = 0 -> disabled.
-     * fence_mode: FenceRestriction Break predicate (:906-988) - 0 none (fence, fencerestriction easy), 1 medium (no
+    /* Shuffled-subset reset passes, in the order they run = the order their wrappers were injected (a wrapper's reset() calls
+     * the wrapped env's first): np.where(<predicate>) row-major, np.random.shuffle, randint(pct_lo, pct_hi), then the first
+     * ceil(len * pct / 100) cells are edited (never the agent cell).  pass_kind: NGW_PASS_ADDITEM - AddItem / Crate
+     * (novelty_wrappers.py:1013-1034, :1071): air cells become pass_item; NGW_PASS_REPLACE - ReplaceItem / FireWall
+     * (:1129-1148): cells holding pass_from become pass_item; NGW_PASS_FENCE - Fence / FenceRestriction (:867-889): every free
+     * 8-neighbour of a chosen non-air, non-wall cell gets pass_item (add_fence_around, pogostick_v1_env.py:524-536).  Any
+     * number of passes of the same kind may be stacked (additem + crate, fence + fencerestriction, replaceitem + firewall). */
+    uint8_t n_passes;
+    uint8_t pass_kind[NGW_MAX_PASSES], pass_item[NGW_MAX_PASSES], pass_from[NGW_MAX_PASSES];
+    uint8_t pass_pct_lo[NGW_MAX_PASSES], pass_pct_hi[NGW_MAX_PASSES];
+    /* FenceRestriction Break predicate (:906-988) on fence_item: fence_mode 0 none (fence, fencerestriction easy), 1 medium (no
      * fence beside the AGENT, across its facing), 2 hard (no fence in the 3x3 around the block in front) */
-    uint8_t fence_item, fence_pct_lo, fence_pct_hi, fence_mode;
+    uint8_t fence_item, fence_mode;
     /* FireWall.step (:1164-1200): after the step, a fire_item 4-neighbour of the agent -> reward fire_reward, done,
      * message 'You died due to fire_wall'; fire_item = 0 -> disabled */
     uint8_t fire_item;
@@ -145,9 +150,6 @@ typedef struct ngw_spec {
      * inventory (the ingredient multiset drawn at injection, :1055-1068); crate_item = 0 -> disabled */
     uint8_t crate_item;
     uint8_t crate_add[NGW_MAX_ITEMS];
-    /* order of the shuffled-subset reset passes (1 = AddItem/Crate, 2 = ReplaceItem/FireWall, 3 = Fence): stacked wrappers
-     * reset innermost first, i.e. in the order they were injected; a permutation of {1, 2, 3} */
-    uint8_t pass_order[3];
     /* wrapper nesting of a stack, as far as the step can tell: NGW_XF_FIRE_SKIP_BREAK - the FireWall wrapper sits BELOW a
      * Break-overriding one (axe / axetobreak / breakincrease handle Break without calling the env they wrap), so its check
      * does not run on Break steps; fire_skip_recipe = 1 + recipe of a craftable axe whose wrapper sits above FireWall (its

@@ -115,15 +115,13 @@ static const int TURN_LEFT[4] = {2, 3, 1, 0}, TURN_RIGHT[4] = {3, 2, 0, 1}; /* (
 /* The reset passes of AddItem (novelty_wrappers.py:1017-1028), ReplaceItem (:1131-1144) and Fence (:871-884) share one
  * shape: np.where(<predicate>) in row-major order, np.random.shuffle of the index array (Fisher-Yates from the top),
  * percent = np.random.randint(lo, hi), then the first int(np.ceil(len * (percent / 100))) cells are edited. */
-enum { PASS_ADDITEM = 0, PASS_REPLACE = 1, PASS_FENCE = 2 };
-static void subset_pass(const ngw_spec* sp, ngwo_rng* rng, int8_t* map, int agent, int kind, int pct_lo, int pct_hi) {
+static void subset_pass(const ngw_spec* sp, ngwo_rng* rng, int8_t* map, int agent, int kind, int item, int from, int pct_lo, int pct_hi) {
     const int S = sp->map_size;
     int n = 0;
     int16_t* cells = (int16_t*)malloc(sizeof(int16_t) * (size_t)(S * S));
     for (int i = 0; i < S * S; i++) {
         const int v = map[i];
-        const int hit = kind == PASS_ADDITEM ? v == 0 : kind == PASS_REPLACE ? v == sp->replace_from
-                                                                             : (v != 0 && v != sp->wall_item);
+        const int hit = kind == NGW_PASS_ADDITEM ? v == 0 : kind == NGW_PASS_REPLACE ? v == from : (v != 0 && v != sp->wall_item);
         if (hit) cells[n++] = (int16_t)i;
     }
     for (int i = n - 1; i >= 1; i--) {
@@ -134,12 +132,12 @@ static void subset_pass(const ngw_spec* sp, ngwo_rng* rng, int8_t* map, int agen
     int cnt = (int)ceil((double)n * ((double)pct / 100.0));
     for (int i = 0; i < cnt; i++) {
         const int cell = cells[i];
-        if (kind == PASS_FENCE) {                                 /* add_fence_around, pogostick_v1_env.py:524-536 */
+        if (kind == NGW_PASS_FENCE) {                                 /* add_fence_around, pogostick_v1_env.py:524-536 */
             for (int rr = cell / S - 1; rr <= cell / S + 1; rr++)
                 for (int cc = cell % S - 1; cc <= cell % S + 1; cc++)
-                    if (map[rr * S + cc] == 0 && rr * S + cc != agent) map[rr * S + cc] = (int8_t)sp->fence_item;
+                    if (map[rr * S + cc] == 0 && rr * S + cc != agent) map[rr * S + cc] = (int8_t)item;
         } else if (cell != agent) {                               /* :1027 / :1143 skip the agent cell */
-            map[cell] = (int8_t)(kind == PASS_ADDITEM ? sp->additem_item : sp->replace_to);
+            map[cell] = (int8_t)item;
         }
     }
     free(cells);
@@ -197,15 +195,10 @@ static int reset_env(const ngw_spec* sp, ngwo_rng* rng, int8_t* map, int32_t* lo
         }
         free(logs);
     }
-    for (int j = 0; j < 3; j++) {                                 /* stacked wrappers reset innermost first (pass_order) */
-        const int kind = sp->pass_order[j];
-        if (kind == 1 && sp->additem_item)                        /* AddItem.reset, novelty_wrappers.py:1017-1028 (also Crate.reset :1071) */
-            subset_pass(sp, rng, map, agent, PASS_ADDITEM, sp->additem_pct_lo, sp->additem_pct_hi);
-        if (kind == 2 && sp->replace_to)                          /* ReplaceItem.reset :1129-1148 (also FireWall.reset :1160) */
-            subset_pass(sp, rng, map, agent, PASS_REPLACE, sp->replace_pct_lo, sp->replace_pct_hi);
-        if (kind == 3 && sp->fence_item)                          /* Fence.reset :867-889 (also FenceRestriction.reset :904) */
-            subset_pass(sp, rng, map, agent, PASS_FENCE, sp->fence_pct_lo, sp->fence_pct_hi);
-    }
+    /* stacked wrappers reset innermost first = injection order: AddItem.reset novelty_wrappers.py:1017-1028 (also Crate.reset :1071),
+     * ReplaceItem.reset :1129-1148 (also FireWall.reset :1160), Fence.reset :867-889 (also FenceRestriction.reset :904) */
+    for (int j = 0; j < sp->n_passes; j++)
+        subset_pass(sp, rng, map, agent, sp->pass_kind[j], sp->pass_item[j], sp->pass_from[j], sp->pass_pct_lo[j], sp->pass_pct_hi[j]);
     for (int j = 0; j < sp->n_inv_start; j++) inv[sp->inv_start_item[j]] = sp->inv_start_qty[j];   /* AxeEasy.reset :33, AxetoBreakHard.reset :667-670 */
     return 0;
 }

@@ -94,13 +94,21 @@ CFGS = {
     'stk_crate_fr12': (BOW, 12, [('crate', 'medium', '', ''), ('fencerestriction', 'hard', 'oak', '')]),      # crate inside the restriction
     'stk_fr_crate12': (BOW, 12, [('fencerestriction', 'hard', 'oak', ''), ('crate', 'medium', '', '')]),
     'stk_crate_bi10': (POGO, 10, [('crate', 'hard', '', ''), ('breakincrease', 'hard', '', '')]),             # no crate bonus
+    # two reset passes of the SAME kind in one stack (round 2): the reference nests them freely (novelty_wrappers.py:1013-1034, :1070-1076, :1129-1160)
+    'stk_add_crate12': (POGO, 12, [('additem', 'medium', 'arrow', ''), ('crate', 'medium', '', '')]),
+    'stk_crate_add12': (BOW, 12, [('crate', 'hard', '', ''), ('additem', 'easy', 'arrow', '')]),
+    'stk_fen_fr12':    (POGO, 12, [('fence', 'easy', 'oak', ''), ('fencerestriction', 'hard', 'jungle', '')]),
+    'stk_fr_fen12':    (BOW, 12, [('fencerestriction', 'medium', 'oak', ''), ('fence', 'medium', 'jungle', '')]),
+    'stk_repl_fire12': (POGO, 12, [('replaceitem', 'medium', 'crafting_table', 'anvil'), ('firewall', 'hard', '', '')]),
+    'stk_fire_repl12': (BOW, 12, [('firewall', 'medium', '', ''), ('replaceitem', 'hard', 'wool', 'silk')]),
     # the v0 variants
     'pogov0_10':   (POGO0, 10, None),
     'pogov0_14':   (POGO0, 14, ('axe', 'medium', 'wooden', '')),
     'bowv0_12':    (BOW0, 12, None),
 }
 REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13,      # np.random.seed right before inject_novelty
-              'crate10m': 31, 'crate12h': 32, 'crate11e': 33, 'stk_crate_fr12': 34, 'stk_fr_crate12': 35, 'stk_crate_bi10': 36}      # (remapaction shuffles / Crate draws its ingredients there)
+              'crate10m': 31, 'crate12h': 32, 'crate11e': 33, 'stk_crate_fr12': 34, 'stk_fr_crate12': 35, 'stk_crate_bi10': 36,
+              'stk_add_crate12': 37, 'stk_crate_add12': 38}      # (remapaction shuffles / Crate draws its ingredients there)
 DIRS = ['NORTH', 'SOUTH', 'WEST', 'EAST']
 
 
@@ -661,6 +669,8 @@ PLAN = {  # cfg: (reset seeds, traces, steps per trace, single-step cases, solve
     'stk_fire_axe10': (8, 2, 1000, 4000, 0), 'stk_fire_axeh10': (8, 2, 1000, 4000, 0), 'stk_fr_axe10': (8, 2, 800, 4000, 0),
     'stk_axe_fr10': (8, 2, 800, 4000, 0), 'stk_crate_fr12': (8, 2, 800, 4000, 0), 'stk_fr_crate12': (8, 2, 800, 4000, 0),
     'stk_crate_bi10': (8, 2, 800, 3000, 0),
+    'stk_add_crate12': (12, 2, 800, 3000, 0), 'stk_crate_add12': (12, 2, 800, 3000, 0), 'stk_fen_fr12': (12, 2, 800, 4000, 0),
+    'stk_fr_fen12': (12, 2, 800, 4000, 0), 'stk_repl_fire12': (12, 2, 800, 2000, 0), 'stk_fire_repl12': (12, 2, 800, 2000, 0),
 }
 
 

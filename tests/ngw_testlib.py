@@ -50,13 +50,19 @@ CFGS.update({
     'stk_crate_fr12': (BOW, 12, [('crate', 'medium', '', ''), ('fencerestriction', 'hard', 'oak', '')]),
     'stk_fr_crate12': (BOW, 12, [('fencerestriction', 'hard', 'oak', ''), ('crate', 'medium', '', '')]),
     'stk_crate_bi10': (POGO, 10, [('crate', 'hard', '', ''), ('breakincrease', 'hard', '', '')]),
+    'stk_add_crate12': (POGO, 12, [('additem', 'medium', 'arrow', ''), ('crate', 'medium', '', '')]),
+    'stk_crate_add12': (BOW, 12, [('crate', 'hard', '', ''), ('additem', 'easy', 'arrow', '')]),
+    'stk_fen_fr12': (POGO, 12, [('fence', 'easy', 'oak', ''), ('fencerestriction', 'hard', 'jungle', '')]),
+    'stk_fr_fen12': (BOW, 12, [('fencerestriction', 'medium', 'oak', ''), ('fence', 'medium', 'jungle', '')]),
+    'stk_repl_fire12': (POGO, 12, [('replaceitem', 'medium', 'crafting_table', 'anvil'), ('firewall', 'hard', '', '')]),
+    'stk_fire_repl12': (BOW, 12, [('firewall', 'medium', '', ''), ('replaceitem', 'hard', 'wool', 'silk')]),
 })
 # configurations WITHOUT reference fixtures (larger maps of pinned components: the oracle is the checker there)
 CFGS.update({'fire32m': (POGO, 32, ('firewall', 'medium', '', '')), 'fencer24h': (BOW, 24, ('fencerestriction', 'hard', 'oak', '')),
              'repl40e': (POGO, 40, ('replaceitem', 'easy', 'wall', 'brick'))})
 NO_FIXTURES = ('fire32m', 'fencer24h', 'repl40e')
 REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13, 'crate10m': 31, 'crate12h': 32, 'crate11e': 33,
-              'stk_crate_fr12': 34, 'stk_fr_crate12': 35, 'stk_crate_bi10': 36}
+              'stk_crate_fr12': 34, 'stk_fr_crate12': 35, 'stk_crate_bi10': 36, 'stk_add_crate12': 37, 'stk_crate_add12': 38}
 HEADLINE = ['pogo10', 'bow20', 'axe10', 'add32']       # BASELINE.json configs 2-5
 
 _spec_json = None

@@ -25,17 +25,21 @@ def _create(cspec, n=64):
     (lambda s: setattr(s, 'n_actions', 99), 'n_actions'),
     (lambda s: s.act_kind.__setitem__(3, 77), 'unknown kind'),
     (lambda s: s.act_arg.__setitem__(8, 7), 'recipe'),                     # action 8 = Craft_*: recipe index out of range
-    (lambda s: (setattr(s, 'additem_item', 3), setattr(s, 'additem_pct_lo', 40), setattr(s, 'additem_pct_hi', 30)), 'additem percent'),
-    (lambda s: (setattr(s, 'replace_to', 3), setattr(s, 'replace_pct_lo', 0), setattr(s, 'replace_pct_hi', 90)), 'replace percent'),
+    (lambda s: (setattr(s, 'n_passes', 1), s.pass_kind.__setitem__(0, 1), s.pass_item.__setitem__(0, 3), s.pass_pct_lo.__setitem__(0, 40),
+                s.pass_pct_hi.__setitem__(0, 30)), 'additem percent'),
+    (lambda s: (setattr(s, 'n_passes', 1), s.pass_kind.__setitem__(0, 2), s.pass_item.__setitem__(0, 3), s.pass_pct_lo.__setitem__(0, 0),
+                s.pass_pct_hi.__setitem__(0, 90)), 'replace percent'),
+    (lambda s: (setattr(s, 'n_passes', 1), s.pass_kind.__setitem__(0, 7), s.pass_item.__setitem__(0, 3)), 'unknown kind'),
+    (lambda s: setattr(s, 'n_passes', 9), 'n_passes'),
     (lambda s: setattr(s, 'fence_mode', 2), 'fence_mode'),
     (lambda s: s.crate_add.__setitem__(2, 3), 'crate_add'),
     (lambda s: (setattr(s, 'n_inv_start', 1), s.inv_start_item.__setitem__(0, 0)), 'inv_start_item'),
     (lambda s: setattr(s, 'map_size', 3), 'map_size'),
     (lambda s: setattr(s, 'abi_version', 99), 'abi'),
     (lambda s: setattr(s, 'n_items', 3), 'n_items'),                       # rows move as 16-byte chunks: at least four items
-    (lambda s: (setattr(s, 'replace_from', s.wall_item), setattr(s, 'replace_to', 3), setattr(s, 'replace_pct_lo', 10), setattr(s, 'replace_pct_hi', 20),
-                setattr(s, 'fence_item', 4), setattr(s, 'fence_pct_lo', 10), setattr(s, 'fence_pct_hi', 20),
-                s.pass_order.__setitem__(0, 2), s.pass_order.__setitem__(1, 3), s.pass_order.__setitem__(2, 1)), 'outside the map'),
+    (lambda s: (setattr(s, 'n_passes', 2), s.pass_kind.__setitem__(0, 2), s.pass_from.__setitem__(0, s.wall_item), s.pass_item.__setitem__(0, 3),
+                s.pass_pct_lo.__setitem__(0, 10), s.pass_pct_hi.__setitem__(0, 20), s.pass_kind.__setitem__(1, 3), s.pass_item.__setitem__(1, 4),
+                s.pass_pct_lo.__setitem__(1, 10), s.pass_pct_hi.__setitem__(1, 20)), 'outside the map'),
 ])
 def test_malformed_spec_is_rejected(edit, needle):
     cs = make_spec(T.POGO, 10).compile()

@@ -49,7 +49,8 @@ def test_solved_episodes_match_reference(cfg):
                                    ('fence12h', 700), ('fencer10m', 1000), ('fencer12h', 600), ('repl10m', 1000), ('replwall12e', 800),
                                    ('fire10h', 1500), ('fire14m', 600), ('crate10m', 1000), ('crate12h', 600), ('fire32m', 200),
                                    ('fencer24h', 333), ('repl40e', 130), ('stk_fen_fire12', 700), ('stk_add_repl12', 600),
-                                   ('stk_add_axe12', 500)])
+                                   ('stk_add_axe12', 500), ('stk_add_crate12', 600), ('stk_crate_add12', 500), ('stk_fen_fr12', 600),
+                                   ('stk_fr_fen12', 500), ('stk_repl_fire12', 600), ('stk_fire_repl12', 500)])
 def test_reset_matches_oracle(cfg, n):
     """reset(): template + per-env Philox item scatter (+ AddItem pass), three episodes, ragged N, masked reset."""
     spec = T.build_spec(cfg)
@@ -75,7 +76,9 @@ def test_reset_matches_oracle(cfg, n):
                                                  ('atbhard10', 1000, 150, 35), ('axehardi12', 640, 100, 30), ('fence12h', 500, 80, 25),
                                                  ('fire32m', 128, 60, 20), ('fencer24h', 256, 60, 20), ('stk_fen_fire12', 1000, 100, 25),
                                                  ('stk_bi_axe10', 1000, 100, 30), ('stk_atb_bi11', 800, 100, 0), ('stk_fire_axe10', 1500, 120, 40),
-                                                 ('stk_crate_fr12', 800, 100, 30), ('stk_fr_crate12', 800, 100, 30), ('stk_fr_axe10', 800, 80, 25)])
+                                                 ('stk_crate_fr12', 800, 100, 30), ('stk_fr_crate12', 800, 100, 30), ('stk_fr_axe10', 800, 80, 25),
+                                                 ('stk_add_crate12', 800, 80, 25), ('stk_fen_fr12', 800, 80, 25), ('stk_repl_fire12', 800, 80, 25),
+                                                 ('stk_fire_repl12', 640, 100, 0)])
 def test_autoreset_steps_match_oracle(cfg, n, steps, horizon):
     """Random actions with same-step autoreset (done or horizon): outputs every step, full state at checkpoints."""
     spec = T.build_spec(cfg)
