@@ -1306,6 +1306,14 @@ extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, in
         default: return launch_lean<NGW_MAP_BYTE, true>(dspec, a, grid, lds_bytes, stream);
         }
     }
+    if ((feat & 4) && !(feat & 3) && (a->mode == NGW_MODE_ROLLOUT || a->mode == NGW_MODE_ROLLOUT_ACT)) {   // plain configuration: lean fused rollout
+        const bool sup = a->mode == NGW_MODE_ROLLOUT_ACT;
+        switch (map_mode) {
+        case NGW_MAP_STRAIGHT: return sup ? launch_rollout_lean<NGW_MAP_STRAIGHT, true>(dspec, a, grid, lds_bytes, stream) : launch_rollout_lean<NGW_MAP_STRAIGHT, false>(dspec, a, grid, lds_bytes, stream);
+        case NGW_MAP_DWORD: return sup ? launch_rollout_lean<NGW_MAP_DWORD, true>(dspec, a, grid, lds_bytes, stream) : launch_rollout_lean<NGW_MAP_DWORD, false>(dspec, a, grid, lds_bytes, stream);
+        default: return sup ? launch_rollout_lean<NGW_MAP_BYTE, true>(dspec, a, grid, lds_bytes, stream) : launch_rollout_lean<NGW_MAP_BYTE, false>(dspec, a, grid, lds_bytes, stream);
+        }
+    }
     switch (map_mode) {
     case NGW_MAP_STRAIGHT: return launch_feat<NGW_MAP_STRAIGHT>(dspec, a, feat, grid, lds_bytes, stream);
     case NGW_MAP_DWORD: return launch_feat<NGW_MAP_DWORD>(dspec, a, feat, grid, lds_bytes, stream);

@@ -19,7 +19,7 @@ import bench  # noqa: E402
 from gym_novel_gridworlds_amd import VecNovelGridworld, _cabi, apply_novelty, make_spec  # noqa: E402
 
 NAMES = ['entry', 'loads issued', 'landed in LDS', 'scalars ready', 'step done', 'outputs issued', 'stores acked']
-LEAN = ['entry', 'loads issued', 'landed in LDS', 'LDS reads back', 'outcome known', 'step done', 'outputs issued', 'stores acked']
+LEAN = ['entry', 'loads issued', 'landed in LDS', 'step begins', 'step done', 'outputs begin', 'outputs issued', 'stores acked']
 
 
 def main():
