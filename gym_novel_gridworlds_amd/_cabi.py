@@ -22,7 +22,7 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_graph_build', 'ngw_graph_launch', 'ngw_lidar_configure', 'ngw_lidar', 'ngw_lidar_fuse',
            'ngw_get_lidar', 'ngw_lidar_device_ptr', 'ngw_host_alloc', 'ngw_host_free', 'ngw_agent_view',
            'ngw_get_agent_view', 'ngw_agent_view_device_ptr', 'ngw_set_reset_prefetch', 'ngw_step_host', 'ngw_lidar_set_output', 'ngw_rollout_actions',
-           'ngw_pack_layout', 'ngw_pack_obs', 'ngw_unpack_obs', 'ngw_rollout_outputs', 'ngw_episode_stats']
+           'ngw_pack_layout', 'ngw_pack_obs', 'ngw_unpack_obs', 'ngw_rollout_outputs', 'ngw_episode_stats', 'ngw_host_step_layout']
 
 _lib = None
 
@@ -116,6 +116,8 @@ def lib():
     if hasattr(L, 'ngw_rollout_outputs'):
         L.ngw_rollout_outputs.argtypes = [vp, vp, vp, i64, C.c_int]
         L.ngw_episode_stats.argtypes = [vp, vp, vp, vp, vp, C.c_int]
+    if hasattr(L, 'ngw_host_step_layout'):
+        L.ngw_host_step_layout.argtypes = [vp, C.POINTER(u64)]
     L.ngw_host_alloc.argtypes = [u64]
     L.ngw_host_alloc.restype = vp
     L.ngw_host_free.argtypes = [vp]

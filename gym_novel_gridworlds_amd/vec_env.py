@@ -63,7 +63,7 @@ class VecNovelGridworld:
         self._flags_word = C.c_uint32(0)
         self._host = None                                     # host mirrors of the host API: allocated on first use
 
-    _HOST_ATTRS = ('_obs', '_reward', '_done', '_act_pinned', '_sel_host', '_steps_host', '_result', '_cost', '_msg', '_arg')
+    _HOST_ATTRS = ('_obs', '_reward', '_done', '_act_pinned', '_sel_host', '_steps_host', '_result', '_cost', '_msg', '_arg', '_flags_np')
 
     def __getattr__(self, name):
         # The host mirrors (10 MB page-locked at 65 536 envs, 157 B per env) exist only for the host API; a handle that is
@@ -71,12 +71,21 @@ class VecNovelGridworld:
         if name in VecNovelGridworld._HOST_ATTRS:
             if self.__dict__.get('_host') is None:
                 N, S, K = self.num_envs, self.map_size, self.n_items
-                pin = _cabi.pinned_array                      # page-locked: D2H / H2D at full PCIe rate (API mode)
+                # ONE page-locked block laid out as ngw_host_step_layout says: a big batch's step() then comes back with a single
+                # copy across PCIe (one pack launch on the device) instead of nine
+                offs = (C.c_uint64 * 11)()
+                _cabi.check(_cabi.lib().ngw_host_step_layout(self._h, offs))
+                block = _cabi.pinned_array((int(offs[10]),), np.uint8)
+
+                def sec(i, shape, dt):
+                    nb = int(np.prod(shape)) * np.dtype(dt).itemsize
+                    return block[int(offs[i]):int(offs[i]) + nb].view(dt).reshape(shape)
                 self.__dict__['_host'] = dict(
-                    _obs={'map': pin((N, S, S), np.int8), 'agent_location': pin((N, 2), np.int32),
-                          'agent_facing_id': pin((N,), np.int32), 'inventory_items_quantity': pin((N, K), np.int32)},
-                    _reward=pin((N,), np.int32), _done=pin((N,), np.uint8), _act_pinned=pin((N,), np.int32),
-                    _sel_host=np.zeros(N, np.uint8), _steps_host=np.zeros(N, np.int32),   # selected item / step_count after the last step()
+                    _obs={'map': sec(0, (N, S, S), np.int8), 'agent_location': sec(1, (N, 2), np.int32),
+                          'agent_facing_id': sec(2, (N,), np.int32), 'inventory_items_quantity': sec(3, (N, K), np.int32)},
+                    _reward=sec(4, (N,), np.int32), _done=sec(5, (N,), np.uint8), _flags_np=sec(7, (1,), np.uint32),
+                    _sel_host=sec(8, (N,), np.uint8), _steps_host=sec(9, (N,), np.int32),     # selected item / step_count after the last step()
+                    _act_pinned=_cabi.pinned_array((N,), np.int32),
                     _result=np.zeros(N, np.uint8), _cost=np.zeros(N, np.uint8), _msg=np.zeros(N, np.uint16), _arg=np.zeros(N, np.uint16))
                 self.__dict__.update(self.__dict__['_host'])   # plain attributes from now on (no __getattr__ detour per access)
             return self.__dict__[name]
@@ -130,11 +139,11 @@ class VecNovelGridworld:
             self._h, p(self._act_pinned, np.int32), m, p(o['agent_location'], np.int32),
             p(o['agent_facing_id'], np.int32), p(o['inventory_items_quantity'], np.int32), p(self._reward, np.int32),
             p(self._done, np.uint8), p(self._result, np.uint8), p(self._cost, np.uint8), p(self._msg, np.uint16), p(self._arg, np.uint16),
-            C.byref(self._flags_word), p(self._sel_host, np.uint8), p(self._steps_host, np.int32)))
+            p(self._flags_np, np.uint32), p(self._sel_host, np.uint8), p(self._steps_host, np.int32)))
         self._last_actions = a
         obs = None if not with_obs else ({k: v.copy() for k, v in o.items()} if copy else o)
         reward, done, info = self._step_out_views(copy)
-        if self._flags_word.value:
+        if self._flags_np[0]:
             self._raise_flags()
         return obs, reward, done, info
 
@@ -149,13 +158,13 @@ class VecNovelGridworld:
                 self._h, p(self._act_pinned, np.int32), p(o['map'], np.int8), p(o['agent_location'], np.int32),
                 p(o['agent_facing_id'], np.int32), p(o['inventory_items_quantity'], np.int32), p(self._reward, np.int32),
                 p(self._done, np.uint8), p(self._result, np.uint8), p(self._cost, np.uint8), p(self._msg, np.uint16), p(self._arg, np.uint16),
-                C.byref(self._flags_word), p(self._sel_host, np.uint8), p(self._steps_host, np.int32))
+                p(self._flags_np, np.uint32), p(self._sel_host, np.uint8), p(self._steps_host, np.int32))
             self._step1_fn = _cabi.lib().ngw_step_host
         self._act_pinned[0] = action
         rc = self._step1_fn(*args)
         if rc:
             _cabi.check(rc)
-        if self._flags_word.value:
+        if self._flags_np[0]:
             self._raise_flags()
         return (int(self._reward[0]), bool(self._done[0]), bool(self._result[0]), int(self._cost[0]), int(self._msg[0]), int(self._arg[0]))
 

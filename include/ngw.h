@@ -226,6 +226,11 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
                   int32_t* reward, uint8_t* done, uint8_t* result, uint8_t* cost_code, uint16_t* msg_code, uint16_t* msg_arg,
                   uint32_t* error_flags /* the sticky NGW_F_* word, as ngw_error_flags */,
                   uint8_t* selected /* item id, 0 = '' */, int32_t* step_count);
+/* Big batches: when the output arrays handed to ngw_step_host are the sections of ONE page-locked block laid out as this call
+ * says (offsets11[0..9] = byte offsets of map | agent_location | agent_facing_id | inventory | reward | done | info words
+ * (internal) | error flags | selected | step_count from the block's start, each section padded to 256 bytes; offsets11[10] =
+ * block size; allocate it with ngw_host_alloc), the device packs every output with one launch and ONE copy crosses PCIe. */
+int ngw_host_step_layout(ngw_handle* h, uint64_t* offsets11);
 /* Fused bench mode: T steps in one launch with on-device uniform actions
  * a(t, env) = (word (t & 3) of philox(action_seed; t >> 2, env) * A) >> 32; state stays in LDS/registers between
  * steps and every step's changes are written through to the observation buffers. */
