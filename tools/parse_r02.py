@@ -152,7 +152,7 @@ pm.append('')
 # rollout traffic
 f_by, w_by = counters('pmc_C2rollout_FETCH_SIZE'), counters('pmc_C2rollout_WRITE_SIZE')
 for (k, cn), v in f_by.items():
-    if ', 2,' in k:
+    if 'rollout_lean' in k or ', 2,' in k:
         fv, wv = max(v), max(w_by.get((k, 'WRITE_SIZE'), [0]))
         total = fv * 1024 * ff + wv * 1024 * wf
         steps = 60
@@ -165,7 +165,7 @@ for (k, cn), v in f_by.items():
 pm.append('## SQ counters\n')
 pm.append('Two `--pmc` passes of 7 / 6 SQ counters each (the SQ block has 8 slots).  `SQ_WAVE_CYCLES`, `SQ_WAIT_*`, `SQ_ACTIVE_INST_*` count quad-cycles.\n')
 for label, dirs, pick, per in (('C2 step kernel `ngw_step_lean<0, true>` (per launch: 1024 waves, one batched step)', ('sq_step_1', 'sq_step_2'), 'step_lean', 1),
-                               ('C2 fused rollout `ngw_kernel<0, 2, false, false>` (200 steps per launch, prepared episodes off)', ('sq_rollout_1', 'sq_rollout_2'), ', 2,', 200)):
+                               ('C2 fused rollout `ngw_rollout_lean<0, false>` (200 steps per launch, prepared episodes off)', ('sq_rollout_1', 'sq_rollout_2'), 'rollout_lean', 200)):
     vals = {}
     for d in dirs:
         for (k, cn), v in counters(d).items():

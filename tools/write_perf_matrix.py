@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""gpurun_out/matrix_r02/ (tools/perf_matrix_r02.sh) -> profiles/r02_perf_matrix.md"""
+import json, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d = os.path.join(ROOT, 'gpurun_out', 'matrix_r02') + '/'
+out = ['# Performance matrix of round 2 (one MI355X; `tools/perf_matrix_r02.sh`)\n',
+       'Every JSON block below is the line `bench.py` printed (default flags unless stated), trimmed to the measured fields.\n']
+
+
+def trim(x):
+    r = x['roofline']
+    o = {'value_G': round(x['value'] / 1e9, 2), 'us_per_step': round(x['ms_per_step'] * 1e3, 2), 'n_gpus': x['n_gpus'], 'steps': x['steps'],
+         'resets_in_timed_region': x['resets_in_timed_region'], 'roofline_frac': r['frac'], 'kernel_us_avg': round(r['kernel_ms_avg'] * 1e3, 3),
+         'traffic_bytes': r.get('traffic'), 'frac_on_measured_traffic': r.get('frac_of_peak_on_measured_traffic')}
+    if 'gather' in x:
+        o['gather'] = {k: x['gather'][k] for k in ('ms', 'GBps_into_root', 'payload_bytes_per_rank', 'ranks', 'backend')}
+    if 'fused_rollout' in x:
+        o['fused_G'] = round(x['fused_rollout']['value'] / 1e9, 1)
+        o['fused_supplied_actions_G'] = round(x['fused_rollout'].get('with_supplied_actions', {}).get('value', 0) / 1e9, 1)
+    if 'staggered_resets' in x:
+        o['staggered_inline_G'] = round(x['staggered_resets']['inline_resets']['value'] / 1e9, 2)
+        o['staggered_prepared_G'] = round(x['staggered_resets']['prepared_next_episodes_every_32']['value'] / 1e9, 2)
+    if 'api_mode' in x:
+        o['api_mode_G'] = round(x['api_mode']['value'] / 1e9, 3)
+    if 'c1_single_env' in x:
+        o['c1_steps_per_s'] = {k: v['value'] for k, v in x['c1_single_env'].items()}
+    if 'cpu_baseline' in x:
+        o['cpu_G_16_threads'] = round(x['cpu_baseline']['value'] / 1e9, 3)
+        o['cpu_G_1_thread'] = round(x['cpu_baseline']['one_core_value'] / 1e9, 4)
+    return o
+
+
+for f, title in [('bench_C2', 'C2 `python bench.py`'), ('bench_C3', 'C3 `--workload C3`'), ('bench_C4', 'C4 `--workload C4`'), ('bench_C5', 'C5 `--workload C5`'),
+                 ('bench_C2_driver_style', 'C2 driver-style `--steps 20 --warmup 5` (eager launches below 100 steps)'),
+                 ('bench_2rank_C4', '2 ranks on ONE GPU (rehearsal of the N > 1 path; the ranks share the GPU, so per-rank rates halve): `python bench.py --gpus 2 --dist-backend gloo --single-device --workload C4 --steps 400`'),
+                 ('bench_2rank_C5', '2 ranks on ONE GPU: `... --workload C5 --steps 400`')]:
+    try:
+        x = json.load(open(d + f + '.json'))
+    except Exception:
+        continue
+    out.append('## %s\n\n```json\n%s\n```\n' % (title, json.dumps(trim(x))))
+for f, title in [('reset_time.log', 'Reset launches (`tools/reset_time.py`, HIP events, eager; dedicated kernel where it applies)'),
+                 ('reset_time_general.log', 'Reset launches, general kernel only (`NGW_FAST_RESET=0`)'),
+                 ('adapter.log', 'Single-env adapter (`tools/adapter_latency.py`)'), ('api.log', 'Host API by batch size (`tools/api_latency.py`)'),
+                 ('stamps.log', 'In-kernel timelines of one step launch (`tools/stamp_timeline.py`, stamps build)'),
+                 ('stamps_general.log', "The same for round 1's general kernel at C2 (`NGW_LEAN=0`)")]:
+    if os.path.exists(d + f):
+        out.append('## %s\n\n```\n%s\n```\n' % (title, ''.join(ln for ln in open(d + f) if 'amdgpu.ids' not in ln).strip()))
+open(os.path.join(ROOT, 'profiles', 'r02_perf_matrix.md'), 'w').write('\n'.join(out))
