@@ -141,6 +141,10 @@ class ShardedVecNovelGridworld:
                 self._recv = torch.empty((self.world, send.numel()), dtype=torch.uint8, device=send.device)
             recv = [self._recv[r] for r in range(self.world)]
         self.dist.gather(send, recv, dst=dst, group=self.group)
+        if send.is_cuda:
+            # RCCL runs the collective on torch's stream and only orders THAT stream behind it; the unpack launch goes to the
+            # handle's own stream, so wait for the device here (host tensors / gloo: the call above is already synchronous)
+            torch.cuda.synchronize(send.device)
         if self.rank != dst:
             return None
         stacked = self._recv.to(mine.device) if host_side else self._recv
