@@ -599,3 +599,54 @@ def test_autoreset_switches_prepared_episodes_on_at_the_c_abi():
     v.rollout(200, action_seed=3, t0=230); o.rollout(200, 3, 230)
     assert_state_equal(v, o, 'caller cadence kept')
     assert v.error_flags() == 0
+
+
+@pytest.mark.parametrize('cfg,n,prefetch', [('pogo10', 50, 4), ('axe10', 64, 0), ('bow20', 33, 8), ('fire10h', 40, 0)])
+def test_one_wavefront_handles_with_host_resident_state_match_oracle(cfg, n, prefetch):
+    """Handles of at most 64 envs keep their state in GPU-addressable host memory (the gym.Env adapter's fast path): steps with
+    autoreset, prepared episodes, a fused rollout, masked resets and state round trips equal the oracle."""
+    spec = T.build_spec(cfg)
+    A = len(spec.actions_id)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=9, autoreset=True, horizon=10, reset_prefetch=prefetch)
+    o = Oracle(spec.compile(), n, seed=9, autoreset=True, horizon=10)
+    v.reset(); o.reset()
+    rs = np.random.RandomState(2)
+    for t in range(60):
+        a = rs.randint(0, A, size=n).astype(np.int32)
+        _, reward, done, info = v.step(a); o.step(a)
+        assert (reward == o.reward).all() and (done == o.done.astype(bool)).all() and (info['message_code'] == o.msg_code).all(), t
+        if t == 30:
+            mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+            v.reset(mask); o.reset(mask)
+    assert_state_equal(v, o, cfg + ' host-resident steps')
+    v.rollout(37, action_seed=4, t0=3); o.rollout(37, 4, 3)
+    assert_state_equal(v, o, cfg + ' host-resident rollout')
+    st = v.get_state()
+    v.set_state(0, **{k: st[k] for k in ('map', 'loc', 'facing', 'inv', 'selected', 'step_count', 'episode')})
+    assert_state_equal(v, o, cfg + ' state round trip')
+    with pytest.raises(ValueError):
+        v.step(np.full(n, A, np.int32))                                 # invalid id: raised on the host, nothing stepped
+    assert v.error_flags() == 0
+
+
+def test_big_batch_host_step_uses_one_block_and_matches_oracle():
+    """VecNovelGridworld.step() at 40 000 envs: the host arrays are the sections of one page-locked block (ngw_host_step_layout),
+    the outputs come back with one pack launch + one copy; values equal the oracle's, also without the map (with_obs=False)."""
+    n = 40000
+    spec = T.build_spec('pogo10')
+    A = len(spec.actions_id)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=6, autoreset=True, horizon=9)
+    o = Oracle(spec.compile(), n, seed=6, autoreset=True, horizon=9)
+    v.reset(); o.reset()
+    rs = np.random.RandomState(8)
+    for t in range(25):
+        a = rs.randint(0, A, size=n).astype(np.int32)
+        obs, reward, done, info = v.step(a, with_obs=(t % 5 != 4)); o.step(a)
+        assert (reward == o.reward).all() and (done == o.done.astype(bool)).all(), t
+        assert (info['result'] == o.result.astype(bool)).all() and (info['step_cost_code'] == o.cost_code).all() and (info['message_arg'] == o.msg_arg).all(), t
+        if obs is not None:
+            assert (obs['map'].reshape(n, -1) == o.st.map).all() and (obs['agent_location'] == o.st.loc).all()
+            assert (obs['agent_facing_id'] == o.st.facing).all() and (obs['inventory_items_quantity'] == o.st.inv).all()
+            ls = v.last_state()
+            assert (ls['selected'] == o.st.selected).all() and (ls['step_count'] == o.st.step_count).all()
+    assert_state_equal(v, o, 'one-block host steps')
