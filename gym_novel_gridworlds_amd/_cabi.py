@@ -22,7 +22,7 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_graph_build', 'ngw_graph_launch', 'ngw_lidar_configure', 'ngw_lidar', 'ngw_lidar_fuse',
            'ngw_get_lidar', 'ngw_lidar_device_ptr', 'ngw_host_alloc', 'ngw_host_free', 'ngw_agent_view',
            'ngw_get_agent_view', 'ngw_agent_view_device_ptr', 'ngw_set_reset_prefetch', 'ngw_step_host', 'ngw_lidar_set_output', 'ngw_rollout_actions',
-           'ngw_pack_layout', 'ngw_pack_obs', 'ngw_unpack_obs', 'ngw_rollout_outputs', 'ngw_episode_stats', 'ngw_host_step_layout']
+           'ngw_pack_layout', 'ngw_pack_obs', 'ngw_unpack_obs', 'ngw_rollout_outputs', 'ngw_episode_stats', 'ngw_host_step_layout', 'ngw_step_device_many']
 
 _lib = None
 
@@ -82,6 +82,8 @@ def lib():
     L.ngw_reset.argtypes = [vp, vp]
     L.ngw_step.argtypes = [vp, vp]
     L.ngw_step_device.argtypes = [vp, vp]
+    if hasattr(L, 'ngw_step_device_many'):
+        L.ngw_step_device_many.argtypes = [vp, vp, i64, i32]
     if hasattr(L, 'ngw_step_host'):
         L.ngw_step_host.argtypes = [vp] + [vp] * 14
     L.ngw_rollout.argtypes = [vp, i32, u64, i64]

@@ -727,6 +727,15 @@ int ngw_step_device(ngw_handle* h, const int32_t* actions_dev) {
     return launch(h, NGW_MODE_STEP, 1, actions_dev, nullptr, 0, 0);
 }
 
+int ngw_step_device_many(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps) {
+    if (!h || !actions_dev) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    if (n_steps < 1) return fail(NGW_E_INVALID_ARG, "n_steps must be >= 1");
+    HIP_TRY(hipSetDevice(h->device));
+    for (int32_t i = 0; i < n_steps; i++)
+        if (int rc = launch(h, NGW_MODE_STEP, 1, actions_dev + (int64_t)i * step_stride, nullptr, 0, 0)) return rc;
+    return NGW_OK;
+}
+
 int ngw_rollout(ngw_handle* h, int32_t n_steps, uint64_t action_seed, int64_t t0) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     if (n_steps < 1) return fail(NGW_E_INVALID_ARG, "n_steps must be >= 1");

@@ -210,6 +210,10 @@ class VecNovelGridworld:
         """One batched step with int32 actions already in HBM (`actions_ptr` = device address, e.g. tensor.data_ptr())."""
         _cabi.check(_cabi.lib().ngw_step_device(self._h, C.c_void_p(int(actions_ptr))))
 
+    def step_device_many(self, actions_ptr, step_stride, n_steps):
+        """n_steps batched steps from one call: step i reads int32 actions at device address actions_ptr + 4 * i * step_stride."""
+        _cabi.check(_cabi.lib().ngw_step_device_many(self._h, C.c_void_p(int(actions_ptr)), int(step_stride), int(n_steps)))
+
     def set_reset_prefetch(self, every_n_steps):
         """Keep every env's NEXT episode prepared in shadow buffers and re-prepare consumed ones every `every_n_steps`
         batched steps (include/ngw.h ngw_set_reset_prefetch): resets become a row copy, which matters when episode ends

@@ -218,6 +218,10 @@ int ngw_reset(ngw_handle* h, const uint8_t* mask_host);
 int ngw_step(ngw_handle* h, const int32_t* actions_host);
 /* Same with actions already in HBM; an out-of-range id sets NGW_F_INVALID_ACTION and leaves that env untouched. */
 int ngw_step_device(ngw_handle* h, const int32_t* actions_dev);
+/* n_steps consecutive ngw_step_device launches from ONE call: step i reads actions_dev + i * step_stride (int32 elements).  For
+ * short open-loop stretches where a host loop's per-call overhead (an interpreter, a binding) would outweigh the 4-5 us a step
+ * takes on the device; semantically identical to n_steps calls of ngw_step_device. */
+int ngw_step_device_many(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps);
 /* ngw_step + ngw_get_obs + ngw_get_step_out as ONE call with one stream synchronisation: what a host-driven loop pays per
  * step() is launch and PCIe latency, so the three round trips of the separate calls matter at small batch sizes.  Any
  * output pointer may be NULL; batches whose outputs fit in 1 MiB travel through host memory the GPU addresses directly
