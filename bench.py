@@ -44,6 +44,10 @@ WORKLOADS = {   # name -> (env id, map size, novelty, envs per GPU, description)
     'C3': (BOW, 20, None, 65536, 'NovelGridworld-Bow-v1, 65536 envs/GPU, 20x20'),
     'C4': (POGO, 10, ('axe', 'medium', 'wooden', ''), 32768, "Pogostick-v1 + inject_novelty('axe','medium','wooden'), 32768 envs/GPU, 10x10"),
     'C5': (POGO, 32, ('additem', 'hard', 'arrow', ''), 65536, "Pogostick-v1 + inject_novelty('additem','hard','arrow'), 65536 envs/GPU, 32x32"),
+    # tuning cases (not BASELINE.json configs): the wrapper predicates of the step - FireWall, FenceRestriction, Crate
+    'X1': (POGO, 10, ('firewall', 'hard', '', ''), 65536, "Pogostick-v1 + inject_novelty('firewall','hard'), 65536 envs/GPU, 10x10"),
+    'X2': (POGO, 10, ('fencerestriction', 'hard', 'oak', ''), 65536, "Pogostick-v1 + inject_novelty('fencerestriction','hard','oak'), 65536 envs/GPU, 10x10"),
+    'X3': (POGO, 10, ('crate', 'hard', '', ''), 65536, "Pogostick-v1 + inject_novelty('crate','hard'), 65536 envs/GPU, 10x10"),
 }
 HORIZON = 100                  # per-episode step cap of the reference's evaluation scripts (tests/test.py:30, enjoy.py:107)
 ACTION_SEED = 1234

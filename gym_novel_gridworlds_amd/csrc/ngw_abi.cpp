@@ -68,6 +68,12 @@ struct ngw_handle {
     size_t lidar_lds = 0;
     NgwNx nx = {};                        // prepared next episodes (ngw_set_reset_prefetch); all null = off
     int prefetch_every = 0, since_refill = 0;
+    // The cadence adapts under the DEFAULT setting: resets that find their prepared row stale (an env that ends two episodes
+    // between refills - FireWall kills within a few steps) are counted on the device; the refill launch copies the count to a
+    // host word and the host halves the cadence while it keeps growing, and doubles it back after four quiet refills.
+    int cadence = 0, quiet = 0, adapt = 1;
+    uint32_t slow_seen = 0;
+    bool capturing = false;
     int prefetch_user = 0;                // the caller chose the cadence (ngw_set_reset_prefetch): ngw_set_autoreset leaves it alone
     int32_t* row_reward = nullptr;        // fused rollouts: the caller's output rows (ngw_rollout_outputs)
     uint8_t* row_done = nullptr;
@@ -337,8 +343,19 @@ int launch_reset_fast(ngw_handle* h, int mode, const uint8_t* mask_dev, bool* ta
 }
 
 // Prepared next episodes: one launch re-prepares the shadow rows that resets have consumed since the last one.
+void adapt_cadence(ngw_handle* h) {
+    if (h->capturing || h->prefetch_user || !h->adapt || !h->nx.slow_host) return;
+    const uint32_t cur = *(volatile uint32_t*)h->nx.slow_host;          // as of the last refill launch the GPU has run
+    const uint32_t delta = cur - h->slow_seen;
+    h->slow_seen = cur;
+    const uint32_t many = h->n >= 512 ? (uint32_t)(h->n / 256) : 2u;
+    if (delta >= many) { h->cadence = h->cadence / 2 < 2 ? 2 : h->cadence / 2; h->quiet = 0; }
+    else if (h->cadence < h->prefetch_every && ++h->quiet >= 4) { h->cadence = h->cadence * 2 > h->prefetch_every ? h->prefetch_every : h->cadence * 2; h->quiet = 0; }
+}
+
 int launch_refill(ngw_handle* h) {
     h->since_refill = 0;
+    adapt_cadence(h);
     bool taken = false;
     if (int rc = launch_reset_fast(h, NGW_MODE_REFILL, nullptr, &taken)) return rc;
     if (taken) return NGW_OK;
@@ -367,10 +384,10 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     const unsigned grid = (unsigned)(h->n_pad / NGW_EPB);
     bool taken = false;
     if (mode == NGW_MODE_RESET) { if (int rc = launch_reset_fast(h, NGW_MODE_RESET, mask_dev, &taken)) return rc; }
-    if (!taken && mode == NGW_MODE_STEP && h->lean && h->nostage && !h->lidar_fused && !h->ext) {   // big maps: no-stage lean kernel
+    if (!taken && mode == NGW_MODE_STEP && h->lean && h->nostage && !h->lidar_fused) {   // big maps: no-stage lean kernel
         NgwLaunch q = h->ns_proto;
         q.b = h->b; q.mode = mode; q.n_steps = 1; q.actions = actions_dev; q.autoreset = h->autoreset; q.horizon = h->horizon; q.stamps = h->proto.stamps;
-        HIP_TRY(ngw_launch(h->dspec, &q, h->map_mode, 4 | 8, grid, h->ns_lds, h->stream));
+        HIP_TRY(ngw_launch(h->dspec, &q, h->map_mode, 4 | 8 | (h->ext ? 2 : 0), grid, h->ns_lds, h->stream));
         taken = true;
     }
     if (!taken)
@@ -379,7 +396,7 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
         // Prepared next episodes: every `prefetch_every` batched steps (and right after an explicit reset) one more launch
         // refills the shadow rows that resets have consumed since.  Same stream, so it is ordered between the steps.
         h->since_refill += mode == NGW_MODE_RESET ? h->prefetch_every : n_steps;
-        if (h->since_refill >= h->prefetch_every) return launch_refill(h);
+        if (h->since_refill >= h->cadence) return launch_refill(h);
     }
     return NGW_OK;
 }
@@ -394,6 +411,7 @@ int rollout_chunks(ngw_handle* h, int mode, int32_t n_steps, const int32_t* acti
     if (h->prefetch_every > 0) {
         chunk = h->horizon > 0 ? (h->horizon < 256 ? h->horizon : 256) : 4 * h->prefetch_every;
         if (chunk < h->prefetch_every) chunk = h->prefetch_every;
+        if (h->cadence < h->prefetch_every) chunk = h->cadence < 4 ? 8 : 2 * h->cadence;   // episodes end faster than rows are prepared
     }
     for (int32_t done = 0; done < n_steps; done += chunk) {
         const int32_t k = n_steps - done < chunk ? n_steps - done : chunk;
@@ -467,6 +485,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     h->own_stream = true;
     if (const char* v = getenv("NGW_LEAN")) h->lean = atoi(v) != 0;
     if (const char* v = getenv("NGW_FAST_RESET")) h->fast_reset = atoi(v);
+    if (const char* v = getenv("NGW_ADAPT_PREFETCH")) h->adapt = atoi(v) != 0;
     {
         int min_s2 = 256;                                  // 16 x 16 and larger (measured: see DESIGN.md)
         if (const char* v = getenv("NGW_NOSTAGE")) min_s2 = atoi(v);
@@ -671,12 +690,23 @@ int ngw_set_reset_prefetch(ngw_handle* h, int32_t every_n_steps) {
         if (!rc) rc = dev_alloc(h, &h->nx.facing, np);
         if (!rc) rc = dev_alloc(h, &h->nx.inv, np * K);
         if (!rc) rc = dev_alloc(h, &h->nx.episode, np);
+        if (!rc) rc = dev_alloc(h, &h->nx.slow, 16);
+        if (!rc) {
+            void* q = nullptr;
+            if (hipHostMalloc(&q, 64, hipHostMallocMapped) == hipSuccess) {       // (without it the cadence simply stays fixed)
+                memset(q, 0, 64);
+                h->host_allocs.push_back(q);
+                void* d = nullptr;
+                if (hipHostGetDevicePointer(&d, q, 0) == hipSuccess && d == q) h->nx.slow_host = static_cast<uint32_t*>(q);
+            }
+        }
         if (rc) { h->nx = NgwNx{}; return rc; }
     }
     const NgwNx on_device = every_n_steps > 0 ? h->nx : NgwNx{};      // null pointers switch the consume path off
     HIP_TRY(hipMemcpyAsync(&h->dspec->nx, &on_device, sizeof(NgwNx), hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->prefetch_every = every_n_steps;
+    h->cadence = every_n_steps; h->quiet = 0;
     h->prefetch_user = 1;
     h->since_refill = every_n_steps;                 // the next launch is followed by a refill
     return NGW_OK;
@@ -784,6 +814,10 @@ int ngw_debug_set_stamps(ngw_handle* h, void* stamps_dev) {
     h->proto.stamps = static_cast<uint64_t*>(stamps_dev);
     return NGW_OK;
 }
+
+/* Diagnostics (not part of include/ngw.h): the refill cadence of the prepared episodes right now (0 = off); under the default
+ * setting it adapts between 2 and 32 steps to how fast episodes end. */
+int ngw_debug_refill_cadence(ngw_handle* h) { return h ? (h->prefetch_every > 0 ? h->cadence : 0) : -1; }
 
 /* Diagnostic launches (profiling only, not part of include/ngw.h): mode 8 = empty kernel, 9 = stage in/out only. */
 int ngw_debug_launch(ngw_handle* h, int mode, int32_t n_launches) {
@@ -1308,6 +1342,7 @@ int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stri
     drop_graph(h);
     h->since_refill = 0;                              // the captured refill cadence starts from a known phase
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    h->capturing = true;                              // (the cadence the handle has adapted to so far is the one captured)
     int rc = NGW_OK;
     for (int i = 0; i < n_steps && !rc; i++) rc = launch(h, NGW_MODE_STEP, 1, actions_dev + (int64_t)i * step_stride, nullptr, 0, 0);
     // every replay must leave the refill cadence where it found it: a graph shorter than (or not a multiple of) the cadence
@@ -1316,6 +1351,7 @@ int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stri
         h->since_refill = h->prefetch_every;
         rc = launch_refill(h);
     }
+    h->capturing = false;
     hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
     if (rc) { drop_graph(h); return rc; }
     if (e != hipSuccess) { drop_graph(h); return fail(NGW_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e)); }

@@ -108,6 +108,8 @@ struct NgwNx {
     int32_t* facing;      /* [n_pad]      */
     int32_t* inv;         /* [n_pad][K]   */
     uint32_t* episode;    /* [n_pad] episode the row was prepared for (0 = nothing prepared) */
+    uint32_t* slow;       /* [1] resets that found their row stale and ran the placement loop inside a step (cumulative) */
+    uint32_t* slow_host;  /* [1] GPU-addressable host word every refill launch copies `slow` to: the host adapts the cadence */
 };
 
 /* What the cold reset path needs besides the spec: static per handle, read there with scalar loads from the HBM blob

@@ -400,10 +400,13 @@ __device__ __noinline__ uint32_t new_episode(const NgwDevSpec* dspec, LDS_AS int
     ru.S2 = rp->S2; ru.K = rp->K; ru.CW = rp->CW; ru.perm_lds = rp->perm_lds; ru.magicS = rp->magicS; ru.off_rng = rp->off_rng;
     const GLOBAL_AS uint32_t* rsw = (const GLOBAL_AS uint32_t*)&rp->wall_item;
     const uint32_t rs0 = rsw[0], rs1 = rsw[1], rs2 = rsw[2], rs3 = rsw[3], pw0 = rsw[4], pw1 = rsw[5], pw2 = rsw[6], pw3 = rsw[7];
-    nx.map = np->map; nx.loc = np->loc; nx.facing = np->facing; nx.inv = np->inv; nx.episode = np->episode;
-    if (may_consume && nx.episode && ((const GLOBAL_AS uint32_t*)nx.episode)[env_local] == episode)
-        return consume_lane(nx, mp, inv, (GLOBAL_AS int8_t*)ru.map + env_local * ru.S2, (GLOBAL_AS int32_t*)ru.inv + env_local * ru.K,
-                            env_local, ru.S2, ru.K) | NGW_F_ROWS_STORED;
+    nx.map = np->map; nx.loc = np->loc; nx.facing = np->facing; nx.inv = np->inv; nx.episode = np->episode; nx.slow = np->slow;
+    if (may_consume && nx.episode) {
+        if (((const GLOBAL_AS uint32_t*)nx.episode)[env_local] == episode)
+            return consume_lane(nx, mp, inv, (GLOBAL_AS int8_t*)ru.map + env_local * ru.S2, (GLOBAL_AS int32_t*)ru.inv + env_local * ru.K,
+                                env_local, ru.S2, ru.K) | NGW_F_ROWS_STORED;
+        atomicAdd(nx.slow, 1u);                                                    // a stale row: the host shortens the refill cadence
+    }
     const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS, rs0, rs1, rs2, rs3, pw0, pw1, pw2, pw3};
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_base[];            // the kernel's dynamic LDS (offset 0)
     if (ru.off_rng != 0xFFFFFFFFu)                                                 // which word source: decided with the LDS layout (ngw_abi.cpp)
@@ -771,6 +774,10 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     const bool rolling = MODE == NGW_MODE_ROLLOUT || MODE == NGW_MODE_ROLLOUT_ACT;
     int acc_ret = 0, acc_len = 0, acc_sum = 0, acc_eps = 0;
     if (rolling && a.acc && live) { acc_ret = a.acc[e]; acc_len = a.acc[a.n_pad + e]; acc_sum = a.acc[2 * a.n_pad + e]; acc_eps = a.acc[3 * a.n_pad + e]; }
+    if (MODE == NGW_MODE_REFILL && blockIdx.x == 0 && tid == 0) {                  // what the host reads (without a sync) before the next refill
+        uint32_t* const sh = dspec->nx.slow_host;
+        if (sh) *sh = *dspec->nx.slow;
+    }
     STAMP(3);
     for (int t = 0; t < n_steps; t++, tt++) {
         bool do_reset = false;
@@ -1298,22 +1305,36 @@ extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, in
         hipLaunchKernelGGL(ngw_nop_kernel, dim3(grid * NGW_EPB / tpb), dim3(tpb), a->mode == 12 ? lds_bytes * 2 : 0, stream, dspec, *a);
         return hipGetLastError();
     }
-    if ((feat & 4) && a->mode == NGW_MODE_STEP && !(feat & 3)) {    // plain configuration, one step: the lean kernel
-        if (feat & 8) return launch_lean<NGW_MAP_STRAIGHT, false>(dspec, a, grid, lds_bytes, stream);   // no-stage (big maps)
+    // Everything but the fused LidarInFront epilogue steps through the lean kernels; the wrapper predicates (feat & 2) are a
+    // template flag of the same body.
+#define NGW_LEAN_EXT(CALL_F, CALL_T) ((feat & 2) ? CALL_T : CALL_F)
+    if ((feat & 4) && a->mode == NGW_MODE_STEP && !(feat & 1)) {    // one step
+        if (feat & 8)                                               // no-stage (big maps)
+            return NGW_LEAN_EXT((launch_lean<NGW_MAP_STRAIGHT, false, false>(dspec, a, grid, lds_bytes, stream)),
+                                (launch_lean<NGW_MAP_STRAIGHT, false, true>(dspec, a, grid, lds_bytes, stream)));
         switch (map_mode) {
-        case NGW_MAP_STRAIGHT: return launch_lean<NGW_MAP_STRAIGHT, true>(dspec, a, grid, lds_bytes, stream);
-        case NGW_MAP_DWORD: return launch_lean<NGW_MAP_DWORD, true>(dspec, a, grid, lds_bytes, stream);
-        default: return launch_lean<NGW_MAP_BYTE, true>(dspec, a, grid, lds_bytes, stream);
+        case NGW_MAP_STRAIGHT: return NGW_LEAN_EXT((launch_lean<NGW_MAP_STRAIGHT, true, false>(dspec, a, grid, lds_bytes, stream)),
+                                                   (launch_lean<NGW_MAP_STRAIGHT, true, true>(dspec, a, grid, lds_bytes, stream)));
+        case NGW_MAP_DWORD: return NGW_LEAN_EXT((launch_lean<NGW_MAP_DWORD, true, false>(dspec, a, grid, lds_bytes, stream)),
+                                                (launch_lean<NGW_MAP_DWORD, true, true>(dspec, a, grid, lds_bytes, stream)));
+        default: return NGW_LEAN_EXT((launch_lean<NGW_MAP_BYTE, true, false>(dspec, a, grid, lds_bytes, stream)),
+                                     (launch_lean<NGW_MAP_BYTE, true, true>(dspec, a, grid, lds_bytes, stream)));
         }
     }
-    if ((feat & 4) && !(feat & 3) && (a->mode == NGW_MODE_ROLLOUT || a->mode == NGW_MODE_ROLLOUT_ACT)) {   // plain configuration: lean fused rollout
+    if ((feat & 4) && !(feat & 1) && (a->mode == NGW_MODE_ROLLOUT || a->mode == NGW_MODE_ROLLOUT_ACT)) {   // fused rollout
         const bool sup = a->mode == NGW_MODE_ROLLOUT_ACT;
+#define NGW_LEAN_RO(MM) (sup ? NGW_LEAN_EXT((launch_rollout_lean<MM, true, false>(dspec, a, grid, lds_bytes, stream)),   \
+                                            (launch_rollout_lean<MM, true, true>(dspec, a, grid, lds_bytes, stream)))    \
+                             : NGW_LEAN_EXT((launch_rollout_lean<MM, false, false>(dspec, a, grid, lds_bytes, stream)),  \
+                                            (launch_rollout_lean<MM, false, true>(dspec, a, grid, lds_bytes, stream))))
         switch (map_mode) {
-        case NGW_MAP_STRAIGHT: return sup ? launch_rollout_lean<NGW_MAP_STRAIGHT, true>(dspec, a, grid, lds_bytes, stream) : launch_rollout_lean<NGW_MAP_STRAIGHT, false>(dspec, a, grid, lds_bytes, stream);
-        case NGW_MAP_DWORD: return sup ? launch_rollout_lean<NGW_MAP_DWORD, true>(dspec, a, grid, lds_bytes, stream) : launch_rollout_lean<NGW_MAP_DWORD, false>(dspec, a, grid, lds_bytes, stream);
-        default: return sup ? launch_rollout_lean<NGW_MAP_BYTE, true>(dspec, a, grid, lds_bytes, stream) : launch_rollout_lean<NGW_MAP_BYTE, false>(dspec, a, grid, lds_bytes, stream);
+        case NGW_MAP_STRAIGHT: return NGW_LEAN_RO(NGW_MAP_STRAIGHT);
+        case NGW_MAP_DWORD: return NGW_LEAN_RO(NGW_MAP_DWORD);
+        default: return NGW_LEAN_RO(NGW_MAP_BYTE);
         }
+#undef NGW_LEAN_RO
     }
+#undef NGW_LEAN_EXT
     switch (map_mode) {
     case NGW_MAP_STRAIGHT: return launch_feat<NGW_MAP_STRAIGHT>(dspec, a, feat, grid, lds_bytes, stream);
     case NGW_MAP_DWORD: return launch_feat<NGW_MAP_DWORD>(dspec, a, feat, grid, lds_bytes, stream);
