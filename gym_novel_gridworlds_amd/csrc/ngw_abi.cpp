@@ -305,17 +305,34 @@ void layout_reset_fast(ngw_handle* h) {
     int n_place = 0;
     for (int j = 0; j < s.n_start; j++) n_place += s.start_qty[j];
     const int nw = CW <= 2 ? 2 : (CW <= 8 ? 8 : 0);
+    // AddItem's shuffle array: 10-bit elements, three per dword, where every cell id fits (maps up to 32 x 32; override:
+    // NGW_RESET_PACK=0) - 77 KB per wave at 32 x 32 instead of 115 KB, so two waves share a CU
+    bool pack = additem_only && S2 <= 1024 && CW <= 25 && n_place <= 12;      // (the kernel keeps the placed cells in 12 registers)
+    if (const char* v = getenv("NGW_RESET_PACK")) pack = pack && atoi(v) != 0;
+    const uint32_t tmpl_dw = (uint32_t)((2 * S2 + 16 + NGW_MAX_PLACE + 3) / 4);
+    const uint32_t placed_dw = (uint32_t)((n_place > 0 ? n_place : 1) * NGW_EPB);
     uint32_t off = 0;
     a.off_ring = off; off += 16 * NGW_EPB;
-    a.off_masks = off; if (nw == 0) off += (uint32_t)(3 * CW * NGW_EPB);
-    a.off_placed = off; off += (uint32_t)((n_place > 0 ? n_place : 1) * NGW_EPB);
-    a.off_tmpl = off; off += (uint32_t)((2 * S2 + 16 + NGW_MAX_PLACE + 3) / 4);
-    off = (off + 3u) & ~3u;
-    a.off_perm = off;
-    if (additem_only) off += (uint32_t)(((S - 2) * (S - 2) + 1) * NGW_EPB * 2 / 4);   // + one spare row (rejected / idle lanes store there)
+    if (pack) {
+        // candidate / blocked masks, the placed list and the template are dead before the array is built: they overlay it
+        const uint32_t perm_dw = (uint32_t)(((S - 2) * (S - 2) + 2) / 3 + 1) * NGW_EPB;
+        a.off_perm = off;
+        uint32_t o = off;
+        a.off_masks = o; if (nw == 0) o += (uint32_t)(2 * CW * NGW_EPB);
+        a.off_placed = o; o += placed_dw;
+        a.off_tmpl = o; o += tmpl_dw;
+        off += perm_dw > o - off ? perm_dw : o - off;
+    } else {
+        a.off_masks = off; if (nw == 0) off += (uint32_t)(3 * CW * NGW_EPB);
+        a.off_placed = off; off += placed_dw;
+        a.off_tmpl = off; off += tmpl_dw;
+        off = (off + 3u) & ~3u;
+        a.off_perm = off;
+        if (additem_only) off += (uint32_t)(((S - 2) * (S - 2) + 1) * NGW_EPB * 2 / 4);   // + one spare row (rejected / idle lanes store there)
+    }
     if ((size_t)off * 4 > 160 * 1024) return;                                       // the shuffle array does not fit: general kernel
     h->rf_lds = (size_t)off * 4;
-    h->rf_nw = nw; h->rf_additem = additem_only ? 1 : 0;
+    h->rf_nw = nw; h->rf_additem = additem_only ? (pack ? 2 : 1) : 0;
     a.main = h->b; a.nx = h->nx;
     a.pctq = reinterpret_cast<const double*>(h->dspec->pctq[0]);
     a.n = h->n; a.env_base = h->env_base; a.seed = h->seed; a.flags = h->b.flags;
@@ -329,6 +346,8 @@ void layout_reset_fast(ngw_handle* h) {
     const uint32_t W = (uint32_t)(S - 4);
     a.magicW = W ? (uint32_t)((0x100000000ull + W - 1) / W) : 0;
     a.magicS2 = (uint32_t)((0x100000000ull + (uint32_t)S2 - 1) / (uint32_t)S2);
+    a.magicS = (uint32_t)((0x100000000ull + (uint32_t)S - 1) / (uint32_t)S);
+    a.magicIW = S > 2 ? (uint32_t)((0x100000000ull + (uint32_t)(S - 2) - 1) / (uint32_t)(S - 2)) : 0;
 }
 
 // mode = NGW_MODE_RESET (mask_dev or nullptr) / NGW_MODE_REFILL; returns 1 if the dedicated kernel took the launch

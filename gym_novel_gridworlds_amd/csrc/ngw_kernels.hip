@@ -1286,8 +1286,9 @@ __global__ void ngw_nop_kernel(const NgwDevSpec* dspec, const NgwLaunch a) {}
 extern "C" hipError_t ngw_reset_fast_launch(const NgwDevSpec* dspec, const NgwResetFast* a, int nw, int additem, unsigned grid, size_t lds_bytes,
                                             hipStream_t stream) {
     const void* fn = nullptr;
-#define NGW_RF(NWV, AV) if (nw == NWV && additem == AV) fn = reinterpret_cast<const void*>(ngw_reset_fast<NWV, AV != 0>)
-    NGW_RF(2, 0); NGW_RF(2, 1); NGW_RF(8, 0); NGW_RF(8, 1); NGW_RF(0, 0); NGW_RF(0, 1);
+    // additem: 0 = plain, 1 = AddItem with a u16 shuffle array, 2 = AddItem with the packed 10-bit array (maps up to 32 x 32)
+#define NGW_RF(NWV, AV) if (nw == NWV && additem == AV) fn = reinterpret_cast<const void*>(ngw_reset_fast<NWV, AV != 0, AV == 2>)
+    NGW_RF(2, 0); NGW_RF(2, 1); NGW_RF(2, 2); NGW_RF(8, 0); NGW_RF(8, 1); NGW_RF(8, 2); NGW_RF(0, 0); NGW_RF(0, 1); NGW_RF(0, 2);
 #undef NGW_RF
     if (!fn) return hipErrorInvalidValue;
     if (lds_bytes > 64 * 1024) {
