@@ -347,7 +347,7 @@ void layout_reset_fast(ngw_handle* h) {
     a.magicW = W ? (uint32_t)((0x100000000ull + W - 1) / W) : 0;
     a.magicS2 = (uint32_t)((0x100000000ull + (uint32_t)S2 - 1) / (uint32_t)S2);
     a.magicS = (uint32_t)((0x100000000ull + (uint32_t)S - 1) / (uint32_t)S);
-    a.magicIW = S > 2 ? (uint32_t)((0x100000000ull + (uint32_t)(S - 2) - 1) / (uint32_t)(S - 2)) : 0;
+    a.magicIW22 = S > 3 ? (uint32_t)(((1u << 22) + (uint32_t)(S - 2) - 1) / (uint32_t)(S - 2)) : 0;
 }
 
 // mode = NGW_MODE_RESET (mask_dev or nullptr) / NGW_MODE_REFILL; returns 1 if the dedicated kernel took the launch
