@@ -58,6 +58,9 @@ struct ngw_handle {
     std::vector<void*> host_allocs;       // state of a single-wavefront handle kept in GPU-addressable host memory (hostres)
     int hostres = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing pair
+    hipEvent_t gev0 = nullptr, gev1 = nullptr; // recorded by the first / last node of the captured graph (ngw_graph_elapsed)
+    bool graph_timed = false;
+    bool ev_marked = false;                    // ngw_timing_mark recorded the closing event already
     // LidarInFront observation
     NgwLidarDev* lidar_cfg = nullptr;     // device tables
     int32_t* lidar_out = nullptr;
@@ -675,6 +678,8 @@ int ngw_destroy(ngw_handle* h) {
     drop_graph(h);
     if (h->info_host) (void)hipHostFree(h->info_host);
     if (h->zc_host) (void)hipHostFree(h->zc_host);
+    if (h->gev0) (void)hipEventDestroy(h->gev0);
+    if (h->gev1) (void)hipEventDestroy(h->gev1);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -1333,11 +1338,33 @@ int ngw_agent_view_device_ptr(ngw_handle* h, void** out) {
     return NGW_OK;
 }
 
+int ngw_graph_elapsed(ngw_handle* h, double* elapsed_ms) {
+    if (!h || !elapsed_ms) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    if (!h->graph_exec) return fail(NGW_E_INVALID_ARG, "no graph: call ngw_graph_build first");
+    if (!h->graph_timed) return fail(NGW_E_HIP, "this HIP runtime did not accept event-record nodes in the graph");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventSynchronize(h->gev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->gev0, h->gev1));
+    *elapsed_ms = ms;
+    return NGW_OK;
+}
+
 int ngw_timing_begin(ngw_handle* h) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     HIP_TRY(hipSetDevice(h->device));
     if (!h->ev0) { HIP_TRY(hipEventCreate(&h->ev0)); HIP_TRY(hipEventCreate(&h->ev1)); }
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    h->ev_marked = false;
+    return NGW_OK;
+}
+
+int ngw_timing_mark(ngw_handle* h) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (!h->ev0) return fail(NGW_E_INVALID_ARG, "ngw_timing_mark without ngw_timing_begin");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    h->ev_marked = true;
     return NGW_OK;
 }
 
@@ -1345,7 +1372,8 @@ int ngw_timing_end(ngw_handle* h, double* elapsed_ms) {
     if (!h || !elapsed_ms) return fail(NGW_E_INVALID_ARG, "NULL argument");
     if (!h->ev0) return fail(NGW_E_INVALID_ARG, "ngw_timing_end without ngw_timing_begin");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    if (!h->ev_marked) HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    h->ev_marked = false;
     HIP_TRY(hipEventSynchronize(h->ev1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
@@ -1360,6 +1388,7 @@ int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stri
     HIP_TRY(hipStreamSynchronize(h->stream));
     drop_graph(h);
     h->since_refill = 0;                              // the captured refill cadence starts from a known phase
+    if (!h->gev0) { HIP_TRY(hipEventCreate(&h->gev0)); HIP_TRY(hipEventCreate(&h->gev1)); }
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     h->capturing = true;                              // (the cadence the handle has adapted to so far is the one captured)
     int rc = NGW_OK;
@@ -1374,6 +1403,31 @@ int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stri
     hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
     if (rc) { drop_graph(h); return rc; }
     if (e != hipSuccess) { drop_graph(h); return fail(NGW_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e)); }
+    {   // event-record nodes before the first and after the last captured launch: ngw_graph_elapsed times the replay's own
+        // kernels, without the latency of launching the graph.  (Best effort: without them ngw_graph_elapsed reports an error.)
+        h->graph_timed = false;
+        size_t n_nodes = 0, n_edges = 0, n_roots = 0;
+        if (hipGraphGetNodes(h->graph, nullptr, &n_nodes) == hipSuccess && n_nodes > 0 &&
+            hipGraphGetEdges(h->graph, nullptr, nullptr, &n_edges) == hipSuccess && hipGraphGetRootNodes(h->graph, nullptr, &n_roots) == hipSuccess && n_roots == 1) {
+            std::vector<hipGraphNode_t> nodes(n_nodes), from(n_edges ? n_edges : 1), to(n_edges ? n_edges : 1);
+            hipGraphNode_t root = nullptr;
+            bool ok = hipGraphGetNodes(h->graph, nodes.data(), &n_nodes) == hipSuccess && hipGraphGetRootNodes(h->graph, &root, &n_roots) == hipSuccess;
+            if (ok && n_edges) ok = hipGraphGetEdges(h->graph, from.data(), to.data(), &n_edges) == hipSuccess;
+            hipGraphNode_t leaf = nullptr;
+            int n_leaves = 0;
+            for (size_t i = 0; ok && i < n_nodes; i++) {
+                bool has_out = false;
+                for (size_t k = 0; k < n_edges; k++) has_out |= from[k] == nodes[i];
+                if (!has_out) { leaf = nodes[i]; n_leaves++; }
+            }
+            hipGraphNode_t e0 = nullptr, e1 = nullptr;
+            if (ok && n_leaves == 1 && hipGraphAddEventRecordNode(&e0, h->graph, nullptr, 0, h->gev0) == hipSuccess &&
+                hipGraphAddDependencies(h->graph, &e0, &root, 1) == hipSuccess &&
+                hipGraphAddEventRecordNode(&e1, h->graph, &leaf, 1, h->gev1) == hipSuccess)
+                h->graph_timed = true;
+        }
+        (void)hipGetLastError();
+    }
     e = hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0);
     if (e != hipSuccess) { drop_graph(h); return fail(NGW_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
     (void)hipGraphUpload(h->graph_exec, h->stream);   // pre-stage the graph so the first replay does not pay for it

@@ -285,12 +285,18 @@ int ngw_error_flags(ngw_handle* h, uint32_t* flags);
  * recorded on that stream (bench.py roofline leg: elapsed / launches = average launch duration incl. gaps). */
 int ngw_timing_begin(ngw_handle* h);
 int ngw_timing_end(ngw_handle* h, double* elapsed_ms);
+/* Records the closing event now, without waiting: a later ngw_timing_end only waits for it and reads the pair (a caller that
+ * synchronises anyway - a benchmark's closing fence - keeps the event wait out of its wall-clock region). */
+int ngw_timing_mark(ngw_handle* h);
 
 /* hipGraph stepping for launch-bound loops: captures n_steps consecutive ngw_step_device launches whose
  * actions are read from actions_dev + i * step_stride (int32 elements) into one executable graph, then replays it.
  * Semantically identical to calling ngw_step_device n_steps * reps times with those action rows. */
 int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps);
 int ngw_graph_launch(ngw_handle* h, int32_t reps);
+/* Device time of the LAST replay, first node to last node (event-record nodes captured with the launches): what the replay's
+ * kernels took, without the latency of launching the graph itself.  Waits for that replay to finish. */
+int ngw_graph_elapsed(ngw_handle* h, double* elapsed_ms);
 
 /* Multi-GPU observation stack (the only collective of the path, outside step()).  One process per GPU,
  * each with its own handle; per step (or whenever the host wants the whole batch) every rank packs its observation and
