@@ -60,9 +60,13 @@ CFGS.update({
 # configurations WITHOUT reference fixtures (larger maps of pinned components: the oracle is the checker there)
 CFGS.update({'fire32m': (POGO, 32, ('firewall', 'medium', '', '')), 'fencer24h': (BOW, 24, ('fencerestriction', 'hard', 'oak', '')),
              'repl40e': (POGO, 40, ('replaceitem', 'easy', 'wall', 'brick'))})
-NO_FIXTURES = ('fire32m', 'fencer24h', 'repl40e')
+# AddItem at every mask width of the new-episode kernel (register masks of 2 / 8 words, LDS masks) and beyond the packed array
+CFGS.update({'add18h': (BOW, 18, ('additem', 'hard', 'arrow', '')), 'add24m': (POGO, 24, ('additem', 'medium', 'arrow', '')),
+             'add29h': (BOW, 29, ('additem', 'hard', 'spring', '')), 'add36e': (POGO, 36, ('additem', 'easy', 'arrow', '')),
+             'crate20h': (POGO, 20, ('crate', 'hard', '', ''))})
+NO_FIXTURES = ('fire32m', 'fencer24h', 'repl40e', 'add18h', 'add24m', 'add29h', 'add36e', 'crate20h')
 REMAP_SEED = {'remape10': 11, 'remapm10': 12, 'remaph10': 13, 'crate10m': 31, 'crate12h': 32, 'crate11e': 33,
-              'stk_crate_fr12': 34, 'stk_fr_crate12': 35, 'stk_crate_bi10': 36, 'stk_add_crate12': 37, 'stk_crate_add12': 38}
+              'stk_crate_fr12': 34, 'stk_fr_crate12': 35, 'stk_crate_bi10': 36, 'stk_add_crate12': 37, 'stk_crate_add12': 38, 'crate20h': 39}
 HEADLINE = ['pogo10', 'bow20', 'axe10', 'add32']       # BASELINE.json configs 2-5
 
 _spec_json = None

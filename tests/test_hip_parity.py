@@ -677,3 +677,31 @@ def test_refill_cadence_adapts_to_short_episodes_and_results_stay_exact():
     v.rollout(300, action_seed=8, t0=0); assert o.rollout(300, 8, 0) == 0
     assert_state_equal(v, o, 'fire10h adaptive cadence, fused')
     assert v.error_flags() == 0
+
+
+@pytest.mark.parametrize('pack', ['1', '0'])
+@pytest.mark.parametrize('cfg,n', [('add12m', 700), ('add18h', 500), ('add24m', 300), ('add29h', 200), ('add32', 260), ('add36e', 130), ('crate20h', 400)])
+def test_additem_new_episode_kernel_every_variant(cfg, n, pack, monkeypatch):
+    """The dedicated new-episode kernel with AddItem's shuffle array packed to 10-bit ordinals (maps up to 32 x 32) and as
+    u16 cells (NGW_RESET_PACK=0, and always beyond 32 x 32), at every mask width (register masks of 2 / 8 words, LDS masks):
+    explicit resets, masked resets, prepared episodes under autoreset and a fused rollout equal the oracle."""
+    monkeypatch.setenv('NGW_RESET_PACK', pack)
+    spec = T.build_spec(cfg)
+    A = len(spec.actions_id)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=5, autoreset=True, horizon=12, env_index_base=3)
+    o = Oracle(spec.compile(), n, seed=5, autoreset=True, horizon=12, env_index_base=3)
+    for ep in range(2):
+        v.reset(); assert o.reset() == 0
+        assert_state_equal(v, o, '%s pack=%s reset %d' % (cfg, pack, ep))
+    mask = (np.arange(n) % 5 == 1).astype(np.uint8)
+    v.reset(mask); o.reset(mask)
+    assert_state_equal(v, o, '%s pack=%s masked reset' % (cfg, pack))
+    rs = np.random.RandomState(8)
+    for t in range(40):
+        a = rs.randint(0, A, size=n).astype(np.int32)
+        _, reward, done, info = v.step(a); o.step(a)
+        assert (reward == o.reward).all() and (done == o.done.astype(bool)).all(), t
+    assert_state_equal(v, o, '%s pack=%s stepped' % (cfg, pack))
+    v.rollout(30, action_seed=3, t0=0); assert o.rollout(30, 3, 0) == 0
+    assert_state_equal(v, o, '%s pack=%s fused' % (cfg, pack))
+    assert v.error_flags() == 0

@@ -10,12 +10,21 @@ timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT
 for W in C4 C5; do
   timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --single-device --workload $W --no-cpu-baseline --steps 400 > $OUT/bench_2rank_$W.log 2>&1; grep '^{' $OUT/bench_2rank_$W.log | tail -1 > $OUT/bench_2rank_$W.json
 done
-timeout -k 10 300 python tools/reset_time.py > $OUT/reset_time.log 2>&1
+for W in X1 X2 X3; do   # wrapper predicates (FireWall, FenceRestriction, Crate): lean kernel vs round 1's general kernel
+  for L in 1 0; do
+    NGW_LEAN=$L timeout -k 10 200 python bench.py --workload $W --no-cpu-baseline --no-side > $OUT/bench_${W}_lean$L.log 2>&1; grep '^{' $OUT/bench_${W}_lean$L.log | tail -1 > $OUT/bench_${W}_lean$L.json
+  done
+done
+timeout -k 10 100 python tools/short_run.py 20 > $OUT/short_run.log 2>&1
+timeout -k 10 300 python tools/reset_time.py C2 C3 C4 C5 X1 X2 X3 > $OUT/reset_time.log 2>&1
+NGW_RESET_PACK=0 timeout -k 10 300 python tools/reset_time.py C5 > $OUT/reset_time_u16.log 2>&1
 NGW_FAST_RESET=0 timeout -k 10 300 python tools/reset_time.py > $OUT/reset_time_general.log 2>&1
 timeout -k 10 100 python tools/adapter_latency.py > $OUT/adapter.log 2>&1
 timeout -k 10 200 python tools/api_latency.py > $OUT/api.log 2>&1
 if [ -f gym_novel_gridworlds_amd/libngw_hip_stamps.so ]; then
   NGW_LIB=$PWD/gym_novel_gridworlds_amd/libngw_hip_stamps.so timeout -k 10 300 python tools/stamp_timeline.py C2 C3 C4 C5 > $OUT/stamps.log 2>&1
   NGW_LIB=$PWD/gym_novel_gridworlds_amd/libngw_hip_stamps.so NGW_LEAN=0 timeout -k 10 300 python tools/stamp_timeline.py C2 > $OUT/stamps_general.log 2>&1
+  NGW_LIB=$PWD/gym_novel_gridworlds_amd/libngw_hip_stamps.so timeout -k 10 300 python tools/stamp_reset.py C5 > $OUT/stamps_reset.log 2>&1
+  NGW_LIB=$PWD/gym_novel_gridworlds_amd/libngw_hip_stamps.so NGW_RESET_PACK=0 timeout -k 10 300 python tools/stamp_reset.py C5 > $OUT/stamps_reset_u16.log 2>&1
 fi
 echo matrix done

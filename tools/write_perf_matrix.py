@@ -32,6 +32,10 @@ def trim(x):
 
 for f, title in [('bench_C2', 'C2 `python bench.py`'), ('bench_C3', 'C3 `--workload C3`'), ('bench_C4', 'C4 `--workload C4`'), ('bench_C5', 'C5 `--workload C5`'),
                  ('bench_C2_driver_style', 'C2 driver-style `--steps 20 --warmup 5` (eager launches below 100 steps)'),
+                 ('bench_X1_lean1', 'X1 FireWall hard (`--workload X1 --no-side`): lean kernel with the wrapper predicates'),
+                 ('bench_X1_lean0', "X1, round 1's general kernel (`NGW_LEAN=0`)"),
+                 ('bench_X2_lean1', 'X2 FenceRestriction hard'), ('bench_X2_lean0', 'X2, general kernel'),
+                 ('bench_X3_lean1', 'X3 Crate hard'), ('bench_X3_lean0', 'X3, general kernel'),
                  ('bench_2rank_C4', '2 ranks on ONE GPU (rehearsal of the N > 1 path; the ranks share the GPU, so per-rank rates halve): `python bench.py --gpus 2 --dist-backend gloo --single-device --workload C4 --steps 400`'),
                  ('bench_2rank_C5', '2 ranks on ONE GPU: `... --workload C5 --steps 400`')]:
     try:
@@ -41,6 +45,10 @@ for f, title in [('bench_C2', 'C2 `python bench.py`'), ('bench_C3', 'C3 `--workl
     out.append('## %s\n\n```json\n%s\n```\n' % (title, json.dumps(trim(x))))
 for f, title in [('reset_time.log', 'Reset launches (`tools/reset_time.py`, HIP events, eager; dedicated kernel where it applies)'),
                  ('reset_time_general.log', 'Reset launches, general kernel only (`NGW_FAST_RESET=0`)'),
+                 ('reset_time_u16.log', "C5 reset launches with the shuffle array as u16 (`NGW_RESET_PACK=0`: one wave per CU)"),
+                 ('short_run.log', 'A 20-step region fence to fence, eager vs one graph replay (`tools/short_run.py`)'),
+                 ('stamps_reset.log', 'In-kernel timeline of the new-episode kernel at C5 (`tools/stamp_reset.py`, stamps build)'),
+                 ('stamps_reset_u16.log', 'The same with the u16 shuffle array (`NGW_RESET_PACK=0`)'),
                  ('adapter.log', 'Single-env adapter (`tools/adapter_latency.py`)'), ('api.log', 'Host API by batch size (`tools/api_latency.py`)'),
                  ('stamps.log', 'In-kernel timelines of one step launch (`tools/stamp_timeline.py`, stamps build)'),
                  ('stamps_general.log', "The same for round 1's general kernel at C2 (`NGW_LEAN=0`)")]:
