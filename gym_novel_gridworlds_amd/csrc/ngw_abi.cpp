@@ -74,7 +74,7 @@ struct ngw_handle {
     // The cadence adapts under the DEFAULT setting: resets that find their prepared row stale (an env that ends two episodes
     // between refills - FireWall kills within a few steps) are counted on the device; the refill launch copies the count to a
     // host word and the host halves the cadence while it keeps growing, and doubles it back after four quiet refills.
-    int cadence = 0, quiet = 0, adapt = 1;
+    int cadence = 0, quiet = 0, noisy = 0, adapt = 1;
     uint32_t slow_seen = 0;
     bool capturing = false;
     int prefetch_user = 0;                // the caller chose the cadence (ngw_set_reset_prefetch): ngw_set_autoreset leaves it alone
@@ -371,8 +371,10 @@ void adapt_cadence(ngw_handle* h) {
     const uint32_t delta = cur - h->slow_seen;
     h->slow_seen = cur;
     const uint32_t many = h->n >= 512 ? (uint32_t)(h->n / 256) : 2u;
-    if (delta >= many) { h->cadence = h->cadence / 2 < 2 ? 2 : h->cadence / 2; h->quiet = 0; }
-    else if (h->cadence < h->prefetch_every && ++h->quiet >= 4) { h->cadence = h->cadence * 2 > h->prefetch_every ? h->prefetch_every : h->cadence * 2; h->quiet = 0; }
+    if (delta >= many) {                                            // two noisy refills in a row: a one-off burst (stale tags after
+        h->quiet = 0;                                               // ngw_set_state, the first steps of a handle) does not count
+        if (++h->noisy >= 2) { h->cadence = h->cadence / 2 < 2 ? 2 : h->cadence / 2; h->noisy = 0; }
+    } else if ((h->noisy = 0, h->cadence < h->prefetch_every) && ++h->quiet >= 4) { h->cadence = h->cadence * 2 > h->prefetch_every ? h->prefetch_every : h->cadence * 2; h->quiet = 0; }
 }
 
 int launch_refill(ngw_handle* h) {
@@ -730,7 +732,7 @@ int ngw_set_reset_prefetch(ngw_handle* h, int32_t every_n_steps) {
     HIP_TRY(hipMemcpyAsync(&h->dspec->nx, &on_device, sizeof(NgwNx), hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->prefetch_every = every_n_steps;
-    h->cadence = every_n_steps; h->quiet = 0;
+    h->cadence = every_n_steps; h->quiet = 0; h->noisy = 0;
     h->prefetch_user = 1;
     h->since_refill = every_n_steps;                 // the next launch is followed by a refill
     return NGW_OK;
