@@ -204,12 +204,11 @@ def main():
 
     start_episodes()
     GRAPH_MAX = 2048                      # kernel nodes per graph; longer runs replay it (its action rows repeat)
-    # ONE graph launch enqueues the whole region (15 us of host time for 20 launches; the eager loop needs ~4.5 us per launch and
-    # is host-bound: tools/short_run.py, 20 steps fence to fence 97 us vs 110 us).  The device-side average launch duration for
-    # the roofline comes from event-record nodes captured with the launches (ngw_graph_elapsed), i.e. without the ~15 us a graph
-    # launch takes to start its first kernel.
-    # (The FIRST launch of an instantiated graph costs ~70 us more than a later one - measured here, 20 steps: 187 us fence to
-    #  fence against 135 us eager - so regions shorter than 100 launches are issued eagerly, from one C-ABI call.)
+    # ONE graph launch enqueues the whole region (15 us of host time for 20 launches; an eager launch costs ~3.3 us of host time),
+    # but the FIRST launch of an instantiated graph costs ~70 us more than a later one (20 steps fence to fence: 187 us against
+    # 110 us eager), so regions shorter than 100 launches are issued eagerly, from one C-ABI call (tools/short_run.py).
+    # (Tried: event-record nodes inside the graph to time a replay without its launch latency - two such nodes cost ~80 us per
+    #  replay on this runtime, more than they explain.)
     use_graph = args.mode == 'step' and args.launch == 'graph' and steps >= 100
     ptrs = []
     if args.mode == 'step' or not args.no_side:
@@ -272,7 +271,6 @@ def main():
     fence()
     ep_before = episode0()
     fence()
-    one_replay = use_graph and steps == g_steps
     v.timing_begin()                      # HIP event pair on the kernel's own stream, around the timed launches
     t0 = time.perf_counter()
     run_timed()
@@ -280,11 +278,6 @@ def main():
     fence(closing=True)
     dt = time.perf_counter() - t0
     dev_ms = v.timing_end()
-    if one_replay:
-        try:
-            dev_ms = v.graph_elapsed()    # the same pair, recorded by the graph's first and last node
-        except Exception:
-            one_replay = False            # (runtime without event-record nodes: keep the outer pair)
     assert v.error_flags() == 0
     resets_timed = episode0() - ep_before
     dt, dev_ms = reduce_max([dt, dev_ms])
@@ -311,8 +304,7 @@ def main():
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel': 'ngw_step_lean',
                     'kernel_ms_avg': round(launch_ms, 6), 'launches_timed': launches,
                     'algorithmic_bytes_per_env_step': B, 'env_steps_per_launch': n * steps_per_launch,
-                    'timing': ('HIP event pair recorded by the first and last node of the replayed graph' if one_replay else
-                               'HIP event pair on the kernel stream around the timed launches') + ' (includes inter-launch gaps and the reset launches)'}
+                    'timing': 'HIP event pair on the kernel stream around the timed launches (includes inter-launch gaps and the reset launches)'}
         tr, src = traffic_of('step', n)
         if tr:
             roofline['traffic'], roofline['traffic_source'] = tr, src

@@ -58,8 +58,6 @@ struct ngw_handle {
     std::vector<void*> host_allocs;       // state of a single-wavefront handle kept in GPU-addressable host memory (hostres)
     int hostres = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing pair
-    hipEvent_t gev0 = nullptr, gev1 = nullptr; // recorded by the first / last node of the captured graph (ngw_graph_elapsed)
-    bool graph_timed = false;
     bool ev_marked = false;                    // ngw_timing_mark recorded the closing event already
     // LidarInFront observation
     NgwLidarDev* lidar_cfg = nullptr;     // device tables
@@ -308,30 +306,25 @@ void layout_reset_fast(ngw_handle* h) {
     int n_place = 0;
     for (int j = 0; j < s.n_start; j++) n_place += s.start_qty[j];
     const int nw = CW <= 2 ? 2 : (CW <= 8 ? 8 : 0);
-    // AddItem's shuffle array: 10-bit elements, three per dword, where every cell id fits (maps up to 32 x 32; override:
-    // NGW_RESET_PACK=0) - 77 KB per wave at 32 x 32 instead of 115 KB, so two waves share a CU
-    bool pack = additem_only && S2 <= 1024 && CW <= 25 && n_place <= 12;      // (the kernel keeps the placed cells in 12 registers)
+    // AddItem's shuffle array holds ordinals + 1: 10-bit elements, three per dword, up to 32 x 32 (override: NGW_RESET_PACK=0) -
+    // 77 KB per wave at 32 x 32 instead of 115 KB as u16, so two waves share a CU; u16 beyond.  The kernel keeps the placed
+    // cells in 12 registers.
+    if (additem_only && n_place > 12) return;
+    bool pack = additem_only && S2 <= 1024;
     if (const char* v = getenv("NGW_RESET_PACK")) pack = pack && atoi(v) != 0;
     const uint32_t tmpl_dw = (uint32_t)((2 * S2 + 16 + NGW_MAX_PLACE + 3) / 4);
     const uint32_t placed_dw = (uint32_t)((n_place > 0 ? n_place : 1) * NGW_EPB);
+    const int nint = (S - 2) * (S - 2);
     uint32_t off = 0;
     a.off_ring = off; off += 16 * NGW_EPB;
-    if (pack) {
-        // candidate / blocked masks, the placed list and the template are dead before the array is built: they overlay it
-        const uint32_t perm_dw = (uint32_t)(((S - 2) * (S - 2) + 2) / 3 + 1) * NGW_EPB;
-        a.off_perm = off;
-        uint32_t o = off;
-        a.off_masks = o; if (nw == 0) o += (uint32_t)(2 * CW * NGW_EPB);
-        a.off_placed = o; o += placed_dw;
-        a.off_tmpl = o; o += tmpl_dw;
-        off += perm_dw > o - off ? perm_dw : o - off;
-    } else {
-        a.off_masks = off; if (nw == 0) off += (uint32_t)(3 * CW * NGW_EPB);
-        a.off_placed = off; off += placed_dw;
-        a.off_tmpl = off; off += tmpl_dw;
-        off = (off + 3u) & ~3u;
-        a.off_perm = off;
-        if (additem_only) off += (uint32_t)(((S - 2) * (S - 2) + 1) * NGW_EPB * 2 / 4);   // + one spare row (rejected / idle lanes store there)
+    a.off_perm = off;
+    // candidate / blocked masks, the placed list and the template are dead before the array is touched: they overlay it
+    a.off_masks = off; if (nw == 0) off += (uint32_t)(2 * CW * NGW_EPB);
+    a.off_placed = off; off += placed_dw;
+    a.off_tmpl = off; off += tmpl_dw;
+    if (additem_only) {
+        const uint32_t perm_dw = pack ? (uint32_t)((nint + 2) / 3 + 1) * NGW_EPB : (uint32_t)((nint + 1) * NGW_EPB * 2 / 4 + 1);
+        if (a.off_perm + perm_dw > off) off = a.off_perm + perm_dw;
     }
     if ((size_t)off * 4 > 160 * 1024) return;                                       // the shuffle array does not fit: general kernel
     h->rf_lds = (size_t)off * 4;
@@ -351,6 +344,7 @@ void layout_reset_fast(ngw_handle* h) {
     a.magicS2 = (uint32_t)((0x100000000ull + (uint32_t)S2 - 1) / (uint32_t)S2);
     a.magicS = (uint32_t)((0x100000000ull + (uint32_t)S - 1) / (uint32_t)S);
     a.magicIW22 = S > 3 ? (uint32_t)(((1u << 22) + (uint32_t)(S - 2) - 1) / (uint32_t)(S - 2)) : 0;
+    a.magicIW = S > 3 ? (uint32_t)((0x100000000ull + (uint32_t)(S - 2) - 1) / (uint32_t)(S - 2)) : 0;
 }
 
 // mode = NGW_MODE_RESET (mask_dev or nullptr) / NGW_MODE_REFILL; returns 1 if the dedicated kernel took the launch
@@ -680,8 +674,6 @@ int ngw_destroy(ngw_handle* h) {
     drop_graph(h);
     if (h->info_host) (void)hipHostFree(h->info_host);
     if (h->zc_host) (void)hipHostFree(h->zc_host);
-    if (h->gev0) (void)hipEventDestroy(h->gev0);
-    if (h->gev1) (void)hipEventDestroy(h->gev1);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -844,6 +836,16 @@ int ngw_debug_set_stamps(ngw_handle* h, void* stamps_dev) {
 /* Diagnostics (not part of include/ngw.h): the refill cadence of the prepared episodes right now (0 = off); under the default
  * setting it adapts between 2 and 32 steps to how fast episodes end. */
 int ngw_debug_refill_cadence(ngw_handle* h) { return h ? (h->prefetch_every > 0 ? h->cadence : 0) : -1; }
+
+/* Diagnostics: resets that found no prepared episode (stale row) and ran the placement loop inside a step or rollout launch
+ * since prepared episodes were switched on; -1 = off.  Waits for the stream. */
+long long ngw_debug_slow_resets(ngw_handle* h) {
+    if (!h || !h->nx.slow || h->prefetch_every <= 0) return -1;
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -2;
+    uint32_t v = 0;
+    if (hipMemcpy(&v, h->nx.slow, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    return (long long)v;
+}
 
 /* Diagnostic launches (profiling only, not part of include/ngw.h): mode 8 = empty kernel, 9 = stage in/out only. */
 int ngw_debug_launch(ngw_handle* h, int mode, int32_t n_launches) {
@@ -1340,18 +1342,6 @@ int ngw_agent_view_device_ptr(ngw_handle* h, void** out) {
     return NGW_OK;
 }
 
-int ngw_graph_elapsed(ngw_handle* h, double* elapsed_ms) {
-    if (!h || !elapsed_ms) return fail(NGW_E_INVALID_ARG, "NULL argument");
-    if (!h->graph_exec) return fail(NGW_E_INVALID_ARG, "no graph: call ngw_graph_build first");
-    if (!h->graph_timed) return fail(NGW_E_HIP, "this HIP runtime did not accept event-record nodes in the graph");
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipEventSynchronize(h->gev1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, h->gev0, h->gev1));
-    *elapsed_ms = ms;
-    return NGW_OK;
-}
-
 int ngw_timing_begin(ngw_handle* h) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     HIP_TRY(hipSetDevice(h->device));
@@ -1390,7 +1380,6 @@ int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stri
     HIP_TRY(hipStreamSynchronize(h->stream));
     drop_graph(h);
     h->since_refill = 0;                              // the captured refill cadence starts from a known phase
-    if (!h->gev0) { HIP_TRY(hipEventCreate(&h->gev0)); HIP_TRY(hipEventCreate(&h->gev1)); }
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     h->capturing = true;                              // (the cadence the handle has adapted to so far is the one captured)
     int rc = NGW_OK;
@@ -1405,31 +1394,6 @@ int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stri
     hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
     if (rc) { drop_graph(h); return rc; }
     if (e != hipSuccess) { drop_graph(h); return fail(NGW_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e)); }
-    {   // event-record nodes before the first and after the last captured launch: ngw_graph_elapsed times the replay's own
-        // kernels, without the latency of launching the graph.  (Best effort: without them ngw_graph_elapsed reports an error.)
-        h->graph_timed = false;
-        size_t n_nodes = 0, n_edges = 0, n_roots = 0;
-        if (hipGraphGetNodes(h->graph, nullptr, &n_nodes) == hipSuccess && n_nodes > 0 &&
-            hipGraphGetEdges(h->graph, nullptr, nullptr, &n_edges) == hipSuccess && hipGraphGetRootNodes(h->graph, nullptr, &n_roots) == hipSuccess && n_roots == 1) {
-            std::vector<hipGraphNode_t> nodes(n_nodes), from(n_edges ? n_edges : 1), to(n_edges ? n_edges : 1);
-            hipGraphNode_t root = nullptr;
-            bool ok = hipGraphGetNodes(h->graph, nodes.data(), &n_nodes) == hipSuccess && hipGraphGetRootNodes(h->graph, &root, &n_roots) == hipSuccess;
-            if (ok && n_edges) ok = hipGraphGetEdges(h->graph, from.data(), to.data(), &n_edges) == hipSuccess;
-            hipGraphNode_t leaf = nullptr;
-            int n_leaves = 0;
-            for (size_t i = 0; ok && i < n_nodes; i++) {
-                bool has_out = false;
-                for (size_t k = 0; k < n_edges; k++) has_out |= from[k] == nodes[i];
-                if (!has_out) { leaf = nodes[i]; n_leaves++; }
-            }
-            hipGraphNode_t e0 = nullptr, e1 = nullptr;
-            if (ok && n_leaves == 1 && hipGraphAddEventRecordNode(&e0, h->graph, nullptr, 0, h->gev0) == hipSuccess &&
-                hipGraphAddDependencies(h->graph, &e0, &root, 1) == hipSuccess &&
-                hipGraphAddEventRecordNode(&e1, h->graph, &leaf, 1, h->gev1) == hipSuccess)
-                h->graph_timed = true;
-        }
-        (void)hipGetLastError();
-    }
     e = hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0);
     if (e != hipSuccess) { drop_graph(h); return fail(NGW_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
     (void)hipGraphUpload(h->graph_exec, h->stream);   // pre-stage the graph so the first replay does not pay for it

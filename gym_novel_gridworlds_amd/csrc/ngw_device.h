@@ -186,6 +186,7 @@ struct NgwResetFast {            // kernel arguments (by value)
     uint32_t magicW;             // ceil(2^32 / (S-4))
     uint32_t magicS2;            // ceil(2^32 / S2): chunk byte offset / S2
     uint32_t magicS, magicIW22;  // ceil(2^32 / S), ceil(2^22 / (S-2)): 24-bit multiply form for operands < 1024
+    uint32_t magicIW;            // ceil(2^32 / (S-2))
     uint32_t off_ring, off_masks, off_placed, off_tmpl, off_perm;    // LDS dword offsets
     uint64_t* stamps;            // diagnostics builds (-DNGW_STAMPS), or nullptr
 };

@@ -374,12 +374,6 @@ class VecNovelGridworld:
         """Record the closing event of the timing pair without waiting for it (timing_end then only reads the pair)."""
         _cabi.check(_cabi.lib().ngw_timing_mark(self._h))
 
-    def graph_elapsed(self):
-        """Device milliseconds of the last replay, first captured launch to last (waits for it)."""
-        ms = C.c_double()
-        _cabi.check(_cabi.lib().ngw_graph_elapsed(self._h, C.byref(ms)))
-        return ms.value
-
     def agent_view(self, view_size=5, device=False, copy=False):
         """AgentMap window (reference observation_wrappers.py:104-121): int8 [N, 2*view_size+1, 2*view_size+1], the map
         around each agent with 0 outside the map; one gather launch on the current state."""

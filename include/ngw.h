@@ -294,9 +294,6 @@ int ngw_timing_mark(ngw_handle* h);
  * Semantically identical to calling ngw_step_device n_steps * reps times with those action rows. */
 int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps);
 int ngw_graph_launch(ngw_handle* h, int32_t reps);
-/* Device time of the LAST replay, first node to last node (event-record nodes captured with the launches): what the replay's
- * kernels took, without the latency of launching the graph itself.  Waits for that replay to finish. */
-int ngw_graph_elapsed(ngw_handle* h, double* elapsed_ms);
 
 /* Multi-GPU observation stack (the only collective of the path, outside step()).  One process per GPU,
  * each with its own handle; per step (or whenever the host wants the whole batch) every rank packs its observation and

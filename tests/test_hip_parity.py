@@ -705,3 +705,30 @@ def test_additem_new_episode_kernel_every_variant(cfg, n, pack, monkeypatch):
     v.rollout(30, action_seed=3, t0=0); assert o.rollout(30, 3, 0) == 0
     assert_state_equal(v, o, '%s pack=%s fused' % (cfg, pack))
     assert v.error_flags() == 0
+
+
+def test_staggered_episode_ends_are_served_by_prepared_episodes():
+    """Episode ends spread over the batch (a learning loop): every reset must find its prepared row - the device counter of
+    resets that ran the placement loop inside a step stays at zero - and the states equal the oracle's."""
+    import ctypes
+    from gym_novel_gridworlds_amd import _cabi
+    lib = _cabi.lib()
+    lib.ngw_debug_slow_resets.argtypes = [ctypes.c_void_p]
+    lib.ngw_debug_slow_resets.restype = ctypes.c_longlong
+    spec = T.build_spec('pogo10')
+    A = len(spec.actions_id)
+    n, H = 4096, 80                                              # (prepared episodes are the default from a horizon of 64)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=3, autoreset=True, horizon=H)
+    o = Oracle(spec.compile(), n, seed=3, autoreset=True, horizon=H)
+    v.reset(); o.reset()
+    sc = (np.arange(n) * 7919 % H).astype(np.int32)
+    v.set_state(0, step_count=sc); o.st.step_count[:] = sc
+    s0 = lib.ngw_debug_slow_resets(v._h)                          # (the first explicit reset found nothing prepared: n)
+    assert s0 >= 0
+    rs = np.random.RandomState(12)
+    for t in range(3 * H):
+        a = rs.randint(0, A, size=n).astype(np.int32)
+        v.step(a); o.step(a)
+    assert_state_equal(v, o, 'staggered ends')
+    assert o.st.episode.min() >= 3
+    assert 0 <= lib.ngw_debug_slow_resets(v._h) - s0 <= n // 100  # (an early `done` inside one cadence is the only way to miss)
