@@ -13,6 +13,9 @@ scaling.  Called as plain `python bench.py --gpus N` this script STARTS ITS OWN 
 rendezvous on 127.0.0.1) before it touches a GPU and relays rank 0's JSON line; launched under torchrun by someone
 else it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
 
+Timed region: barrier + torch.cuda.synchronize(), clock, K steps, torch.cuda.synchronize(), clock, barrier; `value` uses the MAX
+over ranks of that span (= until the slowest rank had finished its K steps).
+
 The JSON line carries, besides the contract's fields,
   roofline        algorithmic bytes per env-step (2*S*S + 12*K + 45) * envs per launch / the step kernel's
                   average launch duration, measured with a HIP event pair on the kernel's own stream, vs 8 TB/s HBM peak
@@ -248,10 +251,9 @@ def main():
         else:
             run_eager(steps, 0)
 
-    def fence(closing=False):
-        if not closing:
-            v.sync()
-        torch.cuda.synchronize()          # (waits for every stream of the device, the handle's included)
+    def fence():
+        v.sync()
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
@@ -274,9 +276,12 @@ def main():
     v.timing_begin()                      # HIP event pair on the kernel's own stream, around the timed launches
     t0 = time.perf_counter()
     run_timed()
-    v.timing_mark()                       # (recorded, not waited for: the closing fence below is the only wait in the region)
-    fence(closing=True)
-    dt = time.perf_counter() - t0
+    v.timing_mark()                       # (recorded, not waited for: the synchronisation below is the only wait in the region)
+    torch.cuda.synchronize()              # every stream of the device, the handle's included
+    dt = time.perf_counter() - t0         # this rank's K steps; MAX over ranks below = until the slowest rank was done
+    if world > 1:
+        dist.barrier()                    # the closing barrier of the contract - after the local clock has stopped, so that its
+        torch.cuda.synchronize()          # own latency (a collective) is not billed to the steps
     dev_ms = v.timing_end()
     assert v.error_flags() == 0
     resets_timed = episode0() - ep_before
