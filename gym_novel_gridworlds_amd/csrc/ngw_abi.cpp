@@ -352,7 +352,7 @@ int launch_reset_fast(ngw_handle* h, int mode, const uint8_t* mask_dev, bool* ta
     *taken = false;
     if (h->rf_nw < 0 || h->lidar_fused) return NGW_OK;
     NgwResetFast a = h->rf;
-    a.main = h->b; a.nx = h->nx; a.mode = mode; a.reset_mask = mask_dev; a.stamps = h->proto.stamps;
+    a.main = h->b; a.nx = h->prefetch_every > 0 ? h->nx : NgwNx{}; a.mode = mode; a.reset_mask = mask_dev; a.stamps = h->proto.stamps;
     HIP_TRY(ngw_reset_fast_launch(h->dspec, &a, h->rf_nw, h->rf_additem, (unsigned)(h->n_pad / NGW_EPB), h->rf_lds, h->stream));
     *taken = true;
     return NGW_OK;

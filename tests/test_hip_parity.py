@@ -688,7 +688,8 @@ def test_additem_new_episode_kernel_every_variant(cfg, n, pack, monkeypatch):
     monkeypatch.setenv('NGW_RESET_PACK', pack)
     spec = T.build_spec(cfg)
     A = len(spec.actions_id)
-    v = VecNovelGridworld(spec=spec, num_envs=n, seed=5, autoreset=True, horizon=12, env_index_base=3)
+    # prepared next episodes on (a refill after every reset and every 8 steps): the second explicit reset below COPIES its rows
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=5, autoreset=True, horizon=12, env_index_base=3, reset_prefetch=8)
     o = Oracle(spec.compile(), n, seed=5, autoreset=True, horizon=12, env_index_base=3)
     for ep in range(2):
         v.reset(); assert o.reset() == 0
@@ -702,6 +703,8 @@ def test_additem_new_episode_kernel_every_variant(cfg, n, pack, monkeypatch):
         _, reward, done, info = v.step(a); o.step(a)
         assert (reward == o.reward).all() and (done == o.done.astype(bool)).all(), t
     assert_state_equal(v, o, '%s pack=%s stepped' % (cfg, pack))
+    v.reset(); assert o.reset() == 0                                   # rows consumed since the last refill are stale: copy and build mixed in a wave
+    assert_state_equal(v, o, '%s pack=%s reset with some rows stale' % (cfg, pack))
     v.rollout(30, action_seed=3, t0=0); assert o.rollout(30, 3, 0) == 0
     assert_state_equal(v, o, '%s pack=%s fused' % (cfg, pack))
     assert v.error_flags() == 0
