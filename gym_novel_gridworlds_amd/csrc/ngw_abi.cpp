@@ -57,6 +57,7 @@ struct ngw_handle {
     std::vector<void*> allocs;
     std::vector<void*> host_allocs;       // state of a single-wavefront handle kept in GPU-addressable host memory (hostres)
     int hostres = 0;
+    uint32_t step_seq = 0, launch_seq = 0;   // hostres: sequence number the next step launch reports (launch_seq: only while ngw_step_host issues it)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing pair
     bool ev_marked = false;                    // ngw_timing_mark recorded the closing event already
     // LidarInFront observation
@@ -399,12 +400,14 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     a.horizon = h->horizon;
     a.action_seed = action_seed;
     a.t0 = t0;
+    a.seq = h->launch_seq;
     const unsigned grid = (unsigned)(h->n_pad / NGW_EPB);
     bool taken = false;
     if (mode == NGW_MODE_RESET) { if (int rc = launch_reset_fast(h, NGW_MODE_RESET, mask_dev, &taken)) return rc; }
     if (!taken && mode == NGW_MODE_STEP && h->lean && h->nostage && !h->lidar_fused) {   // big maps: no-stage lean kernel
         NgwLaunch q = h->ns_proto;
         q.b = h->b; q.mode = mode; q.n_steps = 1; q.actions = actions_dev; q.autoreset = h->autoreset; q.horizon = h->horizon; q.stamps = h->proto.stamps;
+        q.seq = h->launch_seq;
         HIP_TRY(ngw_launch(h->dspec, &q, h->map_mode, 4 | 8 | (h->ext ? 2 : 0), grid, h->ns_lds, h->stream));
         taken = true;
     }
@@ -528,7 +531,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     if (!rc) rc = state_alloc(h, &h->b.done, np);
     if (!rc) rc = state_alloc(h, &h->b.info, np);
     if (!rc) rc = dev_alloc(h, &h->b.flags, 1);
-    if (!rc && h->hostres) rc = state_alloc(h, &h->b.flags_host, 1);
+    if (!rc && h->hostres) rc = state_alloc(h, &h->b.flags_host, 16);          // [0] flags, [NGW_SEQ_WORD] sequence of the last finished step
     if (!rc) rc = dev_alloc(h, &h->actions_dev, np);
     if (!rc) rc = dev_alloc(h, &h->mask_dev, np);
     if (!rc && spec->n_passes) rc = dev_alloc(h, &h->b.perm, np * S2);   // HBM fallback for maps too big for the LDS shuffle
@@ -956,8 +959,24 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zc_dev), h->zc_host, 0));
         }
         memcpy(h->zc_host, actions_host, n * sizeof(int32_t));
-        if (int rc = launch(h, NGW_MODE_STEP, 1, reinterpret_cast<const int32_t*>(h->zc_dev), nullptr, 0, 0)) return rc;
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        // The kernel writes this launch's sequence number to host memory once its stores are out: polling that word costs a
+        // PCIe write's latency, a stream synchronisation several microseconds (and would also wait for a refill launch that
+        // follows the step on the stream).  Bounded: after ~20 ms without the word the stream is synchronised the usual way.
+        h->step_seq = h->step_seq + 1u ? h->step_seq + 1u : 1u;
+        h->launch_seq = h->step_seq;
+        const int lrc = launch(h, NGW_MODE_STEP, 1, reinterpret_cast<const int32_t*>(h->zc_dev), nullptr, 0, 0);
+        h->launch_seq = 0;
+        if (lrc) return lrc;
+        {
+            volatile uint32_t* sp = h->b.flags_host + NGW_SEQ_WORD;
+            bool seen = false;
+            for (uint32_t spin = 0; spin < (1u << 21); spin++) {
+                if (*sp == h->step_seq) { seen = true; break; }
+                __builtin_ia32_pause();
+            }
+            if (!seen) HIP_TRY(hipStreamSynchronize(h->stream));
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);                                // the state reads below stay behind the poll
+        }
         for (int r = 0; r < INFO; r++)
             if (outs[r].host && r != 6) memcpy(outs[r].host, outs[r].dev, outs[r].bytes);
         if (error_flags) *error_flags = *h->b.flags_host;             // sticky: ngw_error_flags reads and clears it (with the device word)

@@ -56,6 +56,7 @@ struct NgwLaunch {
     uint32_t magicS;             /* ceil(2^32 / S): cell / S */
     uint32_t off_inv, off_cand, off_act;    /* LDS dword offsets */
     uint64_t* stamps;            /* diagnostics builds (-DNGW_STAMPS): [grid][16] in-kernel clock stamps, or nullptr */
+    uint32_t seq;                /* host-resident handles: written to flags_host[NGW_SEQ_WORD] when the step's stores are out (0 = do not) */
     /* fused rollouts: per-step output rows and per-env episode accumulators (ngw_rollout_outputs), any of them nullptr */
     int32_t* row_reward;         /* [n_steps][row_stride]: reward of step t of env e at [t * row_stride + e] */
     uint8_t* row_done;           /* [n_steps][row_stride]: 1 where the step ended an episode (done, or the horizon under autoreset) */
@@ -102,6 +103,7 @@ enum { NGW_CB_FALSE = 0, NGW_CB_FRONT_NZ = 1, NGW_CB_JUMP_BLOCKED = 2, NGW_CB_NO
 /* Prepared next episodes (ngw_set_reset_prefetch): shadow buffers holding, for env e, the first state of episode
  * nx.episode[e]; a reset whose new episode number matches copies it instead of running the placement loop.  All null
  * when the feature is off.  Read only on the cold reset path, with scalar loads from the HBM blob. */
+#define NGW_SEQ_WORD 8           /* flags_host[8]: sequence number of the last finished step launch (the host polls it instead of a stream sync) */
 struct NgwNx {
     int8_t* map;          /* [n_pad][S*S] */
     int32_t* loc;         /* [n_pad][2]   */

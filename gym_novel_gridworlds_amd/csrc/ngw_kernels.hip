@@ -166,6 +166,16 @@ __device__ __forceinline__ void raise_host_flags(uint32_t* flags_host, uint32_t 
     }
 }
 
+// One-wavefront handles with host-resident state: when every store of the step is out, lane 0 writes the launch's sequence
+// number next to the flags word; the host polls that word instead of paying a stream synchronisation (ngw_step_host).
+__device__ __forceinline__ void signal_host_seq(uint32_t* flags_host, uint32_t seq) {
+    if (flags_host && seq) {                                                       // (uniform)
+        __builtin_amdgcn_s_waitcnt(0);                                             // the wave's stores have been accepted ...
+        __threadfence_system();                                                    // ... and are ordered before the word below
+        if (threadIdx.x == 0) *(volatile uint32_t*)(flags_host + NGW_SEQ_WORD) = seq;
+    }
+}
+
 // ---------------------------------------------------------------- per-lane reset on the LDS map
 // pogostick_v1_env.py:86-157 + add_item_to_map :159-181 (+ AddItem.reset, AxeEasy.reset).  `mp` = this lane's map
 // in LDS, `inv` = this lane's inventory row, `cand` = candidate bitmask column (stride EPB).
@@ -1062,6 +1072,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     }
     if (flags) atomicOr(a.b.flags, flags);
     raise_host_flags(a.b.flags_host, flags);
+    if (MODE == NGW_MODE_STEP) signal_host_seq(a.b.flags_host, a.seq);
 #ifdef NGW_STAMPS
     STAMP(5);
     __builtin_amdgcn_s_waitcnt(0);                                                 // every store acknowledged

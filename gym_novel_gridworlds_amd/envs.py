@@ -80,6 +80,8 @@ class _NovelGridworldEnv(_EnvBase):
         self.reward_done = sp.reward_done
         self.last_done = False
         self._known, self._dev_state_of = None, None         # what the device is known to hold (envs.py _push)
+        self._m8 = self._i32 = self._inv_known = None        # raw bytes of the device's map / inventory row at the last pull
+        self._rev_actions = self._rev_items = None           # (table identity, size, {id: name}) of actions_id / items_id
 
     # ------------------------------------------------------------------ backend
     def _make_backend(self, spec, seed):
@@ -161,8 +163,8 @@ class _NovelGridworldEnv(_EnvBase):
         sel = self.selected_item
         k = self._known
         if (self._dev_state_of is vec and k is not None and k[0] == self.agent_location and k[1] == self.agent_facing_id and k[2] == sel
-                and k[3] == self.step_count and k[4] == self.inventory_items_quantity and self.map.shape == k[5].shape
-                and (self.map == k[5]).all()):
+                and k[3] == self.step_count and k[4] == self.inventory_items_quantity and self.map.shape == k[6]
+                and self.map.tobytes() == k[5]):
             return
         ids, S, K = self.items_id, self.map_size, len(self.items_id)
         inv = np.zeros((1, K), np.int32)
@@ -175,7 +177,8 @@ class _NovelGridworldEnv(_EnvBase):
 
     def _remember(self, vec):
         self._known = (tuple(self.agent_location), self.agent_facing_id, self.selected_item, self.step_count,
-                       dict(self.inventory_items_quantity), np.array(self.map, np.int8))
+                       dict(self.inventory_items_quantity), self.map.tobytes(), self.map.shape)
+        self._m8 = self._i32 = None                          # the next pull rebuilds its caches
         self._dev_state_of = vec
 
     def _pull(self, vec, st=None):
@@ -183,21 +186,30 @@ class _NovelGridworldEnv(_EnvBase):
         if st is None:
             st = vec.get_state(0, 1)
         S = self.map_size
-        if self.map.shape != (S, S):
-            self.map = np.zeros((S, S), dtype=int)
-        m8 = np.array(st['map'][0], np.int8).reshape(S, S)
-        self.map[...] = m8
+        # most steps change neither the map nor the inventory: compare the raw rows with the last pull's before rebuilding anything
+        mb = st['map'][0].tobytes()
+        if mb != self._m8 or self.map.shape != (S, S) or self._known is None or self._dev_state_of is not vec:
+            if self.map.shape != (S, S):
+                self.map = np.zeros((S, S), dtype=int)
+            self.map[...] = np.frombuffer(mb, np.int8).reshape(S, S)
+            self._m8 = mb
+            m64 = self.map.tobytes()
+        else:
+            m64 = self._known[5]
         loc = st['loc'][0]
         self.agent_location = (int(loc[0]), int(loc[1]))
         self.set_agent_facing(DIRECTION_STR[int(st['facing'][0])])
         names = self._spec.item_names
         inv = self.inventory_items_quantity
-        for name, q in zip(names, st['inv'][0].tolist()):
-            inv[name] = q
+        ib = st['inv'][0].tobytes()
+        if ib != self._i32 or self._inv_known != inv:
+            for name, q in zip(names, st['inv'][0].tolist()):
+                inv[name] = q
+            self._i32, self._inv_known = ib, dict(inv)
         sel = int(st['selected'][0])
         self.selected_item = names[sel] if sel else ''
         self.step_count = int(st['step_count'][0])
-        self._known = (self.agent_location, self.agent_facing_id, self.selected_item, self.step_count, dict(inv), m8)
+        self._known = (self.agent_location, self.agent_facing_id, self.selected_item, self.step_count, self._inv_known, m64, self.map.shape)
         self._dev_state_of = vec
 
     # ------------------------------------------------------------------ reference API
@@ -245,7 +257,14 @@ class _NovelGridworldEnv(_EnvBase):
 
     def step(self, action_id):
         # ValueError("<id> is not in list") for an unknown action id, before anything changes (:236)
-        self.last_action = list(self.actions_id.keys())[list(self.actions_id.values()).index(action_id)]
+        rev = self._rev_actions
+        if rev is None or rev[0] is not self.actions_id or rev[1] != len(self.actions_id):
+            rev = self._rev_actions = (self.actions_id, len(self.actions_id), {v: k for k, v in reversed(list(self.actions_id.items()))})
+        name = rev[2].get(action_id)
+        if name is None or self.actions_id.get(name) != action_id:      # (table edited in place, or an unknown id: the reference's own lookup)
+            self._rev_actions = None
+            name = list(self.actions_id.keys())[list(self.actions_id.values()).index(action_id)]
+        self.last_action = name
         vec = self._backend()
         self._push(vec)
         step1 = getattr(vec, 'step1', None)
@@ -297,7 +316,14 @@ class _NovelGridworldEnv(_EnvBase):
         if self.block_in_front_id == 0:
             self.block_in_front_str = 'air'
         else:
-            self.block_in_front_str = list(self.items_id.keys())[list(self.items_id.values()).index(self.block_in_front_id)]
+            rev = self._rev_items
+            if rev is None or rev[0] is not self.items_id or rev[1] != len(self.items_id):
+                rev = self._rev_items = (self.items_id, len(self.items_id), {v: k for k, v in reversed(list(self.items_id.items()))})
+            name = rev[2].get(self.block_in_front_id)
+            if name is None or self.items_id.get(name) != self.block_in_front_id:
+                self._rev_items = None
+                name = list(self.items_id.keys())[list(self.items_id.values()).index(self.block_in_front_id)]
+            self.block_in_front_str = name
 
     def is_block_in_front_next_to(self, item):               # :391-411
         self.update_block_in_front()

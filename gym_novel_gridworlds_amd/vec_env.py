@@ -171,9 +171,12 @@ class VecNovelGridworld:
     def last_state(self):
         """State after the last step() as get_state() would return it, from the host buffers that call filled (no device
         traffic; `episode` is not part of it)."""
-        o = self._obs
-        return dict(map=o['map'].reshape(self.num_envs, -1), loc=o['agent_location'], facing=o['agent_facing_id'],
-                    inv=o['inventory_items_quantity'], selected=self._sel_host.astype(np.int32), step_count=self._steps_host)
+        st = self.__dict__.get('_last_state_views')
+        if st is None:                                        # views of the host buffers every step fills: built once
+            o = self._obs
+            st = self._last_state_views = dict(map=o['map'].reshape(self.num_envs, -1), loc=o['agent_location'], facing=o['agent_facing_id'],
+                                               inv=o['inventory_items_quantity'], selected=self._sel_host, step_count=self._steps_host)
+        return st
 
     def get_observation(self, copy=False):
         o = self._obs
