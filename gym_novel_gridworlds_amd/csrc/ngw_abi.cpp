@@ -56,6 +56,9 @@ struct ngw_handle {
     uint8_t* step_stage = nullptr;        // ngw_step_host, one-block layout: every output packed on the device, ONE copy out
     std::vector<void*> allocs;
     std::vector<void*> host_allocs;       // state of a single-wavefront handle kept in GPU-addressable host memory (hostres)
+    uint8_t* mask_pin = nullptr; uint8_t* mask_pin_dev = nullptr;   // ngw_reset's mask: two page-locked halves the kernel reads in place
+    hipEvent_t mask_ev[2] = {nullptr, nullptr};
+    int mask_next = 0;
     int hostres = 0;
     uint32_t step_seq = 0, launch_seq = 0;   // hostres: sequence number the next step launch reports (launch_seq: only while ngw_step_host issues it)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing pair
@@ -677,6 +680,9 @@ int ngw_destroy(ngw_handle* h) {
     drop_graph(h);
     if (h->info_host) (void)hipHostFree(h->info_host);
     if (h->zc_host) (void)hipHostFree(h->zc_host);
+    if (h->mask_ev[0]) (void)hipEventDestroy(h->mask_ev[0]);
+    if (h->mask_ev[1]) (void)hipEventDestroy(h->mask_ev[1]);
+    if (h->mask_pin) ngw_host_free(h->mask_pin);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -752,12 +758,28 @@ int ngw_reset(ngw_handle* h, const uint8_t* mask_host) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     HIP_TRY(hipSetDevice(h->device));
     const uint8_t* m = nullptr;
+    int slot = -1;
     if (mask_host) {
-        HIP_TRY(hipMemcpyAsync(h->mask_dev, mask_host, (size_t)h->n, hipMemcpyDefault, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));   // mask_host may be pageable and reused by the caller
-        m = h->mask_dev;
+        // The caller's mask may be pageable and is his again when this call returns: it is copied (host to host) into one half
+        // of a page-locked, GPU-addressable buffer that the reset kernel reads across PCIe (n bytes) - no copy call and no stream
+        // synchronisation (which would also wait for a refill still running).  A half is reused only after the launch that
+        // read it last has finished (an event per half; two halves, so this practically never waits).
+        const size_t cap = ((size_t)h->n + 255) & ~(size_t)255;
+        if (!h->mask_pin) {
+            h->mask_pin = static_cast<uint8_t*>(ngw_host_alloc(2 * cap));
+            if (!h->mask_pin) return NGW_E_HIP;
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->mask_pin_dev), h->mask_pin, 0));
+            HIP_TRY(hipEventCreateWithFlags(&h->mask_ev[0], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&h->mask_ev[1], hipEventDisableTiming));
+        }
+        slot = h->mask_next; h->mask_next ^= 1;
+        HIP_TRY(hipEventSynchronize(h->mask_ev[slot]));
+        memcpy(h->mask_pin + (size_t)slot * cap, mask_host, (size_t)h->n);
+        m = h->mask_pin_dev + (size_t)slot * cap;
     }
-    return launch(h, NGW_MODE_RESET, 1, nullptr, m, 0, 0);
+    const int rc = launch(h, NGW_MODE_RESET, 1, nullptr, m, 0, 0);
+    if (slot >= 0 && !rc) HIP_TRY(hipEventRecord(h->mask_ev[slot], h->stream));
+    return rc;
 }
 
 int ngw_step(ngw_handle* h, const int32_t* actions_host) {
