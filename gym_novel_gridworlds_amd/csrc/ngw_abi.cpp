@@ -59,6 +59,9 @@ struct ngw_handle {
     uint8_t* mask_pin = nullptr; uint8_t* mask_pin_dev = nullptr;   // ngw_reset's mask: two page-locked halves the kernel reads in place
     hipEvent_t mask_ev[2] = {nullptr, nullptr};
     int mask_next = 0;
+    uint8_t* act_pin = nullptr;                // ngw_step's actions: two page-locked halves feeding the asynchronous copy
+    hipEvent_t act_ev[2] = {nullptr, nullptr};
+    int act_next = 0;
     int hostres = 0;
     uint32_t step_seq = 0, launch_seq = 0;   // hostres: sequence number the next step launch reports (launch_seq: only while ngw_step_host issues it)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing pair
@@ -683,6 +686,9 @@ int ngw_destroy(ngw_handle* h) {
     if (h->mask_ev[0]) (void)hipEventDestroy(h->mask_ev[0]);
     if (h->mask_ev[1]) (void)hipEventDestroy(h->mask_ev[1]);
     if (h->mask_pin) ngw_host_free(h->mask_pin);
+    if (h->act_ev[0]) (void)hipEventDestroy(h->act_ev[0]);
+    if (h->act_ev[1]) (void)hipEventDestroy(h->act_ev[1]);
+    if (h->act_pin) ngw_host_free(h->act_pin);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -789,8 +795,21 @@ int ngw_step(ngw_handle* h, const int32_t* actions_host) {
         if (actions_host[i] < 0 || actions_host[i] >= A)
             return fail(NGW_E_INVALID_ACTION, "%d is not in list", (int)actions_host[i]);   // pogostick_v1_env.py:236
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpyAsync(h->actions_dev, actions_host, (size_t)h->n * sizeof(int32_t), hipMemcpyDefault, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    // The caller's array may be pageable and is his again when this call returns: it goes (host to host) into one half of a
+    // page-locked buffer and from there to the device by an asynchronous copy - no stream synchronisation (which would also wait
+    // for a refill still running).  A half is rewritten only after the copy that read it last has finished (an event per half).
+    const size_t bytes = (size_t)h->n * sizeof(int32_t), cap = (bytes + 255) & ~(size_t)255;
+    if (!h->act_pin) {
+        h->act_pin = static_cast<uint8_t*>(ngw_host_alloc(2 * cap));
+        if (!h->act_pin) return NGW_E_HIP;
+        HIP_TRY(hipEventCreateWithFlags(&h->act_ev[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->act_ev[1], hipEventDisableTiming));
+    }
+    const int slot = h->act_next; h->act_next ^= 1;
+    HIP_TRY(hipEventSynchronize(h->act_ev[slot]));
+    memcpy(h->act_pin + (size_t)slot * cap, actions_host, bytes);
+    HIP_TRY(hipMemcpyAsync(h->actions_dev, h->act_pin + (size_t)slot * cap, bytes, hipMemcpyDefault, h->stream));
+    HIP_TRY(hipEventRecord(h->act_ev[slot], h->stream));
     return launch(h, NGW_MODE_STEP, 1, h->actions_dev, nullptr, 0, 0);
 }
 
