@@ -1320,18 +1320,20 @@ extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, in
     // Everything but the fused LidarInFront epilogue steps through the lean kernels; the wrapper predicates (feat & 2) are a
     // template flag of the same body.
 #define NGW_LEAN_EXT(CALL_F, CALL_T) ((feat & 2) ? CALL_T : CALL_F)
-    if ((feat & 4) && a->mode == NGW_MODE_STEP && !(feat & 1)) {    // one step
+    if ((feat & 4) && a->mode == NGW_MODE_STEP && (!(feat & 1) || !(feat & 8))) {   // one step (the lidar epilogue needs the staged form)
         if (feat & 8)                                               // no-stage (big maps)
-            return NGW_LEAN_EXT((launch_lean<NGW_MAP_STRAIGHT, false, false>(dspec, a, grid, lds_bytes, stream)),
-                                (launch_lean<NGW_MAP_STRAIGHT, false, true>(dspec, a, grid, lds_bytes, stream)));
+            return NGW_LEAN_EXT((launch_lean<NGW_MAP_STRAIGHT, false, false, false>(dspec, a, grid, lds_bytes, stream)),
+                                (launch_lean<NGW_MAP_STRAIGHT, false, true, false>(dspec, a, grid, lds_bytes, stream)));
+#define NGW_LEAN_STEP(MM) ((feat & 1) ? NGW_LEAN_EXT((launch_lean<MM, true, false, true>(dspec, a, grid, lds_bytes, stream)),   \
+                                                     (launch_lean<MM, true, true, true>(dspec, a, grid, lds_bytes, stream)))    \
+                                      : NGW_LEAN_EXT((launch_lean<MM, true, false, false>(dspec, a, grid, lds_bytes, stream)),  \
+                                                     (launch_lean<MM, true, true, false>(dspec, a, grid, lds_bytes, stream))))
         switch (map_mode) {
-        case NGW_MAP_STRAIGHT: return NGW_LEAN_EXT((launch_lean<NGW_MAP_STRAIGHT, true, false>(dspec, a, grid, lds_bytes, stream)),
-                                                   (launch_lean<NGW_MAP_STRAIGHT, true, true>(dspec, a, grid, lds_bytes, stream)));
-        case NGW_MAP_DWORD: return NGW_LEAN_EXT((launch_lean<NGW_MAP_DWORD, true, false>(dspec, a, grid, lds_bytes, stream)),
-                                                (launch_lean<NGW_MAP_DWORD, true, true>(dspec, a, grid, lds_bytes, stream)));
-        default: return NGW_LEAN_EXT((launch_lean<NGW_MAP_BYTE, true, false>(dspec, a, grid, lds_bytes, stream)),
-                                     (launch_lean<NGW_MAP_BYTE, true, true>(dspec, a, grid, lds_bytes, stream)));
+        case NGW_MAP_STRAIGHT: return NGW_LEAN_STEP(NGW_MAP_STRAIGHT);
+        case NGW_MAP_DWORD: return NGW_LEAN_STEP(NGW_MAP_DWORD);
+        default: return NGW_LEAN_STEP(NGW_MAP_BYTE);
         }
+#undef NGW_LEAN_STEP
     }
     if ((feat & 4) && !(feat & 1) && (a->mode == NGW_MODE_ROLLOUT || a->mode == NGW_MODE_ROLLOUT_ACT)) {   // fused rollout
         const bool sup = a->mode == NGW_MODE_ROLLOUT_ACT;
