@@ -1,0 +1,131 @@
+"""Randomised call sequences over every test configuration, HIP path (through the C-ABI) against the CPU oracle.
+
+Each case draws a configuration, a batch size, a horizon, a prepared-episode setting and a sequence of calls - host steps,
+device steps, fused rollouts (generated and supplied actions), masked and full resets, state injection - and compares the
+whole state with the oracle's after every call.  The default budget is a few seconds per chunk of configurations;
+NGW_FUZZ_SECONDS=<s> runs longer (tools-style soak on the GPU box).  Needs an MI355X."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import ngw_testlib as T
+from gym_novel_gridworlds_amd import VecNovelGridworld
+from oracle.ngw_oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+STATE_KEYS = ('map', 'loc', 'facing', 'inv', 'selected', 'step_count', 'episode')
+CFGS = sorted(T.CFGS)
+BUDGET = float(os.environ.get('NGW_FUZZ_SECONDS', '0'))
+
+
+def check(v, o, where):
+    hs = v.get_state()
+    st = o.st
+    os_ = dict(map=st.map, loc=st.loc, facing=st.facing, inv=st.inv, selected=st.selected, step_count=st.step_count, episode=st.episode)
+    for k in STATE_KEYS:
+        bad = np.nonzero((hs[k] != os_[k]).reshape(len(hs[k]), -1).any(1))[0]
+        assert bad.size == 0, "%s: %s differs for %d envs, first env %d" % (where, k, bad.size, bad[0])
+
+
+def both_reset(v, o, mask, tag):
+    """reset() on both sides; a placement that cannot succeed ("Cannot place items, increase map size!", pogostick_v1_env.py:167)
+    must fail on both - the case ends there."""
+    try:
+        v.reset(mask)
+    except AssertionError:
+        assert (o.reset(mask) if mask is not None else o.reset()) != 0, tag + ': only the HIP path failed to place'
+        return False
+    assert (o.reset(mask) if mask is not None else o.reset()) == 0, tag + ': only the oracle failed to place'
+    return True
+
+
+def one_case(rs, cfg, case):
+    import torch
+    spec = T.build_spec(cfg)
+    A = len(spec.actions_id)
+    S = spec.map_size
+    n = int(rs.choice([1, 37, 64, 65, 200, 513, 1500])) if S <= 16 else int(rs.choice([1, 64, 130, 300]))
+    horizon = int(rs.choice([0, 7, 23, 64, 90]))
+    autoreset = bool(rs.randint(0, 4)) or horizon > 0
+    prefetch = rs.choice(['auto', 0, 3, 16])
+    prefetch = prefetch if prefetch == 'auto' else int(prefetch)
+    seed, base = int(rs.randint(0, 2 ** 31)), int(rs.randint(0, 10 ** 6))
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=seed, autoreset=autoreset, horizon=horizon, reset_prefetch=prefetch, env_index_base=base)
+    o = Oracle(spec.compile(), n, seed=seed, autoreset=autoreset, horizon=horizon, env_index_base=base)
+    tag = '%s case %d (n=%d H=%d auto=%d prefetch=%s)' % (cfg, case, n, horizon, autoreset, prefetch)
+    if not both_reset(v, o, None, tag):
+        v.close()
+        return
+    check(v, o, tag + ' reset')
+    t_roll = 0
+    ofail = [0]                                            # the oracle's own "cannot place" reports (same-step autoreset inside step / rollout)
+
+    def ostep(a):
+        ofail[0] |= int(o.step(a) != 0)
+
+    try:
+        for call in range(int(rs.randint(4, 10))):
+            kind = rs.choice(['step', 'step', 'dev', 'rollout', 'rollact', 'mask', 'reset', 'state'])
+            if not autoreset and kind in ('rollout', 'rollact') and rs.randint(0, 2):
+                kind = 'step'
+            if kind == 'step':
+                for _ in range(int(rs.randint(1, 12))):
+                    a = rs.randint(0, A, size=n).astype(np.int32)
+                    ostep(a)
+                    _, reward, done, info = v.step(a)
+                    assert (reward == o.reward).all() and (done == o.done.astype(bool)).all() and (info['message_code'] == o.msg_code).all(), tag
+            elif kind == 'dev':
+                k = int(rs.randint(1, 9))
+                an = rs.randint(0, A, size=(k, n)).astype(np.int32)
+                acts = torch.from_numpy(an).cuda()
+                torch.cuda.synchronize()
+                for i in range(k):
+                    ostep(an[i])
+                v.step_device_many(acts.data_ptr(), n, k)
+            elif kind == 'rollout':
+                k = int(rs.randint(1, 70))
+                ofail[0] |= int(o.rollout(k, seed ^ 77, t_roll) != 0)
+                v.rollout(k, action_seed=seed ^ 77, t0=t_roll)
+                t_roll += k
+            elif kind == 'rollact':
+                k = int(rs.randint(1, 40))
+                an = rs.randint(0, A, size=(k, n)).astype(np.int32)
+                acts = torch.from_numpy(an).cuda()
+                torch.cuda.synchronize()
+                for i in range(k):
+                    ostep(an[i])
+                v.rollout_actions(acts.data_ptr(), n, k)
+            elif kind in ('mask', 'reset'):
+                m = (rs.randint(0, 3, size=n) == 0).astype(np.uint8) if kind == 'mask' else None
+                if not both_reset(v, o, m, tag):
+                    break
+            else:                                          # inject step counts (and with them where the horizons fall)
+                sc = rs.randint(0, max(horizon, 5), size=n).astype(np.int32)
+                v.set_state(0, step_count=sc); o.st.step_count[:] = sc
+            if ofail[0]:                                   # an in-step reset could not place its items: the HIP path must say so too
+                with pytest.raises(AssertionError, match='Cannot place items'):
+                    v.get_state(); v._raise_flags()
+                break
+            check(v, o, '%s call %d %s' % (tag, call, kind))
+        else:
+            assert v.error_flags() == 0, tag
+    except AssertionError as ex:
+        if 'Cannot place items' not in str(ex) or not ofail[0]:
+            raise
+    v.close()
+
+
+@pytest.mark.parametrize('chunk', range(6))
+def test_random_call_sequences_match_oracle(chunk):
+    rs = np.random.RandomState(1000 + chunk)
+    mine = CFGS[chunk::6]
+    t_end = time.time() + (BUDGET / 6 if BUDGET > 0 else 0)
+    case = 0
+    while True:
+        for cfg in mine:
+            one_case(rs, cfg, case)
+            case += 1
+        if time.time() >= t_end:
+            break
