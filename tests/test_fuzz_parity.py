@@ -20,7 +20,14 @@ CFGS = sorted(T.CFGS)
 BUDGET = float(os.environ.get('NGW_FUZZ_SECONDS', '0'))
 
 
-def check(v, o, where):
+def check(v, o, where, lid=None):
+    if lid is not None:                                    # fused LidarInFront epilogue: the observation every launch left behind
+        from oracle.ngw_oracle import lidar
+        cc, S, K = lid
+        got = v.lidar_observation()
+        exp = lidar(cc, S, K, o.st.map, o.st.loc, o.st.facing, o.st.inv)
+        bad = np.nonzero((got != exp).any(1))[0]
+        assert bad.size == 0, "%s: lidar rows differ for %d envs, first env %d" % (where, bad.size, bad[0])
     hs = v.get_state()
     st = o.st
     os_ = dict(map=st.map, loc=st.loc, facing=st.facing, inv=st.inv, selected=st.selected, step_count=st.step_count, episode=st.episode)
@@ -54,11 +61,17 @@ def one_case(rs, cfg, case):
     seed, base = int(rs.randint(0, 2 ** 31)), int(rs.randint(0, 10 ** 6))
     v = VecNovelGridworld(spec=spec, num_envs=n, seed=seed, autoreset=autoreset, horizon=horizon, reset_prefetch=prefetch, env_index_base=base)
     o = Oracle(spec.compile(), n, seed=seed, autoreset=autoreset, horizon=horizon, env_index_base=base)
-    tag = '%s case %d (n=%d H=%d auto=%d prefetch=%s)' % (cfg, case, n, horizon, autoreset, prefetch)
+    lid = None
+    if rs.randint(0, 3) == 0:                               # one case in three runs with the fused lidar epilogue
+        from gym_novel_gridworlds_amd.lidar import LidarConfig
+        lc = LidarConfig(spec, int(rs.choice([4, 8])))
+        v.lidar_configure(lc, fused=True)
+        lid = (lc.compile(spec), S, len(spec.items_id))
+    tag = '%s case %d (n=%d H=%d auto=%d prefetch=%s lidar=%d)' % (cfg, case, n, horizon, autoreset, prefetch, lid is not None)
     if not both_reset(v, o, None, tag):
         v.close()
         return
-    check(v, o, tag + ' reset')
+    check(v, o, tag + ' reset', lid)
     t_roll = 0
     ofail = [0]                                            # the oracle's own "cannot place" reports (same-step autoreset inside step / rollout)
 
@@ -108,7 +121,7 @@ def one_case(rs, cfg, case):
                 with pytest.raises(AssertionError, match='Cannot place items'):
                     v.get_state(); v._raise_flags()
                 break
-            check(v, o, '%s call %d %s' % (tag, call, kind))
+            check(v, o, '%s call %d %s' % (tag, call, kind), None if kind == 'state' else lid)
         else:
             assert v.error_flags() == 0, tag
     except AssertionError as ex:
