@@ -80,7 +80,7 @@ struct ngw_handle {
     // between refills - FireWall kills within a few steps) are counted on the device; the refill launch copies the count to a
     // host word and the host halves the cadence while it keeps growing, and doubles it back after four quiet refills.
     int cadence = 0, quiet = 0, noisy = 0, adapt = 1;
-    uint32_t slow_seen = 0;
+    uint32_t slow_seen = 0, refill_seen = 0, refill_count = 0;   // reports read / refill launches issued
     bool capturing = false;
     int prefetch_user = 0;                // the caller chose the cadence (ngw_set_reset_prefetch): ngw_set_autoreset leaves it alone
     int32_t* row_reward = nullptr;        // fused rollouts: the caller's output rows (ngw_rollout_outputs)
@@ -302,7 +302,10 @@ int upload_reset_u(ngw_handle* h) {
 void layout_reset_fast(ngw_handle* h) {
     const ngw_spec& s = h->spec;
     h->rf_nw = -1;
-    const bool additem_only = s.n_passes == 1 && s.pass_kind[0] == NGW_PASS_ADDITEM;
+    // one shuffled-subset pass whose source cells need no map scan: AddItem / Crate (air: the interior minus the placed items) or
+    // ReplaceItem / FireWall of the WALL item (the ring)
+    const bool wall_pass = s.n_passes == 1 && s.pass_kind[0] == NGW_PASS_REPLACE && s.pass_from[0] == s.wall_item;
+    const bool additem_only = (s.n_passes == 1 && s.pass_kind[0] == NGW_PASS_ADDITEM) || wall_pass;
     if (!h->fast_reset || s.tap_item || (s.n_passes && !additem_only)) return;    // other reset passes: general kernel
     const int S = s.map_size, S2 = S * S, CW = h->proto.CW;
     // measured (tools/reset_time.py, all 65 536 envs): 10 x 10 plain 26.8 us vs 23.6 us in the general kernel, 20 x 20 24.9 vs 37.4,
@@ -341,6 +344,7 @@ void layout_reset_fast(ngw_handle* h) {
     a.n = h->n; a.env_base = h->env_base; a.seed = h->seed; a.flags = h->b.flags;
     a.S = S; a.S2 = S2; a.K = s.n_items; a.CW = CW; a.n_place = n_place; a.wall_item = s.wall_item;
     a.additem_item = additem_only ? s.pass_item[0] : 0; a.additem_span = additem_only ? s.pass_pct_hi[0] - s.pass_pct_lo[0] : 1;
+    a.pass_wall = wall_pass ? 1 : 0;
     a.n_inv_start = s.n_inv_start;
     for (int j = 0; j < NGW_MAX_INV_START; j++) {
         a.inv_start_items |= (uint32_t)s.inv_start_item[j] << (8 * j);
@@ -360,6 +364,7 @@ int launch_reset_fast(ngw_handle* h, int mode, const uint8_t* mask_dev, bool* ta
     if (h->rf_nw < 0 || h->lidar_fused) return NGW_OK;
     NgwResetFast a = h->rf;
     a.main = h->b; a.nx = h->prefetch_every > 0 ? h->nx : NgwNx{}; a.mode = mode; a.reset_mask = mask_dev; a.stamps = h->proto.stamps;
+    a.refill_seq = h->refill_count;
     HIP_TRY(ngw_reset_fast_launch(h->dspec, &a, h->rf_nw, h->rf_additem, (unsigned)(h->n_pad / NGW_EPB), h->rf_lds, h->stream));
     *taken = true;
     return NGW_OK;
@@ -368,19 +373,33 @@ int launch_reset_fast(ngw_handle* h, int mode, const uint8_t* mask_dev, bool* ta
 // Prepared next episodes: one launch re-prepares the shadow rows that resets have consumed since the last one.
 void adapt_cadence(ngw_handle* h) {
     if (h->capturing || h->prefetch_user || !h->adapt || !h->nx.slow_host) return;
-    const uint32_t cur = *(volatile uint32_t*)h->nx.slow_host;          // as of the last refill launch the GPU has run
+    // what the last refill launch THE GPU HAS RUN reported: its number and the count of stale-row resets so far.  The host may be
+    // many launches ahead of the device (an eager loop without synchronisation): no new report = no information, and one
+    // report may stand for several refills.
+    const uint32_t seq = ((volatile uint32_t*)h->nx.slow_host)[1], cur = ((volatile uint32_t*)h->nx.slow_host)[0];
+    const uint32_t refills = seq - h->refill_seen;
+    if (!refills) return;
+    h->refill_seen = seq;
     const uint32_t delta = cur - h->slow_seen;
     h->slow_seen = cur;
     const uint32_t many = h->n >= 512 ? (uint32_t)(h->n / 256) : 2u;
-    if (delta >= many) {                                            // two noisy refills in a row: a one-off burst (stale tags after
+    if (delta / refills >= many) {                                  // two noisy refills in a row: a one-off burst (stale tags after
         h->quiet = 0;                                               // ngw_set_state, the first steps of a handle) does not count
-        if (++h->noisy >= 2) { h->cadence = h->cadence / 2 < 2 ? 2 : h->cadence / 2; h->noisy = 0; }
-    } else if ((h->noisy = 0, h->cadence < h->prefetch_every) && ++h->quiet >= 4) { h->cadence = h->cadence * 2 > h->prefetch_every ? h->prefetch_every : h->cadence * 2; h->quiet = 0; }
+        h->noisy += (int)refills;
+        if (h->noisy >= 2) { h->cadence = h->cadence / 2 < 2 ? 2 : h->cadence / 2; h->noisy = 0; }
+    } else {
+        h->noisy = 0;
+        if (h->cadence < h->prefetch_every && (h->quiet += (int)refills) >= 4) {
+            h->cadence = h->cadence * 2 > h->prefetch_every ? h->prefetch_every : h->cadence * 2;
+            h->quiet = 0;
+        }
+    }
 }
 
 int launch_refill(ngw_handle* h) {
     h->since_refill = 0;
     adapt_cadence(h);
+    h->refill_count++;
     bool taken = false;
     if (int rc = launch_reset_fast(h, NGW_MODE_REFILL, nullptr, &taken)) return rc;
     if (taken) return NGW_OK;
@@ -390,7 +409,7 @@ int launch_refill(ngw_handle* h) {
     rf.b.flags = h->b.flags; rf.b.perm = h->b.perm;
     rf.mode = NGW_MODE_REFILL; rf.n_steps = 1;
     rf.actions = reinterpret_cast<const int32_t*>(h->b.episode);
-    rf.reset_mask = nullptr; rf.autoreset = 0; rf.horizon = 0; rf.action_seed = 0; rf.t0 = 0;
+    rf.reset_mask = nullptr; rf.autoreset = 0; rf.horizon = 0; rf.action_seed = 0; rf.t0 = (int64_t)h->refill_count;   // (REFILL: t0 = the refill's number)
     HIP_TRY(ngw_launch(h->dspec, &rf, h->map_mode, 0, (unsigned)(h->n_pad / NGW_EPB), h->lds_bytes, h->stream));
     return NGW_OK;
 }

@@ -183,6 +183,8 @@ struct NgwResetFast {            // kernel arguments (by value)
     int32_t mode;                // NGW_MODE_RESET / NGW_MODE_REFILL
     int32_t S, S2, K, CW, n_place, wall_item;
     int32_t additem_item, additem_span;
+    uint32_t refill_seq;         // REFILL: number of this refill launch (reported to the host with the stale-row count)
+    int32_t pass_wall;           // the subset pass replaces WALL cells (ReplaceItem / FireWall of the ring) instead of filling air cells
     int32_t n_inv_start;
     uint32_t inv_start_items, inv_start_qtys;   // 4 bytes each
     uint32_t magicW;             // ceil(2^32 / (S-4))

@@ -786,7 +786,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     if (rolling && a.acc && live) { acc_ret = a.acc[e]; acc_len = a.acc[a.n_pad + e]; acc_sum = a.acc[2 * a.n_pad + e]; acc_eps = a.acc[3 * a.n_pad + e]; }
     if (MODE == NGW_MODE_REFILL && blockIdx.x == 0 && tid == 0) {                  // what the host reads (without a sync) before the next refill
         uint32_t* const sh = dspec->nx.slow_host;
-        if (sh) *sh = *dspec->nx.slow;
+        if (sh) { sh[0] = *dspec->nx.slow; sh[1] = (uint32_t)a.t0; }             // (REFILL: t0 = the refill's number)
     }
     STAMP(3);
     for (int t = 0; t < n_steps; t++, tt++) {
