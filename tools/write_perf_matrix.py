@@ -49,6 +49,8 @@ for f, title in [('reset_time.log', 'Reset launches (`tools/reset_time.py`, HIP 
                  ('short_run.log', 'A 20-step region fence to fence, eager vs one graph replay (`tools/short_run.py`)'),
                  ('stamps_reset.log', 'In-kernel timeline of the new-episode kernel at C5 (`tools/stamp_reset.py`, stamps build)'),
                  ('stamps_reset_u16.log', 'The same with the u16 shuffle array (`NGW_RESET_PACK=0`)'),
+                 ('churn_X1.log', 'FireWall hard, eager loop: cadence the handle adapts to, resets that miss their prepared episode (`tools/churn_probe.py X1`)'),
+                 ('lidar.log', 'LidarInFront observation (`tools/lidar_rate.py`, C2, 8 beams)'),
                  ('adapter.log', 'Single-env adapter (`tools/adapter_latency.py`)'), ('api.log', 'Host API by batch size (`tools/api_latency.py`)'),
                  ('stamps.log', 'In-kernel timelines of one step launch (`tools/stamp_timeline.py`, stamps build)'),
                  ('stamps_general.log', "The same for round 1's general kernel at C2 (`NGW_LEAN=0`)")]:
