@@ -3,7 +3,7 @@
 Each case draws a configuration, a batch size, a horizon, a prepared-episode setting and a sequence of calls - host steps,
 device steps, fused rollouts (generated and supplied actions), masked and full resets, state injection - and compares the
 whole state with the oracle's after every call.  The default budget is a few seconds per chunk of configurations;
-NGW_FUZZ_SECONDS=<s> runs longer (tools-style soak on the GPU box).  Needs an MI355X."""
+NGW_FUZZ_SECONDS=<s> runs longer (a soak on the GPU box), NGW_FUZZ_SEED=<n> draws other sequences.  Needs an MI355X."""
 import os
 import time
 
@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 STATE_KEYS = ('map', 'loc', 'facing', 'inv', 'selected', 'step_count', 'episode')
 CFGS = sorted(T.CFGS)
 BUDGET = float(os.environ.get('NGW_FUZZ_SECONDS', '0'))
+SEED = int(os.environ.get('NGW_FUZZ_SEED', '1000'))
 
 
 def check(v, o, where, lid=None):
@@ -132,7 +133,7 @@ def one_case(rs, cfg, case):
 
 @pytest.mark.parametrize('chunk', range(6))
 def test_random_call_sequences_match_oracle(chunk):
-    rs = np.random.RandomState(1000 + chunk)
+    rs = np.random.RandomState(SEED + chunk)
     mine = CFGS[chunk::6]
     t_end = time.time() + (BUDGET / 6 if BUDGET > 0 else 0)
     case = 0
