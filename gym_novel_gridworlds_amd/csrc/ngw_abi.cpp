@@ -926,9 +926,12 @@ int ngw_sync(ngw_handle* h) {
     return NGW_OK;
 }
 
-static size_t zero_copy_bytes() {                   // ngw_step_host: up to here the outputs go through mapped host memory
+// ngw_step_host: up to here the outputs go through mapped host memory (a kernel writing across PCIe sustains ~12 GB/s, the copy
+// engine ~26 GB/s but costs ~15 us to get going: measured crossover 256-512 KB, tools/api_latency.py with NGW_ZC_BYTES - 16 384
+// envs, 2.6 MB: 186-230 us through mapped memory, 125-140 us staged and copied)
+static size_t zero_copy_bytes() {
     static size_t v = 0;
-    if (!v) { const char* e = getenv("NGW_ZC_BYTES"); v = e ? (size_t)atoll(e) : (size_t)4 << 20; if (!v) v = 1; }
+    if (!v) { const char* e = getenv("NGW_ZC_BYTES"); v = e ? (size_t)atoll(e) : (size_t)256 << 10; if (!v) v = 1; }
     return v;
 }
 #define NGW_ZERO_COPY_BYTES zero_copy_bytes()

@@ -3,7 +3,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gym_novel_gridworlds_amd import VecNovelGridworld
-for n in (1, 64, 1024, 16384, 65536):
+for n in [int(x) for x in os.environ.get('NGW_API_SIZES', '1,64,1024,16384,65536').split(',')]:
     v = VecNovelGridworld(num_envs=n, autoreset=True, horizon=100)
     v.reset()
     a = np.random.randint(0, 17, size=(64, n)).astype(np.int32)
