@@ -24,6 +24,48 @@ class _DevArray:
                                          'version': 2, 'strides': None}
 
 
+class StepInfo(dict):
+    """info of a batched step: 'result' bool[N], 'step_cost_code', 'message_code', 'message_arg' - and 'step_cost' f64[N], which is
+    looked up from the codes when it is first asked for (a 65 536-element gather per step costs more than the step kernel; few
+    callers read it).  Behaves as a dict that has the key."""
+    __slots__ = ()
+
+    def __missing__(self, key):
+        if key == 'step_cost':
+            v = _COST_F64[dict.__getitem__(self, 'step_cost_code')]
+            dict.__setitem__(self, key, v)
+            return v
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return key == 'step_cost' or dict.__contains__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def _all(self):
+        self['step_cost']
+        return self
+
+    def keys(self):
+        return dict.keys(self._all())
+
+    def items(self):
+        return dict.items(self._all())
+
+    def values(self):
+        return dict.values(self._all())
+
+    def __iter__(self):
+        return dict.__iter__(self._all())
+
+    def __len__(self):
+        return dict.__len__(self._all())
+
+    def copy(self):
+        return StepInfo(dict(dict.items(self)))
+
+
 class VecNovelGridworld:
     def __init__(self, env_id='NovelGridworld-Pogostick-v1', num_envs=1, map_size=None, novelty=None, device=0,
                  seed=0, autoreset=False, horizon=0, env_index_base=0, spec=None, reset_prefetch='auto'):
@@ -133,13 +175,19 @@ class VecNovelGridworld:
         a = np.ascontiguousarray(actions, np.int32)
         assert a.shape == (self.num_envs,)
         self._act_pinned[...] = a
-        o, p = self._obs, _cabi._ptr
-        m = p(o['map'], np.int8) if with_obs else None
-        _cabi.check(_cabi.lib().ngw_step_host(                       # actions in, launch, observation + outputs out: one sync
-            self._h, p(self._act_pinned, np.int32), m, p(o['agent_location'], np.int32),
-            p(o['agent_facing_id'], np.int32), p(o['inventory_items_quantity'], np.int32), p(self._reward, np.int32),
-            p(self._done, np.uint8), p(self._result, np.uint8), p(self._cost, np.uint8), p(self._msg, np.uint16), p(self._arg, np.uint16),
-            p(self._flags_np, np.uint32), p(self._sel_host, np.uint8), p(self._steps_host, np.int32)))
+        o = self._obs
+        cache = self.__dict__.setdefault('_step_args', {})
+        args = cache.get(bool(with_obs))
+        if args is None:                                             # the host arrays never move: the argument list is built once
+            p = _cabi._ptr
+            args = cache[bool(with_obs)] = (
+                self._h, p(self._act_pinned, np.int32), p(o['map'], np.int8) if with_obs else None, p(o['agent_location'], np.int32),
+                p(o['agent_facing_id'], np.int32), p(o['inventory_items_quantity'], np.int32), p(self._reward, np.int32),
+                p(self._done, np.uint8), p(self._result, np.uint8), p(self._cost, np.uint8), p(self._msg, np.uint16), p(self._arg, np.uint16),
+                p(self._flags_np, np.uint32), p(self._sel_host, np.uint8), p(self._steps_host, np.int32))
+        rc = _cabi.lib().ngw_step_host(*args)                        # actions in, launch, observation + outputs out: one sync
+        if rc:
+            _cabi.check(rc)
         self._last_actions = a
         obs = None if not with_obs else ({k: v.copy() for k, v in o.items()} if copy else o)
         reward, done, info = self._step_out_views(copy)
@@ -192,12 +240,11 @@ class VecNovelGridworld:
         return self._step_out_views(copy)
 
     def _step_out_views(self, copy=False):
-        info = {'result': self._result.astype(bool), 'step_cost': _COST_F64[self._cost], 'step_cost_code': self._cost,
-                'message_code': self._msg, 'message_arg': self._arg}
-        reward, done = self._reward, self._done.astype(bool)
+        info = StepInfo({'result': self._result.view(np.bool_), 'step_cost_code': self._cost, 'message_code': self._msg, 'message_arg': self._arg})
+        reward, done = self._reward, self._done.view(np.bool_)      # (the kernels store 0 / 1)
         if copy:
-            reward = reward.copy()
-            info = {k: v.copy() for k, v in info.items()}
+            reward, done = reward.copy(), done.copy()
+            info = StepInfo({k: v.copy() for k, v in dict.items(info)})
         return reward, done, info
 
     def messages(self, info, actions):
