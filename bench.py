@@ -366,12 +366,13 @@ def main():
     if args.mode == 'step' and side and not args.no_stagger:
         stag_acts = None
         stag = {'what': 'episode ends staggered over the batch (~%d of %d envs reset per batched step), hipGraph replay' % (n // HORIZON, n)}
-        for key, every in (('inline_resets', 0), ('prepared_next_episodes_every_32', 32)):
+        default_every = sv.local._default_prefetch() if args.reset_prefetch == 'auto' else prefetch
+        for key, every in (('inline_resets', 0), ('prepared_next_episodes', default_every or 32)):
             v.set_reset_prefetch(every)
             v.reset()
             v.set_state(0, step_count=(np.arange(n) * 7919 % HORIZON).astype(np.int32))
-            gs = 64                                           # two refill periods per replay
-            if stag_acts is None:
+            gs = 2 * every if every else 64                   # two refill periods per replay
+            if stag_acts is None or stag_acts.shape[0] < gs:
                 stag_acts = torch.randint(0, A, (gs, n), dtype=torch.int32, device='cuda', generator=g)
                 torch.cuda.synchronize()
             v.graph_build(stag_acts.data_ptr(), n, gs)
@@ -382,7 +383,9 @@ def main():
             s_ms = v.timing_end() / (max(1, 512 // gs) * gs)
             fence()
             stag[key] = {'ms_per_step': round(s_ms, 6), 'value': round(n / (s_ms * 1e-3), 1), 'unit': 'env-steps/s'}
-        stag['default'] = 'prepared_next_episodes_every_32 (VecNovelGridworld / ngw_set_autoreset switch it on)'
+            if every:
+                stag[key]['refill_every'] = every
+        stag['default'] = 'prepared_next_episodes (VecNovelGridworld / ngw_set_autoreset switch it on: a refill every 3/4 horizon)'
         assert v.error_flags() == 0
 
     # PCIe-inclusive host loop (the drop-in API mode of SURVEY.md §8(d)): never `value`

@@ -19,7 +19,7 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_set_autoreset', 'ngw_set_stream', 'ngw_reset', 'ngw_step', 'ngw_step_device', 'ngw_rollout',
            'ngw_get_obs', 'ngw_get_step_out', 'ngw_get_state', 'ngw_set_state', 'ngw_obs_device_ptrs',
            'ngw_out_device_ptrs', 'ngw_sync', 'ngw_error_flags', 'ngw_timing_begin', 'ngw_timing_end',
-           'ngw_graph_build', 'ngw_graph_launch', 'ngw_timing_mark', 'ngw_lidar_configure', 'ngw_lidar', 'ngw_lidar_fuse',
+           'ngw_graph_build', 'ngw_graph_launch', 'ngw_get_reset_prefetch', 'ngw_timing_mark', 'ngw_lidar_configure', 'ngw_lidar', 'ngw_lidar_fuse',
            'ngw_get_lidar', 'ngw_lidar_device_ptr', 'ngw_host_alloc', 'ngw_host_free', 'ngw_agent_view',
            'ngw_get_agent_view', 'ngw_agent_view_device_ptr', 'ngw_set_reset_prefetch', 'ngw_step_host', 'ngw_lidar_set_output', 'ngw_rollout_actions',
            'ngw_pack_layout', 'ngw_pack_obs', 'ngw_unpack_obs', 'ngw_rollout_outputs', 'ngw_episode_stats', 'ngw_host_step_layout', 'ngw_step_device_many']
@@ -102,6 +102,7 @@ def lib():
     L.ngw_timing_mark.argtypes = [vp]
     L.ngw_graph_build.argtypes = [vp, vp, i64, i32]
     L.ngw_graph_launch.argtypes = [vp, i32]
+    L.ngw_get_reset_prefetch.argtypes = [vp, C.POINTER(C.c_int32)]
     L.ngw_lidar_configure.argtypes = [vp, vp]
     L.ngw_lidar.argtypes = [vp]
     L.ngw_lidar_fuse.argtypes = [vp, C.c_int]

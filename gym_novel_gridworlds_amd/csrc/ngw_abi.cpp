@@ -722,10 +722,21 @@ int ngw_set_autoreset(ngw_handle* h, int autoreset, int horizon) {
     h->horizon = horizon;
     if (!h->prefetch_user) {
         // Prepared next episodes are the default under autoreset (bit-identical results; a batch whose episode ends are spread
-        // over the steps runs ~3x faster), unless the episodes are too short for a refill every 32 steps to keep up
-        const int every = (h->autoreset && (horizon == 0 || horizon >= 64)) ? 32 : 0;
+        // over the steps runs ~3x faster), unless the horizon is too short for refills to keep up.  A refill costs a
+        // reset's latency however few rows are stale, and under a horizon H an env needs a new row once per H steps: the cadence
+        // is 3/4 of the horizon (32 .. 128 steps; 32 without a horizon) - episodes that end early make some resets miss their
+        // row, and the cadence then adapts downwards (adapt_cadence).
+        int every = 0;
+        if (h->autoreset && horizon == 0) every = 32;
+        else if (h->autoreset && horizon >= 64) { every = 3 * horizon / 4; every = every < 32 ? 32 : (every > 128 ? 128 : every); }
         if (every != h->prefetch_every) { const int rc = ngw_set_reset_prefetch(h, every); h->prefetch_user = 0; return rc; }
     }
+    return NGW_OK;
+}
+
+int ngw_get_reset_prefetch(ngw_handle* h, int32_t* every_n_steps) {
+    if (!h || !every_n_steps) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    *every_n_steps = h->prefetch_every;
     return NGW_OK;
 }
 

@@ -99,7 +99,7 @@ class VecNovelGridworld:
         self.lidar, self.lidar_fused, self.lidar_len = None, False, 0      # set by lidar_configure()
         # 'auto' = the library's own default: ngw_set_autoreset switched prepared next episodes on (a refill every 32 steps)
         # unless the episodes are too short for that cadence to keep up (rows would go stale and resets simply run inline)
-        self.reset_prefetch = 32 if self.autoreset and (self.horizon == 0 or self.horizon >= 64) else 0
+        self.reset_prefetch = self._default_prefetch()
         if reset_prefetch != 'auto':
             self.set_reset_prefetch(reset_prefetch)
         self._flags_word = C.c_uint32(0)
@@ -149,7 +149,7 @@ class VecNovelGridworld:
         self.autoreset, self.horizon = bool(autoreset), int(horizon)
         _cabi.check(_cabi.lib().ngw_set_autoreset(self._h, int(self.autoreset), self.horizon))
         if not self.__dict__.get('_prefetch_user'):
-            self.reset_prefetch = 32 if self.autoreset and (self.horizon == 0 or self.horizon >= 64) else 0
+            self.reset_prefetch = self._default_prefetch()
 
     def set_stream(self, hip_stream_ptr):
         _cabi.check(_cabi.lib().ngw_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
@@ -263,6 +263,12 @@ class VecNovelGridworld:
     def step_device_many(self, actions_ptr, step_stride, n_steps):
         """n_steps batched steps from one call: step i reads int32 actions at device address actions_ptr + 4 * i * step_stride."""
         _cabi.check(_cabi.lib().ngw_step_device_many(self._h, C.c_void_p(int(actions_ptr)), int(step_stride), int(n_steps)))
+
+    def _default_prefetch(self):
+        """The refill cadence the library chose for this autoreset / horizon setting (include/ngw.h ngw_set_autoreset)."""
+        v = C.c_int32()
+        _cabi.check(_cabi.lib().ngw_get_reset_prefetch(self._h, C.byref(v)))
+        return int(v.value)
 
     def set_reset_prefetch(self, every_n_steps):
         """Keep every env's NEXT episode prepared in shadow buffers and re-prepare consumed ones every `every_n_steps`

@@ -205,10 +205,12 @@ int ngw_set_autoreset(ngw_handle* h, int autoreset, int horizon);
  * in shadow buffers: a reset then copies that row (one memory round trip), and one extra launch every `every_n_steps`
  * batched steps (and after every ngw_reset) re-prepares the rows consumed since.  Results are bit-identical with the
  * feature on or off (the shadow row is the output of the same per-(env, episode) Philox stream).  0 = off.
- * ngw_set_autoreset(h, 1, horizon) switches it ON by itself (a refill every 32 steps; not for horizons under 64 steps, where
+ * ngw_set_autoreset(h, 1, horizon) switches it ON by itself (a refill every 3/4 horizon, 32 to 128 steps, 32 without a horizon; not for horizons under 64 steps, where
  * rows would go stale before they are needed) unless the caller has chosen a cadence with this call, before or after.
  * Fused rollouts run as launches of at most every_n_steps steps with the refills between them. */
 int ngw_set_reset_prefetch(ngw_handle* h, int32_t every_n_steps);
+/* The refill cadence in effect (0 = prepared episodes off): what ngw_set_reset_prefetch set, or the default ngw_set_autoreset chose. */
+int ngw_get_reset_prefetch(ngw_handle* h, int32_t* every_n_steps);
 int ngw_set_stream(ngw_handle* h, void* hip_stream);
 
 /* reset(): pogostick_v1_env.py:86-157 (+ AddItem.reset).  mask = NULL resets all envs, else mask[i] != 0. */

@@ -654,7 +654,7 @@ def test_big_batch_host_step_uses_one_block_and_matches_oracle():
 
 def test_refill_cadence_adapts_to_short_episodes_and_results_stay_exact():
     """Default prepared-episode setting: under FireWall an env ends several episodes between two refills, the stale rows are
-    counted on the device and the host shortens the refill cadence (32 -> ... -> 2) - without changing a single result."""
+    counted on the device and the host shortens the refill cadence (75 -> ... -> 2) - without changing a single result."""
     import ctypes
     from gym_novel_gridworlds_amd import _cabi
     spec = T.build_spec('fire10h')
@@ -665,7 +665,8 @@ def test_refill_cadence_adapts_to_short_episodes_and_results_stay_exact():
     lib = _cabi.lib()
     lib.ngw_debug_refill_cadence.argtypes = [ctypes.c_void_p]
     lib.ngw_debug_refill_cadence.restype = ctypes.c_int
-    assert lib.ngw_debug_refill_cadence(v._h) == 32
+    start = lib.ngw_debug_refill_cadence(v._h)
+    assert start == v.reset_prefetch == 75               # the default under a horizon of 100: 3/4 of it
     v.reset(); o.reset()
     rs = np.random.RandomState(4)
     for t in range(400):
@@ -673,7 +674,7 @@ def test_refill_cadence_adapts_to_short_episodes_and_results_stay_exact():
         _, reward, done, info = v.step(a); o.step(a)
         assert (reward == o.reward).all() and (done == o.done.astype(bool)).all(), t
     assert_state_equal(v, o, 'fire10h adaptive cadence')
-    assert lib.ngw_debug_refill_cadence(v._h) < 32
+    assert lib.ngw_debug_refill_cadence(v._h) < start
     v.rollout(300, action_seed=8, t0=0); assert o.rollout(300, 8, 0) == 0
     assert_state_equal(v, o, 'fire10h adaptive cadence, fused')
     assert v.error_flags() == 0

@@ -19,7 +19,7 @@ def trim(x):
         o['fused_supplied_actions_G'] = round(x['fused_rollout'].get('with_supplied_actions', {}).get('value', 0) / 1e9, 1)
     if 'staggered_resets' in x:
         o['staggered_inline_G'] = round(x['staggered_resets']['inline_resets']['value'] / 1e9, 2)
-        o['staggered_prepared_G'] = round(x['staggered_resets']['prepared_next_episodes_every_32']['value'] / 1e9, 2)
+        o['staggered_prepared_G'] = round(x['staggered_resets']['prepared_next_episodes']['value'] / 1e9, 2)
     if 'api_mode' in x:
         o['api_mode_G'] = round(x['api_mode']['value'] / 1e9, 3)
     if 'c1_single_env' in x:
