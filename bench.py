@@ -185,6 +185,7 @@ def main():
     n = args.envs or n_default
     spec = make_spec(env_id, S)
     if nov:
+        np.random.seed(0)                                 # (Crate draws its contents from the global stream at injection, like the reference)
         apply_novelty(spec, *nov)
     K, A = len(spec.items_id), len(spec.actions_id)
     prefetch = args.reset_prefetch if args.reset_prefetch == 'auto' else int(args.reset_prefetch)

@@ -402,7 +402,7 @@ __device__ __forceinline__ uint32_t consume_lane(const NgwNx nx, LDS_AS int8_t* 
 constexpr uint32_t NGW_F_ROWS_STORED = 0x80u;
 __device__ __noinline__ uint32_t new_episode(const NgwDevSpec* dspec, LDS_AS int8_t* mp, LDS_AS int32_t* inv, LDS_AS uint32_t* cand,
                                              const LDS_AS uint8_t* place_seq, LDS_AS uint16_t* perm_lds, uint64_t env_global,
-                                             int64_t env_local, uint32_t episode, bool may_consume) {
+                                             int64_t env_local, uint32_t episode, bool may_consume, bool count_miss = true) {
     const GLOBAL_AS NgwResetU* rp = (const GLOBAL_AS NgwResetU*)&dspec->ru;        // both blobs requested together
     const GLOBAL_AS NgwNx* np = (const GLOBAL_AS NgwNx*)&dspec->nx;
     NgwResetU ru; NgwNx nx;
@@ -415,7 +415,7 @@ __device__ __noinline__ uint32_t new_episode(const NgwDevSpec* dspec, LDS_AS int
         if (((const GLOBAL_AS uint32_t*)nx.episode)[env_local] == episode)
             return consume_lane(nx, mp, inv, (GLOBAL_AS int8_t*)ru.map + env_local * ru.S2, (GLOBAL_AS int32_t*)ru.inv + env_local * ru.K,
                                 env_local, ru.S2, ru.K) | NGW_F_ROWS_STORED;
-        atomicAdd(nx.slow, 1u);                                                    // a stale row: the host shortens the refill cadence
+        if (count_miss) atomicAdd(nx.slow, 1u);                                    // a stale row inside a step: the host shortens the refill cadence
     }
     const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS, rs0, rs1, rs2, rs3, pw0, pw1, pw2, pw3};
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_base[];            // the kernel's dynamic LDS (offset 0)
@@ -1002,7 +1002,8 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                 episode++;
                 uint32_t rr = new_episode(dspec, (LDS_AS int8_t*)mp, (LDS_AS int32_t*)inv, (LDS_AS uint32_t*)cand,
                                           (const LDS_AS uint8_t*)(lds_act + NGW_MAX_ACTIONS * NGW_ACT_DW),
-                                          (LDS_AS uint16_t*)(lds + a.off_perm), env_global, e, episode, mode != NGW_MODE_REFILL);
+                                          (LDS_AS uint16_t*)(lds + a.off_perm), env_global, e, episode, mode != NGW_MODE_REFILL,
+                                          mode != NGW_MODE_RESET);   // (an explicit reset that finds nothing prepared is not a miss)
                 do_reset = !(rr & NGW_F_ROWS_STORED);                              // from here on: "the wave must store its chunk"
                 rr &= ~(uint32_t)NGW_F_ROWS_STORED;
                 if (mode == NGW_MODE_REFILL && (rr & 0xFFu)) { rr &= ~0xFFu; episode = nx_old; }   // failed placement: leave the row

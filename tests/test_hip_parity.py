@@ -727,7 +727,7 @@ def test_staggered_episode_ends_are_served_by_prepared_episodes():
     v.reset(); o.reset()
     sc = (np.arange(n) * 7919 % H).astype(np.int32)
     v.set_state(0, step_count=sc); o.st.step_count[:] = sc
-    s0 = lib.ngw_debug_slow_resets(v._h)                          # (the first explicit reset found nothing prepared: n)
+    s0 = lib.ngw_debug_slow_resets(v._h)                          # (explicit resets are not counted)
     assert s0 >= 0
     rs = np.random.RandomState(12)
     for t in range(3 * H):
