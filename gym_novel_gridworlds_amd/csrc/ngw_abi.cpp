@@ -271,6 +271,11 @@ int upload_reset_u(ngw_handle* h) {
     NgwResetU ru = {};
     ru.perm = h->b.perm; ru.map = h->b.map; ru.inv = h->b.inv; ru.n_pad = h->n_pad; ru.seed = p.seed;
     ru.S = p.S; ru.S2 = p.S2; ru.K = p.K; ru.CW = p.CW; ru.perm_lds = p.perm_lds; ru.magicS = p.magicS; ru.off_rng = h->off_rng;
+    {   // sparse subset passes (include/ngw.h, ngw_spec.n_passes): interior ordinal / (S-2), and the skip thresholds of the exact multiply-shift draw
+        const uint32_t IW = (uint32_t)(p.S - 2), nint = IW * IW, nring = (uint32_t)(4 * p.S - 4);
+        ru.magicIW22 = ((1u << 22) + IW - 1) / IW;
+        ru.thr_int = (uint32_t)(0u - nint) % nint; ru.thr_ring = (uint32_t)(0u - nring) % nring;
+    }
     const ngw_spec& s = h->spec;
     ru.wall_item = s.wall_item; ru.tap_item = s.tap_item; ru.tap_near = s.tap_near;
     int n_place = 0;
@@ -302,60 +307,49 @@ int upload_reset_u(ngw_handle* h) {
 void layout_reset_fast(ngw_handle* h) {
     const ngw_spec& s = h->spec;
     h->rf_nw = -1;
-    // one shuffled-subset pass whose source cells need no map scan: AddItem / Crate (air: the interior minus the placed items) or
-    // ReplaceItem / FireWall of the WALL item (the ring)
+    // at most one subset pass, and one whose source cells need no map scan: AddItem / Crate (air: the interior minus the placed
+    // items) or ReplaceItem / FireWall of the WALL item (the ring)
     const bool wall_pass = s.n_passes == 1 && s.pass_kind[0] == NGW_PASS_REPLACE && s.pass_from[0] == s.wall_item;
-    const bool additem_only = (s.n_passes == 1 && s.pass_kind[0] == NGW_PASS_ADDITEM) || wall_pass;
-    if (!h->fast_reset || s.tap_item || (s.n_passes && !additem_only)) return;    // other reset passes: general kernel
+    const bool subset = (s.n_passes == 1 && s.pass_kind[0] == NGW_PASS_ADDITEM) || wall_pass;
+    if (!h->fast_reset || s.tap_item || (s.n_passes && !subset)) return;          // other reset passes: general kernel
     const int S = s.map_size, S2 = S * S, CW = h->proto.CW;
-    // measured (tools/reset_time.py, all 65 536 envs): 10 x 10 plain 26.8 us vs 23.6 us in the general kernel, 20 x 20 24.9 vs 37.4,
-    // 32 x 32 + AddItem 1.65 vs 1.87 ms - small plain maps stay with the general kernel (NGW_FAST_RESET=2 forces this one)
-    if (CW <= 2 && !additem_only && h->fast_reset < 2) return;
+    // small plain maps stay with the general kernel unless NGW_FAST_RESET=2 (measured in round 2 with the old two-phase store:
+    // 10 x 10 plain 26.8 us vs 23.6 us for 65 536 envs)
+    if (CW <= 2 && !subset && h->fast_reset < 2) return;
     NgwResetFast& a = h->rf;
     a = NgwResetFast{};
     int n_place = 0;
     for (int j = 0; j < s.n_start; j++) n_place += s.start_qty[j];
+    if (n_place > 12) return;                                                       // the kernel sorts the placed items in 12 registers
     const int nw = CW <= 2 ? 2 : (CW <= 8 ? 8 : 0);
-    // AddItem's shuffle array holds ordinals + 1: 10-bit elements, three per dword, up to 32 x 32 (override: NGW_RESET_PACK=0) -
-    // 77 KB per wave at 32 x 32 instead of 115 KB as u16, so two waves share a CU; u16 beyond.  The kernel keeps the placed
-    // cells in 12 registers.
-    if (additem_only && n_place > 12) return;
-    bool pack = additem_only && S2 <= 1024;
-    if (const char* v = getenv("NGW_RESET_PACK")) pack = pack && atoi(v) != 0;
-    const uint32_t tmpl_dw = (uint32_t)((2 * S2 + 16 + NGW_MAX_PLACE + 3) / 4);
-    const uint32_t placed_dw = (uint32_t)((n_place > 0 ? n_place : 1) * NGW_EPB);
-    const int nint = (S - 2) * (S - 2);
+    const uint32_t MW = (uint32_t)((S2 + 31) / 32);                                 // words of a per-env bit column
     uint32_t off = 0;
     a.off_ring = off; off += 16 * NGW_EPB;
-    a.off_perm = off;
-    // candidate / blocked masks, the placed list and the template are dead before the array is touched: they overlay it
     a.off_masks = off; if (nw == 0) off += (uint32_t)(2 * CW * NGW_EPB);
-    a.off_placed = off; off += placed_dw;
-    a.off_tmpl = off; off += tmpl_dw;
-    if (additem_only) {
-        const uint32_t perm_dw = pack ? (uint32_t)((nint + 2) / 3 + 1) * NGW_EPB : (uint32_t)((nint + 1) * NGW_EPB * 2 / 4 + 1);
-        if (a.off_perm + perm_dw > off) off = a.off_perm + perm_dw;
-    }
-    if ((size_t)off * 4 > 160 * 1024) return;                                       // the shuffle array does not fit: general kernel
+    a.off_placed = off; off += 13 * NGW_EPB;                                        // 12 placed items + the sentinel
+    a.off_tmpl = off; off += (uint32_t)((S2 + 16 + NGW_MAX_PLACE + 3) / 4);
+    a.off_dom = off; if (subset) off += MW + 1;
+    a.off_mcol = off; if (subset) off += (MW + 1) * NGW_EPB;
+    if ((size_t)off * 4 > 160 * 1024) return;
     h->rf_lds = (size_t)off * 4;
-    h->rf_nw = nw; h->rf_additem = additem_only ? (pack ? 2 : 1) : 0;
+    h->rf_nw = nw; h->rf_additem = subset ? 1 : 0;
     a.main = h->b; a.nx = h->nx;
     a.pctq = reinterpret_cast<const double*>(h->dspec->pctq[0]);
     a.n = h->n; a.env_base = h->env_base; a.seed = h->seed; a.flags = h->b.flags;
     a.S = S; a.S2 = S2; a.K = s.n_items; a.CW = CW; a.n_place = n_place; a.wall_item = s.wall_item;
-    a.additem_item = additem_only ? s.pass_item[0] : 0; a.additem_span = additem_only ? s.pass_pct_hi[0] - s.pass_pct_lo[0] : 1;
+    a.additem_item = subset ? s.pass_item[0] : 0; a.additem_span = subset ? s.pass_pct_hi[0] - s.pass_pct_lo[0] : 1;
     a.pass_wall = wall_pass ? 1 : 0;
     a.n_inv_start = s.n_inv_start;
     for (int j = 0; j < NGW_MAX_INV_START; j++) {
         a.inv_start_items |= (uint32_t)s.inv_start_item[j] << (8 * j);
         a.inv_start_qtys |= (uint32_t)s.inv_start_qty[j] << (8 * j);
     }
-    const uint32_t W = (uint32_t)(S - 4);
+    const uint32_t W = (uint32_t)(S - 4), IW = (uint32_t)(S - 2);
     a.magicW = W ? (uint32_t)((0x100000000ull + W - 1) / W) : 0;
-    a.magicS2 = (uint32_t)((0x100000000ull + (uint32_t)S2 - 1) / (uint32_t)S2);
     a.magicS = (uint32_t)((0x100000000ull + (uint32_t)S - 1) / (uint32_t)S);
-    a.magicIW22 = S > 3 ? (uint32_t)(((1u << 22) + (uint32_t)(S - 2) - 1) / (uint32_t)(S - 2)) : 0;
-    a.magicIW = S > 3 ? (uint32_t)((0x100000000ull + (uint32_t)(S - 2) - 1) / (uint32_t)(S - 2)) : 0;
+    a.magicIW22 = ((1u << 22) + IW - 1) / IW;
+    const uint32_t nd = wall_pass ? (uint32_t)(4 * S - 4) : IW * IW;
+    a.sub_thr = (uint32_t)(0u - nd) % nd;
 }
 
 // mode = NGW_MODE_RESET (mask_dev or nullptr) / NGW_MODE_REFILL; returns 1 if the dedicated kernel took the launch

@@ -125,6 +125,8 @@ struct NgwResetU {
     int32_t S, S2, K, CW, perm_lds;
     uint32_t magicS;
     uint32_t off_rng;     /* LDS dword offset of the Philox word ring [32][64] of the reset path */
+    uint32_t magicIW22;   /* ceil(2^22 / (S-2)): interior ordinal / (S-2) as a 24-bit multiply (sparse subset passes) */
+    uint32_t thr_int, thr_ring;   /* 2^32 mod (S-2)^2 and 2^32 mod (4S-4): words below are skipped by the exact multiply-shift draw */
     /* the bytes of ngw_spec the reset reads, packed (8 dwords): fetched together with the rest of this struct, so the
      * reset never waits on one more dependent load of the spec for each optional pass */
     uint8_t wall_item, tap_item, tap_near, n_place;
@@ -170,8 +172,9 @@ extern "C"
 #endif
 hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int feat /* 1 = fused lidar, 2 = EXT */, unsigned grid, size_t lds_bytes,
                       hipStream_t stream);
-/* Arguments of the dedicated new-episode kernel (ngw_reset.inc: explicit resets and prepared next episodes of the plain and
- * AddItem / Crate configurations). */
+/* Arguments of the dedicated new-episode kernel (ngw_reset.inc: explicit resets and prepared next episodes of the plain
+ * configurations and of those with ONE subset pass over the air of the interior (AddItem / Crate) or the wall ring (ReplaceItem /
+ * FireWall of the wall item)). */
 struct NgwResetFast {            // kernel arguments (by value)
     NgwBufs main;                // the handle's state (episode counters; RESET destination)
     NgwNx nx;                    // shadow rows (REFILL destination)
@@ -182,22 +185,21 @@ struct NgwResetFast {            // kernel arguments (by value)
     uint32_t* flags;
     int32_t mode;                // NGW_MODE_RESET / NGW_MODE_REFILL
     int32_t S, S2, K, CW, n_place, wall_item;
-    int32_t additem_item, additem_span;
+    int32_t additem_item, additem_span;   // the subset pass: item written, width of its percent range
     uint32_t refill_seq;         // REFILL: number of this refill launch (reported to the host with the stale-row count)
     int32_t pass_wall;           // the subset pass replaces WALL cells (ReplaceItem / FireWall of the ring) instead of filling air cells
     int32_t n_inv_start;
     uint32_t inv_start_items, inv_start_qtys;   // 4 bytes each
     uint32_t magicW;             // ceil(2^32 / (S-4))
-    uint32_t magicS2;            // ceil(2^32 / S2): chunk byte offset / S2
-    uint32_t magicS, magicIW22;  // ceil(2^32 / S), ceil(2^22 / (S-2)): 24-bit multiply form for operands < 1024
-    uint32_t magicIW;            // ceil(2^32 / (S-2))
-    uint32_t off_ring, off_masks, off_placed, off_tmpl, off_perm;    // LDS dword offsets
+    uint32_t magicS, magicIW22;  // ceil(2^32 / S), ceil(2^22 / (S-2)): 24-bit multiply form for operands < 2^11
+    uint32_t sub_thr;            // 2^32 mod (cells of the pass domain): words below it are skipped (exact multiply-shift)
+    uint32_t off_ring, off_masks, off_placed, off_tmpl, off_dom, off_mcol;    // LDS dword offsets
     uint64_t* stamps;            // diagnostics builds (-DNGW_STAMPS), or nullptr
 };
 #ifdef __cplusplus
 extern "C"
 #endif
-hipError_t ngw_reset_fast_launch(const NgwDevSpec* dspec, const struct NgwResetFast* a, int nw, int additem, unsigned grid, size_t lds_bytes,
+hipError_t ngw_reset_fast_launch(const NgwDevSpec* dspec, const struct NgwResetFast* a, int nw, int subset, unsigned grid, size_t lds_bytes,
                                  hipStream_t stream);
 
 /* Device-side lidar tables, built by ngw_lidar_configure from ngw_lidar_cfg: flat cell offsets dr * S + dc. */

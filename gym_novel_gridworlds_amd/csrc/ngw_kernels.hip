@@ -109,6 +109,16 @@ struct PhiloxRing {
         else nxt = ring[pos * EPB];                                                // lands while the caller works on r
         return r;
     }
+    // the sparse subset passes take whole blocks, from the next block boundary on
+    __device__ __forceinline__ void align() {
+        pos = (pos + 3) & ~3;
+        if (pos == PHILOX_RING) fill(); else nxt = ring[pos * EPB];
+    }
+    __device__ __forceinline__ void block(uint32_t& w0, uint32_t& w1, uint32_t& w2, uint32_t& w3) {   // pos is a multiple of 4
+        w0 = nxt; w1 = ring[(pos + 1) * EPB]; w2 = ring[(pos + 2) * EPB]; w3 = ring[(pos + 3) * EPB];
+        pos += 4;
+        if (pos == PHILOX_RING) fill(); else nxt = ring[pos * EPB];
+    }
 };
 
 struct PhiloxRegs {
@@ -131,6 +141,11 @@ struct PhiloxRegs {
         w0 = w1; w1 = w2; w2 = w3;
         have--;
         return r;
+    }
+    __device__ __forceinline__ void align() { have = 0; }                          // what is left of the current block is dropped
+    __device__ __forceinline__ void block(uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {   // have == 0
+        philox_block(c0, c1, c2, c3, k0, k1, o0, o1, o2, o3);
+        c0++;
     }
 };
 
@@ -192,7 +207,53 @@ struct ResetArgs {
     uint32_t magicS;                // ceil(2^32 / S): cell / S for cell < S*S
     uint32_t rs0, rs1, rs2, rs3;             // NgwResetU's packed spec bytes: wall|tap|tap_near|n_place, n_passes|n_inv_start, inv_start_item[4], inv_start_qty[4]
     uint32_t pw0, pw1, pw2, pw3;              // shuffled-subset passes: kind | item << 8 | from << 16 | span << 24
+    uint32_t magicIW22, thr_int, thr_ring;    // sparse subset passes: ceil(2^22 / (S-2)), 2^32 mod (S-2)^2, 2^32 mod (4S-4)
 };
+
+// The subset passes NGW_PASS_SPARSE names (include/ngw.h, ngw_spec.n_passes; oracle: subset_pass_sparse) on the lane's byte
+// map: AddItem / Crate over the air of the interior, ReplaceItem / FireWall over the wall of the ring.  No index array: the
+// percent first, then min(cnt, len - cnt) distinct matching cells by rejection - the complement when that is the smaller
+// set - candidates (word * ND) >> 32 from whole Philox blocks (next block boundary on; the rest of the last block is
+// dropped), a taken cell marked NGW_PASS_MARK until the closing sweep writes the items.  This is the cold form (resets
+// inside a step when no prepared episode exists, stacks of passes, the fused lidar path); ngw_reset.inc runs the same
+// draws on one bit per cell.
+template <bool RING, class RNG, typename MP>
+__device__ __forceinline__ void sparse_pass(RNG& px, MP mp, int S, int agent, int from, int item, int pct_span, const GLOBAL_AS double* pctq,
+                                            uint32_t magicIW22, uint32_t thr) {
+    const int IW = S - 2;
+    const uint32_t ND = RING ? (uint32_t)(4 * S - 4) : (uint32_t)(IW * IW);
+    auto cell_of = [&](uint32_t t) -> int {
+        if (RING) {                                                                // ring ordinal -> cell, row-major: row 0 | (r, 0), (r, S-1) | row S-1
+            const int u = (int)t - S, mid = 2 * (S - 2);
+            const int side = (1 + (u >> 1)) * S + ((u & 1) ? S - 1 : 0);
+            return (int)t < S ? (int)t : (u < mid ? side : (S - 1) * S + (u - mid));
+        }
+        const uint32_t tr = __umul24(t, magicIW22) >> 22;                          // t / (S-2)
+        return (int)(t + 2u * tr) + S + 1;
+    };
+    int len = 0;
+    for (uint32_t t = 0; t < ND; t++) len += mp[cell_of(t)] == from;
+    const int pct = (int)bounded(px, (uint32_t)(pct_span - 1));                    // randint(lo, hi) FIRST; a span of 1 draws nothing
+    const int cnt = (int)ceil((double)len * pctq[pct]);                            // int(np.ceil(len * (pct / 100)))
+    const bool comp = 2 * cnt > len;
+    const int need = comp ? len - cnt : cnt;
+    px.align();
+    for (int got = 0; got < need;) {
+        uint32_t w[4];
+        px.block(w[0], w[1], w[2], w[3]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t m = (uint64_t)w[k] * ND;
+            const int cell = cell_of((uint32_t)(m >> 32));
+            if (got < need && (uint32_t)m >= thr && mp[cell] == from) { mp[cell] = (int8_t)NGW_PASS_MARK; got++; }
+        }
+    }
+    for (uint32_t t = 0; t < ND; t++) {
+        const int cell = cell_of(t), v = mp[cell];
+        const bool marked = v == NGW_PASS_MARK;
+        if (marked || v == from) mp[cell] = (int8_t)((marked != comp && cell != agent) ? item : from);   // chosen = marked (direct) / unmarked (complement)
+    }
+}
 
 // The shuffled-subset reset passes - AddItem.reset (novelty_wrappers.py:1017-1028), ReplaceItem.reset (:1131-1144),
 // Fence.reset (:871-884) - on a shuffle array `perm` with element stride `ps`: np.where(<predicate>) in row-major order,
@@ -330,9 +391,12 @@ __device__ __forceinline__ uint32_t reset_lane(const ResetArgs a, MP mp, LDS_AS 
         for (int j = 0; j < n_passes; j++) {                                       // stacked wrappers reset innermost first = injection order
             const uint32_t w = j == 0 ? a.pw0 : (j == 1 ? a.pw1 : (j == 2 ? a.pw2 : a.pw3));
             const int kind = w & 255, item = (w >> 8) & 255, from = (w >> 16) & 255, span = w >> 24;
-            if (kind == NGW_PASS_ADDITEM)                                          // AddItem / Crate
-                run_pass<NGW_PASS_ADDITEM>(a, j, perm_lds, env_local, px, mp, agent, 0, item, span);
-            else if (kind == NGW_PASS_REPLACE)                                     // ReplaceItem / FireWall
+            const GLOBAL_AS double* pctq = (const GLOBAL_AS double*)a.dspec->pctq[j];
+            if (kind == NGW_PASS_ADDITEM)                                          // AddItem / Crate: the air of the interior
+                sparse_pass<false>(px, mp, S, agent, 0, item, span, pctq, a.magicIW22, a.thr_int);
+            else if (kind == NGW_PASS_REPLACE && from == wall_item)                // ReplaceItem / FireWall of the wall ring
+                sparse_pass<true>(px, mp, S, agent, from, item, span, pctq, a.magicIW22, a.thr_ring);
+            else if (kind == NGW_PASS_REPLACE)                                     // ReplaceItem of an item of the interior
                 run_pass<NGW_PASS_REPLACE>(a, j, perm_lds, env_local, px, mp, agent, from, item, span);
             else                                                                   // Fence / FenceRestriction
                 run_pass<NGW_PASS_FENCE>(a, j, perm_lds, env_local, px, mp, agent, wall_item, item, span);
@@ -417,7 +481,8 @@ __device__ __noinline__ uint32_t new_episode(const NgwDevSpec* dspec, LDS_AS int
                                 env_local, ru.S2, ru.K) | NGW_F_ROWS_STORED;
         if (count_miss) atomicAdd(nx.slow, 1u);                                    // a stale row inside a step: the host shortens the refill cadence
     }
-    const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS, rs0, rs1, rs2, rs3, pw0, pw1, pw2, pw3};
+    const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS, rs0, rs1, rs2, rs3, pw0, pw1, pw2, pw3,
+                         rp->magicIW22, rp->thr_int, rp->thr_ring};
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_base[];            // the kernel's dynamic LDS (offset 0)
     if (ru.off_rng != 0xFFFFFFFFu)                                                 // which word source: decided with the LDS layout (ngw_abi.cpp)
         return reset_lane<PhiloxRing>(a, mp, inv, cand, place_seq, perm_lds, (LDS_AS uint32_t*)(lds_base + ru.off_rng + threadIdx.x),
@@ -1295,12 +1360,11 @@ __global__ void ngw_nop_kernel(const NgwDevSpec* dspec, const NgwLaunch a) {}
 
 }  // namespace
 
-extern "C" hipError_t ngw_reset_fast_launch(const NgwDevSpec* dspec, const NgwResetFast* a, int nw, int additem, unsigned grid, size_t lds_bytes,
+extern "C" hipError_t ngw_reset_fast_launch(const NgwDevSpec* dspec, const NgwResetFast* a, int nw, int subset, unsigned grid, size_t lds_bytes,
                                             hipStream_t stream) {
     const void* fn = nullptr;
-    // additem: 0 = plain, 1 = AddItem with a u16 shuffle array, 2 = AddItem with the packed 10-bit array (maps up to 32 x 32)
-#define NGW_RF(NWV, AV) if (nw == NWV && additem == AV) fn = reinterpret_cast<const void*>(ngw_reset_fast<NWV, AV != 0, AV == 2>)
-    NGW_RF(2, 0); NGW_RF(2, 1); NGW_RF(2, 2); NGW_RF(8, 0); NGW_RF(8, 1); NGW_RF(8, 2); NGW_RF(0, 0); NGW_RF(0, 1); NGW_RF(0, 2);
+#define NGW_RF(NWV, SV) if (nw == NWV && (subset != 0) == SV) fn = reinterpret_cast<const void*>(ngw_reset_fast<NWV, SV>)
+    NGW_RF(2, false); NGW_RF(2, true); NGW_RF(8, false); NGW_RF(8, true); NGW_RF(0, false); NGW_RF(0, true);
 #undef NGW_RF
     if (!fn) return hipErrorInvalidValue;
     if (lds_bytes > 64 * 1024) {

@@ -54,6 +54,9 @@ enum { NGW_ACT_FORWARD = 0, NGW_ACT_LEFT = 1, NGW_ACT_RIGHT = 2, NGW_ACT_BREAK =
 /* info['message'] codes; the host formats the string (reference strings cited in spec.py) */
 enum { NGW_XF_FIRE_SKIP_BREAK = 1, NGW_XF_CRATE_IN_FENCE = 2 };
 enum { NGW_PASS_ADDITEM = 1, NGW_PASS_REPLACE = 2, NGW_PASS_FENCE = 3 };   /* ngw_spec.pass_kind */
+/* passes sampled without an index array (see ngw_spec.n_passes): AddItem / Crate (air of the interior), ReplaceItem / FireWall of the wall ring */
+#define NGW_PASS_SPARSE(kind, from, wall_item) ((kind) == NGW_PASS_ADDITEM || ((kind) == NGW_PASS_REPLACE && (from) == (wall_item)))
+#define NGW_PASS_MARK 0x7F       /* transient cell value while such a pass runs (item ids are < NGW_MAX_ITEMS) */
 enum { NGW_MSG_NONE = 0, NGW_MSG_BLOCK_IN_PATH = 1, NGW_MSG_CANNOT_BREAK = 2 /* arg = item */,
        NGW_MSG_PLACED = 3 /* arg = item */, NGW_MSG_ALREADY_EXISTS = 4 /* arg = front item */,
        NGW_MSG_NOT_IN_INVENTORY = 5, NGW_MSG_EXTRACT_NO_SRC = 6, NGW_MSG_EXTRACT_NOT_NEAR = 7,
@@ -135,7 +138,18 @@ typedef struct ngw_spec {
      * (novelty_wrappers.py:1013-1034, :1071): air cells become pass_item; NGW_PASS_REPLACE - ReplaceItem / FireWall
      * (:1129-1148): cells holding pass_from become pass_item; NGW_PASS_FENCE - Fence / FenceRestriction (:867-889): every free
      * 8-neighbour of a chosen non-air, non-wall cell gets pass_item (add_fence_around, pogostick_v1_env.py:524-536).  Any
-     * number of passes of the same kind may be stacked (additem + crate, fence + fencerestriction, replaceitem + firewall). */
+     * number of passes of the same kind may be stacked (additem + crate, fence + fencerestriction, replaceitem + firewall).
+     *
+     * How the subset is DRAWN on the device (per-(env, episode) Philox stream; the CPU oracle's Philox mode runs the same
+     * steps, its MT19937 mode follows numpy call for call): passes whose source cells are the air of the interior or the
+     * wall of the ring (NGW_PASS_SPARSE) never build the index array.  The result of shuffle + "first cnt" is a uniformly
+     * random cnt-subset of the matching cells - the order inside it is irrelevant, every chosen cell gets the same item -
+     * and that is what is sampled: percent first (the numpy bounded draw, as before), cnt = ceil(len * pct / 100), then
+     * min(cnt, len - cnt) distinct matching cells by rejection (the complement when that is the smaller set), each
+     * candidate = (word * ND) >> 32 over the ND cells of the domain (interior row-major / ring row-major; exact: a word whose
+     * low product is below 2^32 mod ND is skipped), words taken in whole Philox blocks starting at the next block
+     * boundary, the rest of the last block discarded.  Same distribution of maps as the reference's, pinned by the
+     * distribution fixtures tests/golden/g6_*.npz; every other pass keeps shuffle-then-prefix. */
     uint8_t n_passes;
     uint8_t pass_kind[NGW_MAX_PASSES], pass_item[NGW_MAX_PASSES], pass_from[NGW_MAX_PASSES];
     uint8_t pass_pct_lo[NGW_MAX_PASSES], pass_pct_hi[NGW_MAX_PASSES];

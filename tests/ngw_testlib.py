@@ -452,3 +452,60 @@ def replay_adapter(cfg, backend, max_steps=400, n_single=300):
         checked += 1
     env.close()
     return checked
+
+
+# ---------------------------------------------------------------- G6: distribution of the reset passes (tests/golden/gen_g6.py)
+G6_CFGS = ('add32', 'add12m', 'add11e', 'crate12h', 'fire14m', 'fire10h', 'replwall12e')
+
+
+def g6_stats(maps, locs, item, S):
+    """What gen_g6.py records for the reference, for a batch of freshly reset envs: per-cell frequency of the pass item,
+    histogram of the number of such cells per env, per-cell frequency of the agent cell."""
+    m = np.asarray(maps).reshape(len(maps), S * S) == item
+    freq = m.sum(0).astype(np.int64)
+    hist = np.bincount(m.sum(1), minlength=S * S + 1).astype(np.int64)
+    agent = np.bincount(np.asarray(locs)[:, 0].astype(np.int64) * S + np.asarray(locs)[:, 1], minlength=S * S).astype(np.int64)
+    return freq, hist, agent
+
+
+def _two_sample_z2(a, na, b, nb):
+    """Sum of squared z-scores of two binomial samples per bin (pooled variance) and the number of bins that can differ."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    p = (a + b) / (na + nb)
+    var = p * (1 - p) * (1.0 / na + 1.0 / nb)
+    use = var > 0
+    z2 = ((a[use] / na - b[use] / nb) ** 2 / var[use]).sum()
+    # bins where both samples agree exactly on "never" / "always" carry no information; they must agree, though
+    assert ((a[~use] == 0) == (b[~use] == 0)).all(), "a cell the reference never / always fills differs"
+    return float(z2), int(use.sum())
+
+
+def g6_check(cfg, freq, hist, agent, n):
+    """Two-sample chi-square of a batch's statistics against the reference's (tests/golden/g6_<cfg>.npz).  The sum of k
+    squared z-scores has mean k and standard deviation ~sqrt(2k): six of those is the bound (seeds are fixed, so a pass
+    stays a pass)."""
+    g = dict(np.load(os.path.join(GOLDEN, 'g6_%s.npz' % cfg)))
+    na = int(g['n'])
+    for name, a, b in (('item cells', g['freq'], freq), ('agent cell', g['agent'], agent)):
+        z2, k = _two_sample_z2(a, na, b, n)
+        assert z2 < k + 6 * (2 * k) ** 0.5 + 10, "%s: %s frequencies differ from the reference (chi2 %.1f over %d cells)" % (cfg, name, z2, k)
+    # count histogram: merge bins until each holds >= 20 reference resets
+    ha, hb = g['hist'].astype(np.int64), np.asarray(hist, np.int64)
+    assert ha.sum() == na and hb.sum() == n
+    nz = np.nonzero(ha + hb)[0]
+    A, B, ca, cb = [], [], 0, 0
+    for i in nz:
+        ca += ha[i]; cb += hb[i]
+        if ca >= 20:
+            A.append(ca); B.append(cb); ca = cb = 0
+    if A:
+        A[-1] += ca; B[-1] += cb
+    else:
+        A, B = [ca], [cb]
+    if len(A) > 1:
+        z2, k = _two_sample_z2(A, na, B, n)
+        assert z2 < k + 6 * (2 * k) ** 0.5 + 10, "%s: count histogram differs from the reference (chi2 %.1f over %d bins)" % (cfg, z2, k)
+    else:
+        assert np.nonzero(ha)[0].tolist() == np.nonzero(hb)[0].tolist(), "%s: the count is a constant in the reference" % cfg
+    mean_a, mean_b = (ha * np.arange(len(ha))).sum() / na, (hb * np.arange(len(hb))).sum() / n
+    return mean_a, mean_b

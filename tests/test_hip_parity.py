@@ -681,12 +681,15 @@ def test_refill_cadence_adapts_to_short_episodes_and_results_stay_exact():
 
 
 @pytest.mark.parametrize('pack', ['1', '0'])
-@pytest.mark.parametrize('cfg,n', [('add12m', 700), ('add18h', 500), ('add24m', 300), ('add29h', 200), ('add32', 260), ('add36e', 130), ('crate20h', 400)])
+@pytest.mark.parametrize('cfg,n', [('add12m', 700), ('add18h', 500), ('add24m', 300), ('add29h', 200), ('add32', 260), ('add36e', 130), ('crate20h', 400),
+                                   ('add11e', 300), ('fire10h', 700), ('fire14m', 300), ('replwall12e', 300), ('fire32m', 130)])
 def test_additem_new_episode_kernel_every_variant(cfg, n, pack, monkeypatch):
-    """The dedicated new-episode kernel with AddItem's shuffle array packed to 10-bit ordinals (maps up to 32 x 32) and as
-    u16 cells (NGW_RESET_PACK=0, and always beyond 32 x 32), at every mask width (register masks of 2 / 8 words, LDS masks):
-    explicit resets, masked resets, prepared episodes under autoreset and a fused rollout equal the oracle."""
-    monkeypatch.setenv('NGW_RESET_PACK', pack)
+    """The subset pass of AddItem / Crate (air of the interior) and of FireWall / ReplaceItem of the wall ring, drawn without an
+    index array (include/ngw.h, ngw_spec.n_passes): the dedicated new-episode kernel (one bit per cell; `pack` = '1') and the
+    general kernel's byte-map form (NGW_FAST_RESET=0; also what a reset inside a step runs when no prepared episode exists)
+    at every mask width (register masks of 2 / 8 words, LDS masks) and row alignment (16-byte pieces, dwords, bytes):
+    explicit resets, masked resets, prepared episodes under autoreset and a fused rollout equal the oracle's Philox mode."""
+    monkeypatch.setenv('NGW_FAST_RESET', pack)
     spec = T.build_spec(cfg)
     A = len(spec.actions_id)
     # prepared next episodes on (a refill after every reset and every 8 steps): the second explicit reset below COPIES its rows
@@ -736,3 +739,49 @@ def test_staggered_episode_ends_are_served_by_prepared_episodes():
     assert_state_equal(v, o, 'staggered ends')
     assert o.st.episode.min() >= 3
     assert 0 <= lib.ngw_debug_slow_resets(v._h) - s0 <= n // 100  # (an early `done` inside one cadence is the only way to miss)
+
+
+@pytest.mark.parametrize('cfg', T.G6_CFGS)
+def test_gpu_resets_follow_the_reference_distribution(cfg):
+    """G6: per-cell frequencies of the pass item and of the agent cell, and the histogram of the item
+    count, of 65 536 GPU resets against 10 000 resets of the reference itself (tests/golden/g6_<cfg>.npz)."""
+    import os
+    spec = T.build_spec(cfg)
+    S = spec.map_size
+    n = 65536
+    g = dict(np.load(os.path.join(T.GOLDEN, 'g6_%s.npz' % cfg)))
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=4242)
+    v.reset()
+    st = v.get_state()
+    assert v.error_flags() == 0
+    freq, hist, agent = T.g6_stats(st['map'], st['loc'], int(g['item']), S)
+    mean_ref, mean_got = T.g6_check(cfg, freq, hist, agent, n)
+    assert abs(mean_ref - mean_got) <= 0.02 * max(mean_ref, 1.0) + 0.05
+    v.close()
+
+
+@pytest.mark.parametrize('S', [5, 6, 7, 9])
+def test_wall_ring_pass_on_the_smallest_maps(S):
+    """FireWall on maps whose ring is larger than their interior (4S-4 > (S-2)^2 for S <= 6): the ring pass of the dedicated
+    kernel and of the general kernel equal the oracle."""
+    from gym_novel_gridworlds_amd import apply_novelty, make_spec
+    for fast in ('1', '0'):
+        os_env = __import__('os').environ
+        old = os_env.get('NGW_FAST_RESET')
+        os_env['NGW_FAST_RESET'] = fast
+        try:
+            spec = make_spec(T.POGO, S)
+            spec.items_quantity = {} if S < 6 else ({'crafting_table': 1} if S < 7 else {'crafting_table': 1, 'tree_log': 1})
+            apply_novelty(spec, 'firewall', 'medium', '', '')
+            n = 500
+            v = VecNovelGridworld(spec=spec, num_envs=n, seed=8)
+            o = Oracle(spec.compile(), n, seed=8)
+            for ep in range(2):
+                v.reset(); assert o.reset() == 0
+                assert_state_equal(v, o, 'firewall S=%d fast=%s reset %d' % (S, fast, ep))
+            v.close()
+        finally:
+            if old is None:
+                del os_env['NGW_FAST_RESET']
+            else:
+                os_env['NGW_FAST_RESET'] = old
