@@ -271,11 +271,6 @@ int upload_reset_u(ngw_handle* h) {
     NgwResetU ru = {};
     ru.perm = h->b.perm; ru.map = h->b.map; ru.inv = h->b.inv; ru.n_pad = h->n_pad; ru.seed = p.seed;
     ru.S = p.S; ru.S2 = p.S2; ru.K = p.K; ru.CW = p.CW; ru.perm_lds = p.perm_lds; ru.magicS = p.magicS; ru.off_rng = h->off_rng;
-    {   // sparse subset passes (include/ngw.h, ngw_spec.n_passes): interior ordinal / (S-2), and the skip thresholds of the exact multiply-shift draw
-        const uint32_t IW = (uint32_t)(p.S - 2), nint = IW * IW, nring = (uint32_t)(4 * p.S - 4);
-        ru.magicIW22 = ((1u << 22) + IW - 1) / IW;
-        ru.thr_int = (uint32_t)(0u - nint) % nint; ru.thr_ring = (uint32_t)(0u - nring) % nring;
-    }
     const ngw_spec& s = h->spec;
     ru.wall_item = s.wall_item; ru.tap_item = s.tap_item; ru.tap_near = s.tap_near;
     int n_place = 0;
@@ -322,14 +317,19 @@ void layout_reset_fast(ngw_handle* h) {
     for (int j = 0; j < s.n_start; j++) n_place += s.start_qty[j];
     if (n_place > 12) return;                                                       // the kernel sorts the placed items in 12 registers
     const int nw = CW <= 2 ? 2 : (CW <= 8 ? 8 : 0);
-    const uint32_t MW = (uint32_t)((S2 + 31) / 32);                                 // words of a per-env bit column
+    int nb = 1;
+    while ((1 << nb) < S2) nb++;                                                    // bits of a cell index: bit_length(S2 - 1)
+    const uint32_t NBW = (uint32_t)((1 << nb) >> 5);                                // words of the per-env bit column the candidates index
+    const uint32_t tmpl_cells = (uint32_t)(S2 + 16);
     uint32_t off = 0;
     a.off_ring = off; off += 16 * NGW_EPB;
     a.off_masks = off; if (nw == 0) off += (uint32_t)(2 * CW * NGW_EPB);
     a.off_placed = off; off += 13 * NGW_EPB;                                        // 12 placed items + the sentinel
-    a.off_tmpl = off; off += (uint32_t)((S2 + 16 + NGW_MAX_PLACE + 3) / 4);
-    a.off_dom = off; if (subset) off += MW + 1;
-    a.off_mcol = off; if (subset) off += (MW + 1) * NGW_EPB;
+    a.off_tmpl = off; off += (tmpl_cells + NGW_MAX_PLACE + 3) / 4;
+    a.off_dom = off; if (subset) off += NBW;
+    a.off_mcol = off; if (subset) off += NBW * NGW_EPB;
+    off = (off + 3u) & ~3u;
+    a.off_tile = off; off += 144 * NGW_EPB / 4;                                     // staging tile of the composed rows: [64][128 + 16] bytes
     if ((size_t)off * 4 > 160 * 1024) return;
     h->rf_lds = (size_t)off * 4;
     h->rf_nw = nw; h->rf_additem = subset ? 1 : 0;
@@ -344,12 +344,15 @@ void layout_reset_fast(ngw_handle* h) {
         a.inv_start_items |= (uint32_t)s.inv_start_item[j] << (8 * j);
         a.inv_start_qtys |= (uint32_t)s.inv_start_qty[j] << (8 * j);
     }
-    const uint32_t W = (uint32_t)(S - 4), IW = (uint32_t)(S - 2);
+    const uint32_t W = (uint32_t)(S - 4);
     a.magicW = W ? (uint32_t)((0x100000000ull + W - 1) / W) : 0;
     a.magicS = (uint32_t)((0x100000000ull + (uint32_t)S - 1) / (uint32_t)S);
-    a.magicIW22 = ((1u << 22) + IW - 1) / IW;
-    const uint32_t nd = wall_pass ? (uint32_t)(4 * S - 4) : IW * IW;
-    a.sub_thr = (uint32_t)(0u - nd) % nd;
+    a.sub_nb = nb; a.sub_fields = 32 / nb;
+    {
+        const int tail = S2 % 128, ush = (S2 & 15) == 0 ? 4 : ((S2 & 3) == 0 ? 2 : 0);
+        const uint32_t nu = (uint32_t)((tail + (1 << ush) - 1) >> ush);
+        a.magic_tail = nu ? (uint32_t)((0x100000000ull + nu - 1) / nu) : 0;
+    }
 }
 
 // mode = NGW_MODE_RESET (mask_dev or nullptr) / NGW_MODE_REFILL; returns 1 if the dedicated kernel took the launch

@@ -125,8 +125,6 @@ struct NgwResetU {
     int32_t S, S2, K, CW, perm_lds;
     uint32_t magicS;
     uint32_t off_rng;     /* LDS dword offset of the Philox word ring [32][64] of the reset path */
-    uint32_t magicIW22;   /* ceil(2^22 / (S-2)): interior ordinal / (S-2) as a 24-bit multiply (sparse subset passes) */
-    uint32_t thr_int, thr_ring;   /* 2^32 mod (S-2)^2 and 2^32 mod (4S-4): words below are skipped by the exact multiply-shift draw */
     /* the bytes of ngw_spec the reset reads, packed (8 dwords): fetched together with the rest of this struct, so the
      * reset never waits on one more dependent load of the spec for each optional pass */
     uint8_t wall_item, tap_item, tap_near, n_place;
@@ -191,9 +189,10 @@ struct NgwResetFast {            // kernel arguments (by value)
     int32_t n_inv_start;
     uint32_t inv_start_items, inv_start_qtys;   // 4 bytes each
     uint32_t magicW;             // ceil(2^32 / (S-4))
-    uint32_t magicS, magicIW22;  // ceil(2^32 / S), ceil(2^22 / (S-2)): 24-bit multiply form for operands < 2^11
-    uint32_t sub_thr;            // 2^32 mod (cells of the pass domain): words below it are skipped (exact multiply-shift)
-    uint32_t off_ring, off_masks, off_placed, off_tmpl, off_dom, off_mcol;    // LDS dword offsets
+    uint32_t magicS;             // ceil(2^32 / S)
+    int32_t sub_nb, sub_fields;  // subset pass candidates: bits of a cell index (bit_length(S*S - 1)), fields per 32-bit word
+    uint32_t magic_tail;         // ceil(2^32 / store units of the last (short) 128-byte window of a row), 0 if S*S % 128 == 0
+    uint32_t off_ring, off_masks, off_placed, off_tmpl, off_dom, off_mcol, off_tile;    // LDS dword offsets
     uint64_t* stamps;            // diagnostics builds (-DNGW_STAMPS), or nullptr
 };
 #ifdef __cplusplus

@@ -207,49 +207,38 @@ struct ResetArgs {
     uint32_t magicS;                // ceil(2^32 / S): cell / S for cell < S*S
     uint32_t rs0, rs1, rs2, rs3;             // NgwResetU's packed spec bytes: wall|tap|tap_near|n_place, n_passes|n_inv_start, inv_start_item[4], inv_start_qty[4]
     uint32_t pw0, pw1, pw2, pw3;              // shuffled-subset passes: kind | item << 8 | from << 16 | span << 24
-    uint32_t magicIW22, thr_int, thr_ring;    // sparse subset passes: ceil(2^22 / (S-2)), 2^32 mod (S-2)^2, 2^32 mod (4S-4)
 };
 
 // The subset passes NGW_PASS_SPARSE names (include/ngw.h, ngw_spec.n_passes; oracle: subset_pass_sparse) on the lane's byte
-// map: AddItem / Crate over the air of the interior, ReplaceItem / FireWall over the wall of the ring.  No index array: the
-// percent first, then min(cnt, len - cnt) distinct matching cells by rejection - the complement when that is the smaller
-// set - candidates (word * ND) >> 32 from whole Philox blocks (next block boundary on; the rest of the last block is
-// dropped), a taken cell marked NGW_PASS_MARK until the closing sweep writes the items.  This is the cold form (resets
-// inside a step when no prepared episode exists, stacks of passes, the fused lidar path); ngw_reset.inc runs the same
-// draws on one bit per cell.
-template <bool RING, class RNG, typename MP>
-__device__ __forceinline__ void sparse_pass(RNG& px, MP mp, int S, int agent, int from, int item, int pct_span, const GLOBAL_AS double* pctq,
-                                            uint32_t magicIW22, uint32_t thr) {
-    const int IW = S - 2;
-    const uint32_t ND = RING ? (uint32_t)(4 * S - 4) : (uint32_t)(IW * IW);
-    auto cell_of = [&](uint32_t t) -> int {
-        if (RING) {                                                                // ring ordinal -> cell, row-major: row 0 | (r, 0), (r, S-1) | row S-1
-            const int u = (int)t - S, mid = 2 * (S - 2);
-            const int side = (1 + (u >> 1)) * S + ((u & 1) ? S - 1 : 0);
-            return (int)t < S ? (int)t : (u < mid ? side : (S - 1) * S + (u - mid));
-        }
-        const uint32_t tr = __umul24(t, magicIW22) >> 22;                          // t / (S-2)
-        return (int)(t + 2u * tr) + S + 1;
-    };
+// map: AddItem / Crate over the air cells, ReplaceItem / FireWall over the wall cells.  No index array: the percent first,
+// then min(cnt, len - cnt) distinct matching cells by rejection - the complement when that is the smaller set - candidates
+// = nb-bit cell indices cut from whole Philox blocks (field j of words 0..3, then field j + 1; next block boundary on; the
+// rest of the last block is dropped), a taken cell marked NGW_PASS_MARK until the closing sweep writes the items.  This is
+// the cold form (resets inside a step when no prepared episode exists, stacks of passes, the fused lidar path);
+// ngw_reset.inc runs the same draws on one bit per cell.
+template <class RNG, typename MP>
+__device__ __forceinline__ void sparse_pass(RNG& px, MP mp, int S2, int agent, int from, int item, int pct_span, const GLOBAL_AS double* pctq) {
     int len = 0;
-    for (uint32_t t = 0; t < ND; t++) len += mp[cell_of(t)] == from;
+    for (int i = 0; i < S2; i++) len += mp[i] == from;
     const int pct = (int)bounded(px, (uint32_t)(pct_span - 1));                    // randint(lo, hi) FIRST; a span of 1 draws nothing
     const int cnt = (int)ceil((double)len * pctq[pct]);                            // int(np.ceil(len * (pct / 100)))
     const bool comp = 2 * cnt > len;
     const int need = comp ? len - cnt : cnt;
     px.align();
+    const int nb = 32 - __clz(S2 - 1), F = 32 / nb;                                // (uniform)
+    const uint32_t fm = (1u << nb) - 1u;
     for (int got = 0; got < need;) {
         uint32_t w[4];
         px.block(w[0], w[1], w[2], w[3]);
+        for (int j = 0; j < F; j++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint64_t m = (uint64_t)w[k] * ND;
-            const int cell = cell_of((uint32_t)(m >> 32));
-            if (got < need && (uint32_t)m >= thr && mp[cell] == from) { mp[cell] = (int8_t)NGW_PASS_MARK; got++; }
-        }
+            for (int k = 0; k < 4; k++) {
+                const int cell = (int)((w[k] >> (j * nb)) & fm);
+                if (got < need && cell < S2 && mp[cell] == from) { mp[cell] = (int8_t)NGW_PASS_MARK; got++; }
+            }
     }
-    for (uint32_t t = 0; t < ND; t++) {
-        const int cell = cell_of(t), v = mp[cell];
+    for (int cell = 0; cell < S2; cell++) {
+        const int v = mp[cell];
         const bool marked = v == NGW_PASS_MARK;
         if (marked || v == from) mp[cell] = (int8_t)((marked != comp && cell != agent) ? item : from);   // chosen = marked (direct) / unmarked (complement)
     }
@@ -392,10 +381,10 @@ __device__ __forceinline__ uint32_t reset_lane(const ResetArgs a, MP mp, LDS_AS 
             const uint32_t w = j == 0 ? a.pw0 : (j == 1 ? a.pw1 : (j == 2 ? a.pw2 : a.pw3));
             const int kind = w & 255, item = (w >> 8) & 255, from = (w >> 16) & 255, span = w >> 24;
             const GLOBAL_AS double* pctq = (const GLOBAL_AS double*)a.dspec->pctq[j];
-            if (kind == NGW_PASS_ADDITEM)                                          // AddItem / Crate: the air of the interior
-                sparse_pass<false>(px, mp, S, agent, 0, item, span, pctq, a.magicIW22, a.thr_int);
+            if (kind == NGW_PASS_ADDITEM)                                          // AddItem / Crate: air cells
+                sparse_pass(px, mp, a.S2, agent, 0, item, span, pctq);
             else if (kind == NGW_PASS_REPLACE && from == wall_item)                // ReplaceItem / FireWall of the wall ring
-                sparse_pass<true>(px, mp, S, agent, from, item, span, pctq, a.magicIW22, a.thr_ring);
+                sparse_pass(px, mp, a.S2, agent, from, item, span, pctq);
             else if (kind == NGW_PASS_REPLACE)                                     // ReplaceItem of an item of the interior
                 run_pass<NGW_PASS_REPLACE>(a, j, perm_lds, env_local, px, mp, agent, from, item, span);
             else                                                                   // Fence / FenceRestriction
@@ -481,8 +470,7 @@ __device__ __noinline__ uint32_t new_episode(const NgwDevSpec* dspec, LDS_AS int
                                 env_local, ru.S2, ru.K) | NGW_F_ROWS_STORED;
         if (count_miss) atomicAdd(nx.slow, 1u);                                    // a stale row inside a step: the host shortens the refill cadence
     }
-    const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS, rs0, rs1, rs2, rs3, pw0, pw1, pw2, pw3,
-                         rp->magicIW22, rp->thr_int, rp->thr_ring};
+    const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS, rs0, rs1, rs2, rs3, pw0, pw1, pw2, pw3};
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_base[];            // the kernel's dynamic LDS (offset 0)
     if (ru.off_rng != 0xFFFFFFFFu)                                                 // which word source: decided with the LDS layout (ngw_abi.cpp)
         return reset_lane<PhiloxRing>(a, mp, inv, cand, place_seq, perm_lds, (LDS_AS uint32_t*)(lds_base + ru.off_rng + threadIdx.x),

@@ -145,11 +145,12 @@ typedef struct ngw_spec {
      * wall of the ring (NGW_PASS_SPARSE) never build the index array.  The result of shuffle + "first cnt" is a uniformly
      * random cnt-subset of the matching cells - the order inside it is irrelevant, every chosen cell gets the same item -
      * and that is what is sampled: percent first (the numpy bounded draw, as before), cnt = ceil(len * pct / 100), then
-     * min(cnt, len - cnt) distinct matching cells by rejection (the complement when that is the smaller set), each
-     * candidate = (word * ND) >> 32 over the ND cells of the domain (interior row-major / ring row-major; exact: a word whose
-     * low product is below 2^32 mod ND is skipped), words taken in whole Philox blocks starting at the next block
-     * boundary, the rest of the last block discarded.  Same distribution of maps as the reference's, pinned by the
-     * distribution fixtures tests/golden/g6_*.npz; every other pass keeps shuffle-then-prefix. */
+     * min(cnt, len - cnt) distinct matching cells by rejection (the complement when that is the smaller set).  A candidate
+     * is a cell index of nb = bit_length(S*S - 1) bits: field j of word k of a Philox block (32 / nb fields per word, from
+     * the low end), taken in the order j = 0: words 0..3, j = 1: words 0..3, ...; blocks start at the next block boundary
+     * and the rest of the last one is discarded; a candidate beyond the map, not matching or already taken is skipped.
+     * Same distribution of maps as the reference's, pinned by the distribution fixtures tests/golden/g6_*.npz; every other
+     * pass keeps shuffle-then-prefix. */
     uint8_t n_passes;
     uint8_t pass_kind[NGW_MAX_PASSES], pass_item[NGW_MAX_PASSES], pass_from[NGW_MAX_PASSES];
     uint8_t pass_pct_lo[NGW_MAX_PASSES], pass_pct_hi[NGW_MAX_PASSES];

@@ -118,50 +118,42 @@ static const int TURN_LEFT[4] = {2, 3, 1, 0}, TURN_RIGHT[4] = {3, 2, 0, 1}; /* (
 /* Philox mode of the passes NGW_PASS_SPARSE names (include/ngw.h, ngw_spec.n_passes): what np.random.shuffle + "the first
  * cnt" amounts to is a uniformly random cnt-subset of the matching cells (every chosen cell gets the same item, so the order
  * inside the subset never shows).  The device samples exactly that and this is its restatement, step for step:
- *   domain  : from == 0 -> the (S-2)^2 interior cells, row-major; from == wall -> the 4S-4 ring cells, row-major
- *   len     : matching cells of the domain;  pct: the numpy bounded draw (a span of 1 draws nothing);  cnt = ceil(len * pct / 100)
+ *   len     : cells with map == from (np.where over the whole map);  pct: the numpy bounded draw (a span of 1 draws nothing);
+ *             cnt = ceil(len * pct / 100)
  *   draw    : min(cnt, len - cnt) distinct matching cells - the complement when that is the smaller set - by rejection:
- *             words come in whole Philox blocks from the next block boundary on, candidate t = (word * ND) >> 32 (a word
- *             whose low product is < 2^32 mod ND is skipped: exact uniformity), a cell already taken or not matching is
- *             skipped; what is left of the last block is discarded
+ *             words come in whole Philox blocks from the next block boundary on; a candidate is a CELL INDEX of
+ *             nb = bit_length(S*S - 1) bits, field j of word k of the block (fields from the low end, 32 / nb of them per word),
+ *             in the order j = 0: words 0..3, j = 1: words 0..3, ...; a candidate beyond the map, not matching or already
+ *             taken is skipped; what is left of the last block is discarded
  *   edit    : as the reference - the chosen cells get `item`, never the agent's cell (:1026 / :1142)
  * The MT mode keeps the numpy call sequence and stays pinned to the reference; the distribution of THIS mode is pinned by
  * the G6 fixtures (tests/golden/g6_*.npz: per-cell frequencies and count histograms of 10 000 reference resets). */
-static int sparse_cell(int S, int ring, uint32_t t) {
-    const int IW = S - 2;
-    if (!ring) return (1 + (int)t / IW) * S + 1 + (int)t % IW;
-    if ((int)t < S) return (int)t;
-    const int u = (int)t - S, mid = 2 * (S - 2);
-    if (u < mid) return (1 + (u >> 1)) * S + ((u & 1) ? S - 1 : 0);
-    return (S - 1) * S + (u - mid);
-}
-
 static void subset_pass_sparse(const ngw_spec* sp, ngwo_rng* rng, int8_t* map, int agent, int item, int from, int pct_lo, int pct_hi) {
-    const int S = sp->map_size, ring = from != 0;
-    const uint32_t ND = ring ? (uint32_t)(4 * S - 4) : (uint32_t)((S - 2) * (S - 2));
+    const int S = sp->map_size, S2 = S * S;
     int len = 0;
-    for (uint32_t t = 0; t < ND; t++) len += map[sparse_cell(S, ring, t)] == from;
+    for (int i = 0; i < S2; i++) len += map[i] == from;
     const int pct = pct_lo + (int)rng_bounded(rng, (uint32_t)(pct_hi - pct_lo - 1));
     const int cnt = (int)ceil((double)len * ((double)pct / 100.0));
     const int comp = 2 * cnt > len, need = comp ? len - cnt : cnt;
     ngwo_philox* px = rng->px;
     px->have = 0;                                                 /* next block boundary */
-    const uint32_t thr = (uint32_t)(0u - ND) % ND;                /* 2^32 mod ND */
+    int nb = 1;
+    while ((1 << nb) < S2) nb++;                                  /* bit_length(S2 - 1) */
+    const int F = 32 / nb;
+    const uint32_t fm = (1u << nb) - 1u;
     for (int got = 0; got < need;) {
         uint32_t w[4];
         philox4x32_10(px->ctr, px->key, w);
         px->ctr[0]++;
-        for (int k = 0; k < 4 && got < need; k++) {
-            const uint64_t m = (uint64_t)w[k] * ND;
-            if ((uint32_t)m < thr) continue;
-            const int cell = sparse_cell(S, ring, (uint32_t)(m >> 32));
-            if (map[cell] != from) continue;
-            map[cell] = NGW_PASS_MARK;
-            got++;
-        }
+        for (int j = 0; j < F; j++)
+            for (int k = 0; k < 4 && got < need; k++) {
+                const int cell = (int)((w[k] >> (j * nb)) & fm);
+                if (cell >= S2 || map[cell] != from) continue;
+                map[cell] = NGW_PASS_MARK;
+                got++;
+            }
     }
-    for (uint32_t t = 0; t < ND; t++) {
-        const int cell = sparse_cell(S, ring, t);
+    for (int cell = 0; cell < S2; cell++) {
         const int marked = map[cell] == NGW_PASS_MARK;
         if (!marked && map[cell] != from) continue;
         map[cell] = (int8_t)((marked != comp && cell != agent) ? item : from);   /* chosen = marked (direct) / unmarked (complement) */

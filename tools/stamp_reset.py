@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from gym_novel_gridworlds_amd import VecNovelGridworld, _cabi, apply_novelty, make_spec
-NAMES = ['entry', 'template + rows out', 'placement done', 'items out', 'shuffle array built', 'shuffle done', 'AddItem cells out', 'stores acked']
+NAMES = ['entry', 'LDS template + inventory rows', 'placement done', 'placed sorted, percent drawn', 'subset drawn', 'bit column final', 'map composed + stored', 'stores acked']
 L = _cabi.lib()
 L.ngw_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
 for wl in (sys.argv[1:] or ['C2', 'C5']):
@@ -23,10 +23,11 @@ for wl in (sys.argv[1:] or ['C2', 'C5']):
     rt, cy = st[:, :8].astype(np.float64), st[:, 8:].astype(np.float64)
     t0 = rt[:, 0].min()
     print('== %s: %d waves' % (wl, grid))
-    for i, nm in enumerate(NAMES):
+    have = [i for i in range(8) if rt[:, i].max() > 0]            # (plain configurations have no subset stamps)
+    for i in have:
         x = (rt[:, i] - t0) * 0.01
-        print('%-22s min %9.2f  median %9.2f  max %9.2f us' % (nm, x.min(), np.median(x), x.max()))
-    for i in range(1, 8):
-        d = cy[:, i] - cy[:, i - 1]
-        print('  %-22s -> %-22s %10.0f cycles (median)' % (NAMES[i - 1], NAMES[i], np.median(d)))
+        print('%-32s min %9.2f  median %9.2f  max %9.2f us' % (NAMES[i], x.min(), np.median(x), x.max()))
+    for i0, i1 in zip(have[:-1], have[1:]):
+        d = cy[:, i1] - cy[:, i0]
+        print('  %-32s -> %-32s %10.0f cycles (median)' % (NAMES[i0], NAMES[i1], np.median(d)))
     v.close()
