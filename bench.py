@@ -150,6 +150,9 @@ def main():
     ap.add_argument('--envs', type=int, default=0, help='envs per GPU (default: the workload\'s)')
     ap.add_argument('--launch', default='graph', choices=['graph', 'eager'],
                     help='step mode: replay the K step launches from one hipGraph (default from 100 steps on) or launch them one by one')
+    ap.add_argument('--adapt-steps', type=int, default=-1,
+                    help='untimed eager steps before everything else, so that the handle has adapted its prepared-episode depth / refill '
+                         'cadence to the workload before the graph is captured (default: 3000 for the high-churn tuning cases X*, else 0)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stagger', action='store_true', help='skip the staggered-episode-ends side measurement')
     ap.add_argument('--no-side', action='store_true', help='skip every side measurement (fused rollout, API mode, C1, stagger): tuning runs')
@@ -206,6 +209,19 @@ def main():
     def episode0():
         return int(v.get_state(0, 1)['episode'][0])
 
+    adapt_steps = args.adapt_steps if args.adapt_steps >= 0 else (3000 if args.workload.startswith('X') else 0)
+    if adapt_steps and args.mode == 'step':
+        # a live loop adapts by itself (ngw_abi.cpp adapt_cadence: deeper prepared episodes, then more frequent refills, when envs end
+        # episodes faster than refills come round); the timed region below is a captured graph, so the handle settles first
+        g0 = torch.Generator(device='cuda')
+        g0.manual_seed(ACTION_SEED + 7919 + rank)
+        acts0 = torch.randint(0, A, (100, n), dtype=torch.int32, device='cuda', generator=g0)
+        torch.cuda.synchronize()
+        v.reset()
+        for _ in range((adapt_steps + 99) // 100):
+            v.step_device_many(acts0.data_ptr(), n, 100)
+            v.sync()                                       # (the host reads the refills' reports between calls)
+        del acts0
     start_episodes()
     GRAPH_MAX = 2048                      # kernel nodes per graph; longer runs replay it (its action rows repeat)
     # ONE graph launch enqueues the whole region (15 us of host time for 20 launches; an eager launch costs ~3.3 us of host time),
@@ -428,7 +444,8 @@ def main():
         total = n * world * steps
         line = {
             'metric': 'env-steps/sec', 'value': round(total / dt, 1), 'unit': 'env-steps/s', 'n_gpus': world,
-            'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 6), 'higher_is_better': True,
+            'steps': steps, 'warmup': warmup, 'adapt_steps': adapt_steps if args.mode == 'step' else 0,
+            'prepared_episodes': {'refill_every': v.refill_cadence, 'depth': v.reset_prefetch_depth}, 'ms_per_step': round(dt / steps * 1e3, 6), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8/int32', 'data': 'synthetic',
             'config': {'workload': desc, 'name': args.workload, 'envs_per_gpu': n, 'global_envs': n * world,
                        'map_size': S, 'n_items': K, 'n_actions': A, 'horizon': HORIZON, 'autoreset': 'same-step',

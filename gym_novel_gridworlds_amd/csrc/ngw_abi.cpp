@@ -65,6 +65,7 @@ struct ngw_handle {
     int hostres = 0;
     uint32_t step_seq = 0, launch_seq = 0;   // hostres: sequence number the next step launch reports (launch_seq: only while ngw_step_host issues it)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing pair
+    hipEvent_t order_ev = nullptr;             // ngw_stream_order
     bool ev_marked = false;                    // ngw_timing_mark recorded the closing event already
     // LidarInFront observation
     NgwLidarDev* lidar_cfg = nullptr;     // device tables
@@ -82,7 +83,9 @@ struct ngw_handle {
     int cadence = 0, quiet = 0, noisy = 0, adapt = 1;
     uint32_t slow_seen = 0, refill_seen = 0, refill_count = 0;   // reports read / refill launches issued
     bool capturing = false;
+    bool adapted = false;                 // adapt_cadence changed depth or cadence: a captured graph is stale (ngw_graph_launch re-captures it)
     int prefetch_user = 0;                // the caller chose the cadence (ngw_set_reset_prefetch): ngw_set_autoreset leaves it alone
+    int depth = 1, depth_user = 0;        // prepared episodes per env (power of two); depth_user: chosen through ngw_set_reset_prefetch_depth
     int32_t* row_reward = nullptr;        // fused rollouts: the caller's output rows (ngw_rollout_outputs)
     uint8_t* row_done = nullptr;
     int64_t row_stride = 0;
@@ -103,6 +106,8 @@ struct ngw_handle {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_steps = 0;
+    const int32_t* graph_actions = nullptr;   // what ngw_graph_build captured: an adaptation re-captures it
+    int64_t graph_stride = 0;
 };
 
 namespace {
@@ -162,6 +167,7 @@ int check_spec(const ngw_spec* s) {
         const int kind = s->pass_kind[j];
         if (kind < NGW_PASS_ADDITEM || kind > NGW_PASS_FENCE) return fail(NGW_E_INVALID_ARG, "reset pass %d has unknown kind %d", j, kind);
         if (!item_ok(s->pass_item[j]) || !s->pass_item[j] || !item_ok(s->pass_from[j])) return fail(NGW_E_INVALID_ARG, "reset pass %d: item id out of range", j);
+        if (kind == NGW_PASS_REPLACE && s->pass_item[j] == s->pass_from[j]) return fail(NGW_E_INVALID_ARG, "reset pass %d replaces an item with itself (the reference asserts a NEW item, novelty_wrappers.py:1108)", j);
         if (!pct_ok(s->pass_pct_lo[j], s->pass_pct_hi[j]))
             return fail(NGW_E_INVALID_ARG, "%s percent range invalid", kind == NGW_PASS_ADDITEM ? "additem" : kind == NGW_PASS_REPLACE ? "replace" : "fence");
         if (kind == NGW_PASS_FENCE)     /* a fence pass after a wall-replacing pass would fence border cells: add_fence_around leaves the map (reference: IndexError) */
@@ -361,37 +367,96 @@ int launch_reset_fast(ngw_handle* h, int mode, const uint8_t* mask_dev, bool* ta
     if (h->rf_nw < 0 || h->lidar_fused) return NGW_OK;
     NgwResetFast a = h->rf;
     a.main = h->b; a.nx = h->prefetch_every > 0 ? h->nx : NgwNx{}; a.mode = mode; a.reset_mask = mask_dev; a.stamps = h->proto.stamps;
-    a.refill_seq = h->refill_count;
     HIP_TRY(ngw_reset_fast_launch(h->dspec, &a, h->rf_nw, h->rf_additem, (unsigned)(h->n_pad / NGW_EPB), h->rf_lds, h->stream));
     *taken = true;
     return NGW_OK;
 }
 
-// Prepared next episodes: one launch re-prepares the shadow rows that resets have consumed since the last one.
+void layout_reset_fast_nx(ngw_handle* h);
+
+// (Re)allocates the shadow buffers `depth` deep and publishes them to the kernels; every tag starts at 0 = nothing prepared.
+// Synchronises the stream: called when prepared episodes are switched on and - rarely - when the depth grows.
+int alloc_nx(ngw_handle* h, int depth) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    void* const old[6] = {h->nx.map, h->nx.loc, h->nx.facing, h->nx.inv, h->nx.episode, h->nx.slow};
+    uint32_t* const slow_host = h->nx.slow_host;
+    h->nx = NgwNx{};
+    for (void* q : old) if (q) dev_free(h, q);
+    const size_t np = (size_t)h->n_pad * (size_t)depth, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
+    int rc = dev_alloc(h, &h->nx.map, np * S2);
+    if (!rc) rc = dev_alloc(h, &h->nx.loc, np * 2);
+    if (!rc) rc = dev_alloc(h, &h->nx.facing, np);
+    if (!rc) rc = dev_alloc(h, &h->nx.inv, np * K);
+    if (!rc) rc = dev_alloc(h, &h->nx.episode, np);
+    if (!rc) rc = dev_alloc(h, &h->nx.slow, 16);
+    if (rc) { h->nx = NgwNx{}; return rc; }
+    h->nx.slow_host = slow_host;
+    if (!h->nx.slow_host) {
+        void* q = nullptr;
+        if (hipHostMalloc(&q, 64, hipHostMallocMapped) == hipSuccess) {           // (without it the cadence simply stays fixed)
+            memset(q, 0, 64);
+            h->host_allocs.push_back(q);
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, q, 0) == hipSuccess && d == q) h->nx.slow_host = static_cast<uint32_t*>(q);
+        }
+    }
+    if (h->nx.slow_host) { h->nx.slow_host[0] = 0; h->nx.slow_host[1] = 0; }
+    h->slow_seen = 0; h->refill_seen = 0;
+    h->nx.stride = h->n_pad; h->nx.dmask = depth - 1;
+    h->depth = depth;
+    return NGW_OK;
+}
+
+int publish_nx(ngw_handle* h, bool on) {
+    const NgwNx on_device = on ? h->nx : NgwNx{};                                  // null pointers switch the consume path off
+    HIP_TRY(hipMemcpyAsync(&h->dspec->nx, &on_device, sizeof(NgwNx), hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NGW_OK;
+}
+
+// Prepared next episodes: one refill re-prepares the shadow rows that resets have consumed since the last one.  Under the
+// DEFAULT setting the host adapts to how fast episodes end: a reset that finds no prepared row runs the placement loop inside
+// a step and the whole launch waits for it, so those resets are counted on the device and reported by every refill.  Too
+// many of them per refill - more than one step in eight of the window would be slow - and the prepared episodes first get
+// DEEPER (2, then 4 per env: an env may then end that many episodes between two refills), then refills get more frequent;
+// four quiet refills in a row make them less frequent again.  Results never depend on any of it.
 void adapt_cadence(ngw_handle* h) {
     if (h->capturing || h->prefetch_user || !h->adapt || !h->nx.slow_host) return;
     // what the last refill launch THE GPU HAS RUN reported: its number and the count of stale-row resets so far.  The host may be
     // many launches ahead of the device (an eager loop without synchronisation): no new report = no information, and one
-    // report may stand for several refills.
+    // report may stand for several refills.  (A replayed graph repeats the number it was captured with: not newer = no report.)
     const uint32_t seq = ((volatile uint32_t*)h->nx.slow_host)[1], cur = ((volatile uint32_t*)h->nx.slow_host)[0];
-    const uint32_t refills = seq - h->refill_seen;
-    if (!refills) return;
+    const int32_t refills = (int32_t)(seq - h->refill_seen);
+    if (refills <= 0) return;
     h->refill_seen = seq;
     const uint32_t delta = cur - h->slow_seen;
     h->slow_seen = cur;
-    const uint32_t many = h->n >= 512 ? (uint32_t)(h->n / 256) : 2u;
-    if (delta / refills >= many) {                                  // two noisy refills in a row: a one-off burst (stale tags after
+    const uint32_t many = (uint32_t)(h->cadence / 8 > 2 ? h->cadence / 8 : 2);
+    if (delta / (uint32_t)refills >= many) {                        // two noisy refills in a row: a one-off burst (stale tags after
         h->quiet = 0;                                               // ngw_set_state, the first steps of a handle) does not count
-        h->noisy += (int)refills;
-        if (h->noisy >= 2) { h->cadence = h->cadence / 2 < 2 ? 2 : h->cadence / 2; h->noisy = 0; }
+        h->noisy += refills;
+        if (h->noisy >= 2) {
+            h->noisy = 0;
+            if (h->depth < 4 && !h->depth_user) {                    // deeper first
+                const int every = h->prefetch_every;
+                if (alloc_nx(h, h->depth * 2) == NGW_OK && publish_nx(h, true) == NGW_OK) {
+                    layout_reset_fast_nx(h);
+                    h->since_refill = every;                        // (every row is stale now: refill at once)
+                }
+            } else h->cadence = h->cadence / 2 < 2 ? 2 : h->cadence / 2;
+            h->adapted = true;
+        }
     } else {
         h->noisy = 0;
-        if (h->cadence < h->prefetch_every && (h->quiet += (int)refills) >= 4) {
+        if (h->cadence < h->prefetch_every && (h->quiet += refills) >= 4) {
             h->cadence = h->cadence * 2 > h->prefetch_every ? h->prefetch_every : h->cadence * 2;
             h->quiet = 0;
+            h->adapted = true;
         }
     }
 }
+
+void layout_reset_fast_nx(ngw_handle* h) { h->rf.nx = h->nx; }
 
 int launch_refill(ngw_handle* h) {
     h->since_refill = 0;
@@ -400,14 +465,20 @@ int launch_refill(ngw_handle* h) {
     bool taken = false;
     if (int rc = launch_reset_fast(h, NGW_MODE_REFILL, nullptr, &taken)) return rc;
     if (taken) return NGW_OK;
-    NgwLaunch rf = h->proto;
-    rf.b = NgwBufs{};
-    rf.b.map = h->nx.map; rf.b.loc = h->nx.loc; rf.b.facing = h->nx.facing; rf.b.inv = h->nx.inv; rf.b.episode = h->nx.episode;
-    rf.b.flags = h->b.flags; rf.b.perm = h->b.perm;
-    rf.mode = NGW_MODE_REFILL; rf.n_steps = 1;
-    rf.actions = reinterpret_cast<const int32_t*>(h->b.episode);
-    rf.reset_mask = nullptr; rf.autoreset = 0; rf.horizon = 0; rf.action_seed = 0; rf.t0 = (int64_t)h->refill_count;   // (REFILL: t0 = the refill's number)
-    HIP_TRY(ngw_launch(h->dspec, &rf, h->map_mode, 0, (unsigned)(h->n_pad / NGW_EPB), h->lds_bytes, h->stream));
+    // the general kernel prepares one slot per launch (its shadow set is the launch's buffer set)
+    const size_t np = (size_t)h->n_pad, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
+    for (int slot = 0; slot < h->depth; slot++) {
+        NgwLaunch rf = h->proto;
+        rf.b = NgwBufs{};
+        rf.b.map = h->nx.map + slot * np * S2; rf.b.loc = h->nx.loc + slot * np * 2; rf.b.facing = h->nx.facing + slot * np;
+        rf.b.inv = h->nx.inv + slot * np * K; rf.b.episode = h->nx.episode + slot * np;
+        rf.b.flags = h->b.flags; rf.b.perm = h->b.perm;
+        rf.mode = NGW_MODE_REFILL; rf.n_steps = 1;
+        rf.actions = reinterpret_cast<const int32_t*>(h->b.episode);
+        rf.reset_mask = nullptr; rf.action_seed = 0; rf.t0 = (int64_t)h->refill_count;   // (REFILL: t0 = the refill's number)
+        rf.autoreset = slot; rf.horizon = h->depth - 1;                                    // (REFILL: the slot and depth - 1)
+        HIP_TRY(ngw_launch(h->dspec, &rf, h->map_mode, 0, (unsigned)(h->n_pad / NGW_EPB), h->lds_bytes, h->stream));
+    }
     return NGW_OK;
 }
 
@@ -707,6 +778,7 @@ int ngw_destroy(ngw_handle* h) {
     if (h->act_pin) ngw_host_free(h->act_pin);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->order_ev) (void)hipEventDestroy(h->order_ev);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return NGW_OK;
@@ -743,32 +815,38 @@ int ngw_set_reset_prefetch(ngw_handle* h, int32_t every_n_steps) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     drop_graph(h);                                   // captured launches bake the cadence in
-    if (every_n_steps > 0 && !h->nx.episode) {
-        const size_t np = (size_t)h->n_pad, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
-        int rc = dev_alloc(h, &h->nx.map, np * S2);
-        if (!rc) rc = dev_alloc(h, &h->nx.loc, np * 2);
-        if (!rc) rc = dev_alloc(h, &h->nx.facing, np);
-        if (!rc) rc = dev_alloc(h, &h->nx.inv, np * K);
-        if (!rc) rc = dev_alloc(h, &h->nx.episode, np);
-        if (!rc) rc = dev_alloc(h, &h->nx.slow, 16);
-        if (!rc) {
-            void* q = nullptr;
-            if (hipHostMalloc(&q, 64, hipHostMallocMapped) == hipSuccess) {       // (without it the cadence simply stays fixed)
-                memset(q, 0, 64);
-                h->host_allocs.push_back(q);
-                void* d = nullptr;
-                if (hipHostGetDevicePointer(&d, q, 0) == hipSuccess && d == q) h->nx.slow_host = static_cast<uint32_t*>(q);
-            }
-        }
-        if (rc) { h->nx = NgwNx{}; return rc; }
-    }
-    const NgwNx on_device = every_n_steps > 0 ? h->nx : NgwNx{};      // null pointers switch the consume path off
-    HIP_TRY(hipMemcpyAsync(&h->dspec->nx, &on_device, sizeof(NgwNx), hipMemcpyDefault, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (every_n_steps > 0 && !h->nx.episode) { if (int rc = alloc_nx(h, h->depth)) return rc; }
+    if (int rc = publish_nx(h, every_n_steps > 0)) return rc;
+    layout_reset_fast_nx(h);
     h->prefetch_every = every_n_steps;
     h->cadence = every_n_steps; h->quiet = 0; h->noisy = 0;
     h->prefetch_user = 1;
     h->since_refill = every_n_steps;                 // the next launch is followed by a refill
+    return NGW_OK;
+}
+
+int ngw_set_reset_prefetch_depth(ngw_handle* h, int32_t depth) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (depth != 0 && depth != 1 && depth != 2 && depth != 4 && depth != 8) return fail(NGW_E_INVALID_ARG, "depth must be 0 (automatic), 1, 2, 4 or 8");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    drop_graph(h);                                   // captured launches bake the shadow pointers in
+    h->depth_user = depth != 0;
+    const int want = depth ? depth : 1;
+    if (want != h->depth) {
+        if (h->nx.episode) {
+            if (int rc = alloc_nx(h, want)) return rc;
+            if (int rc = publish_nx(h, h->prefetch_every > 0)) return rc;
+            layout_reset_fast_nx(h);
+            h->since_refill = h->prefetch_every;     // every row is stale: the next launch is followed by a refill
+        } else h->depth = want;
+    }
+    return NGW_OK;
+}
+
+int ngw_get_reset_prefetch_depth(ngw_handle* h, int32_t* depth) {
+    if (!h || !depth) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    *depth = h->depth;
     return NGW_OK;
 }
 
@@ -784,6 +862,17 @@ int ngw_set_stream(ngw_handle* h, void* hip_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->own_stream = true;
     }
+    return NGW_OK;
+}
+
+int ngw_stream_order(ngw_handle* h, void* other_stream, int handle_waits) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t other = static_cast<hipStream_t>(other_stream);
+    if (other == h->stream) return NGW_OK;                          // one stream: already in order
+    if (!h->order_ev) HIP_TRY(hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->order_ev, handle_waits ? other : h->stream));
+    HIP_TRY(hipStreamWaitEvent(handle_waits ? h->stream : other, h->order_ev, 0));
     return NGW_OK;
 }
 
@@ -1043,7 +1132,11 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
             bool seen = false;
             for (uint32_t spin = 0; spin < (1u << 21); spin++) {
                 if (*sp == h->step_seq) { seen = true; break; }
+#if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
+#else
+                __asm__ __volatile__("" ::: "memory");
+#endif
             }
             if (!seen) HIP_TRY(hipStreamSynchronize(h->stream));
             __atomic_thread_fence(__ATOMIC_ACQUIRE);                                // the state reads below stay behind the poll
@@ -1159,20 +1252,25 @@ int ngw_pack_obs(ngw_handle* h, void* payload_dev) {
 int ngw_unpack_obs(ngw_handle* h, const void* payloads_dev, int32_t world, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv,
                    int32_t* reward, uint8_t* done, uint32_t* info) {
     if (!h || !payloads_dev) return fail(NGW_E_INVALID_ARG, "NULL argument");
-    if (world < 1 || world * 7 > NGW_PACK_MAX) return fail(NGW_E_INVALID_ARG, "world %d outside [1, %d]", world, NGW_PACK_MAX / 7);
+    if (world < 1) return fail(NGW_E_INVALID_ARG, "world %d must be >= 1", world);
     HIP_TRY(hipSetDevice(h->device));
     PackSection sec[7]; uint64_t offs[8];
     pack_sections(h, sec, offs);
     uint8_t* const dsts[7] = {reinterpret_cast<uint8_t*>(map), reinterpret_cast<uint8_t*>(loc), reinterpret_cast<uint8_t*>(facing),
                               reinterpret_cast<uint8_t*>(inv), reinterpret_cast<uint8_t*>(reward), done, reinterpret_cast<uint8_t*>(info)};
+    // one launch moves up to NGW_PACK_MAX regions = 9 ranks' payloads; bigger worlds (several nodes) take more launches
     NgwPack p = {};
-    for (int r = 0; r < world; r++)
+    for (int r = 0; r < world; r++) {
         for (int i = 0; i < 7; i++) {
             if (!dsts[i]) continue;
             p.src[p.n_regions] = static_cast<const uint8_t*>(payloads_dev) + (uint64_t)r * offs[7] + offs[i];
             p.dst[p.n_regions] = dsts[i] + (uint64_t)r * sec[i].bytes; p.nbytes[p.n_regions] = sec[i].bytes; p.n_regions++;
         }
-    HIP_TRY(ngw_pack_launch(&p, h->stream));
+        if (p.n_regions + 7 > NGW_PACK_MAX || r == world - 1) {
+            HIP_TRY(ngw_pack_launch(&p, h->stream));
+            p = NgwPack{};
+        }
+    }
     return NGW_OK;
 }
 
@@ -1463,15 +1561,12 @@ int ngw_timing_end(ngw_handle* h, double* elapsed_ms) {
     return NGW_OK;
 }
 
-int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps) {
-    if (!h || !actions_dev) return fail(NGW_E_INVALID_ARG, "NULL argument");
-    if (n_steps < 1) return fail(NGW_E_INVALID_ARG, "n_steps must be >= 1");
-    HIP_TRY(hipSetDevice(h->device));
+static int capture_graph(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     drop_graph(h);
     h->since_refill = 0;                              // the captured refill cadence starts from a known phase
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    h->capturing = true;                              // (the cadence the handle has adapted to so far is the one captured)
+    h->capturing = true;                              // (the depth and cadence the handle has adapted to so far are the ones captured)
     int rc = NGW_OK;
     for (int i = 0; i < n_steps && !rc; i++) rc = launch(h, NGW_MODE_STEP, 1, actions_dev + (int64_t)i * step_stride, nullptr, 0, 0);
     // every replay must leave the refill cadence where it found it: a graph shorter than (or not a multiple of) the cadence
@@ -1488,15 +1583,33 @@ int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stri
     if (e != hipSuccess) { drop_graph(h); return fail(NGW_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
     (void)hipGraphUpload(h->graph_exec, h->stream);   // pre-stage the graph so the first replay does not pay for it
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->graph_steps = n_steps;
+    h->graph_steps = n_steps; h->graph_actions = actions_dev; h->graph_stride = step_stride;
+    h->adapted = false;
     return NGW_OK;
+}
+
+int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps) {
+    if (!h || !actions_dev) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    if (n_steps < 1) return fail(NGW_E_INVALID_ARG, "n_steps must be >= 1");
+    HIP_TRY(hipSetDevice(h->device));
+    return capture_graph(h, actions_dev, step_stride, n_steps);
 }
 
 int ngw_graph_launch(ngw_handle* h, int32_t reps) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     if (!h->graph_exec) return fail(NGW_E_INVALID_ARG, "no graph: call ngw_graph_build first");
     HIP_TRY(hipSetDevice(h->device));
-    for (int i = 0; i < reps; i++) HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
+    for (int i = 0; i < reps; i++) {
+        // A captured graph holds the prepared-episode depth and the refill cadence it was captured with.  The refills inside it
+        // keep reporting, so the host keeps adapting between replays (default setting only); when that changed something the
+        // graph is captured again - a few milliseconds, a handful of times in the life of a handle.
+        if (h->prefetch_every > 0) adapt_cadence(h);
+        if (h->adapted) {
+            const int32_t* acts = h->graph_actions; const int64_t stride = h->graph_stride; const int32_t k = h->graph_steps;
+            if (int rc = capture_graph(h, acts, stride, k)) return rc;
+        }
+        HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
+    }
     return NGW_OK;
 }
 

@@ -100,18 +100,22 @@ enum { NGW_CB_FALSE = 0, NGW_CB_FRONT_NZ = 1, NGW_CB_JUMP_BLOCKED = 2, NGW_CB_NO
        NGW_CB_NOT_NEAR = 6, NGW_CB_MISSING = 7, NGW_CB_NEED_TABLE = 8, NGW_CB_NO_ARG_ITEM = 9, NGW_CB_NEED_AXE = 10,
        NGW_CB_NEAR_PLACE = 11, NGW_CB_BRK_REWARD = 12, NGW_CB_TRUE = 13 };
 
-/* Prepared next episodes (ngw_set_reset_prefetch): shadow buffers holding, for env e, the first state of episode
- * nx.episode[e]; a reset whose new episode number matches copies it instead of running the placement loop.  All null
- * when the feature is off.  Read only on the cold reset path, with scalar loads from the HBM blob. */
+/* Prepared next episodes (ngw_set_reset_prefetch): shadow buffers holding the first states of the next `depth` episodes of
+ * every env (depth = dmask + 1, a power of two).  The row of episode E of env e is row (E & dmask) * stride + e of every
+ * array, and it is valid iff episode[row] == E; a reset whose new episode number matches copies it instead of running the
+ * placement loop.  All null when the feature is off.  Read only on the cold reset path, with scalar loads from the HBM blob. */
 #define NGW_SEQ_WORD 8           /* flags_host[8]: sequence number of the last finished step launch (the host polls it instead of a stream sync) */
 struct NgwNx {
-    int8_t* map;          /* [n_pad][S*S] */
-    int32_t* loc;         /* [n_pad][2]   */
-    int32_t* facing;      /* [n_pad]      */
-    int32_t* inv;         /* [n_pad][K]   */
-    uint32_t* episode;    /* [n_pad] episode the row was prepared for (0 = nothing prepared) */
-    uint32_t* slow;       /* [1] resets that found their row stale and ran the placement loop inside a step (cumulative) */
-    uint32_t* slow_host;  /* [1] GPU-addressable host word every refill launch copies `slow` to: the host adapts the cadence */
+    int8_t* map;          /* [depth][n_pad][S*S] */
+    int32_t* loc;         /* [depth][n_pad][2]   */
+    int32_t* facing;      /* [depth][n_pad]      */
+    int32_t* inv;         /* [depth][n_pad][K]   */
+    uint32_t* episode;    /* [depth][n_pad] episode the row was prepared for (0 = nothing prepared) */
+    uint32_t* slow;       /* [0] resets that found their row stale and ran the placement loop inside a step (cumulative); [1] refills run so far */
+    uint32_t* slow_host;  /* [2] GPU-addressable host words every refill copies `slow` to: the host adapts depth and cadence */
+    int64_t stride;       /* rows per slot = n_pad */
+    int32_t dmask;        /* depth - 1 */
+    int32_t _pad;
 };
 
 /* What the cold reset path needs besides the spec: static per handle, read there with scalar loads from the HBM blob
@@ -184,7 +188,6 @@ struct NgwResetFast {            // kernel arguments (by value)
     int32_t mode;                // NGW_MODE_RESET / NGW_MODE_REFILL
     int32_t S, S2, K, CW, n_place, wall_item;
     int32_t additem_item, additem_span;   // the subset pass: item written, width of its percent range
-    uint32_t refill_seq;         // REFILL: number of this refill launch (reported to the host with the stale-row count)
     int32_t pass_wall;           // the subset pass replaces WALL cells (ReplaceItem / FireWall of the ring) instead of filling air cells
     int32_t n_inv_start;
     uint32_t inv_start_items, inv_start_qtys;   // 4 bytes each

@@ -403,7 +403,7 @@ __device__ __forceinline__ uint32_t reset_lane(const ResetArgs a, MP mp, LDS_AS 
 // The rows were written by an earlier launch on the same stream (NGW_MODE_REFILL): plain visible global memory.
 typedef GLOBAL_AS u32x4_t g_u32x4_t;
 __device__ __forceinline__ uint32_t consume_lane(const NgwNx nx, LDS_AS int8_t* mp, LDS_AS int32_t* inv, GLOBAL_AS int8_t* gm,
-                                                 GLOBAL_AS int32_t* gi, int64_t e, int S2, int K) {
+                                                 GLOBAL_AS int32_t* gi, int64_t e /* row of the shadow arrays */, int S2, int K) {
     const GLOBAL_AS int8_t* src = (const GLOBAL_AS int8_t*)nx.map + e * S2;
     const GLOBAL_AS int32_t* sinv = (const GLOBAL_AS int32_t*)nx.inv + e * K;
     const int pr = ((const GLOBAL_AS int32_t*)nx.loc)[2 * e], pc = ((const GLOBAL_AS int32_t*)nx.loc)[2 * e + 1];
@@ -465,9 +465,10 @@ __device__ __noinline__ uint32_t new_episode(const NgwDevSpec* dspec, LDS_AS int
     const uint32_t rs0 = rsw[0], rs1 = rsw[1], rs2 = rsw[2], rs3 = rsw[3], pw0 = rsw[4], pw1 = rsw[5], pw2 = rsw[6], pw3 = rsw[7];
     nx.map = np->map; nx.loc = np->loc; nx.facing = np->facing; nx.inv = np->inv; nx.episode = np->episode; nx.slow = np->slow;
     if (may_consume && nx.episode) {
-        if (((const GLOBAL_AS uint32_t*)nx.episode)[env_local] == episode)
+        const int64_t row = (int64_t)(episode & (uint32_t)np->dmask) * np->stride + env_local;   // the slot of this episode
+        if (((const GLOBAL_AS uint32_t*)nx.episode)[row] == episode)
             return consume_lane(nx, mp, inv, (GLOBAL_AS int8_t*)ru.map + env_local * ru.S2, (GLOBAL_AS int32_t*)ru.inv + env_local * ru.K,
-                                env_local, ru.S2, ru.K) | NGW_F_ROWS_STORED;
+                                row, ru.S2, ru.K) | NGW_F_ROWS_STORED;
         if (count_miss) atomicAdd(nx.slow, 1u);                                    // a stale row inside a step: the host shortens the refill cadence
     }
     const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS, rs0, rs1, rs2, rs3, pw0, pw1, pw2, pw3};
@@ -722,12 +723,14 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     int r = 1, c = 1, f = 0, sel = 0, steps = 0, action = 0;
     uint32_t episode = 0, nx_old = 0;
     if (MODE == NGW_MODE_REFILL) {
-        // a.b is the SHADOW set; a.actions carries the main episode[].  A row is stale unless it was prepared for the
-        // env's NEXT episode.  Waves without a stale row leave before touching anything else.
+        // a.b is ONE SLOT of the shadow set (a.autoreset = its number, a.horizon = depth - 1); a.actions carries the main
+        // episode[].  The slot belongs to the one episode E of (main, main + depth] with E & (depth - 1) == slot; its row is
+        // stale unless it was prepared for exactly E.  Waves without a stale row leave before touching anything else.
         if (live) {
             nx_old = a.b.episode[e];
             const uint32_t main_ep = reinterpret_cast<const uint32_t*>(a.actions)[e];
-            if (nx_old != main_ep + 1u) { action = 1; episode = main_ep; } else episode = nx_old;
+            const uint32_t target = main_ep + 1u + (((uint32_t)a.autoreset - main_ep - 1u) & (uint32_t)a.horizon);
+            if (nx_old != target) { action = 1; episode = target - 1u; } else episode = nx_old;
         }
         if (!__any(action)) return;
     }
@@ -838,8 +841,8 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     int acc_ret = 0, acc_len = 0, acc_sum = 0, acc_eps = 0;
     if (rolling && a.acc && live) { acc_ret = a.acc[e]; acc_len = a.acc[a.n_pad + e]; acc_sum = a.acc[2 * a.n_pad + e]; acc_eps = a.acc[3 * a.n_pad + e]; }
     if (MODE == NGW_MODE_REFILL && blockIdx.x == 0 && tid == 0) {                  // what the host reads (without a sync) before the next refill
-        uint32_t* const sh = dspec->nx.slow_host;
-        if (sh) { sh[0] = *dspec->nx.slow; sh[1] = (uint32_t)a.t0; }             // (REFILL: t0 = the refill's number)
+        uint32_t* const sh = dspec->nx.slow_host;                                 // (one report per refill: the launch of slot 0 makes it)
+        if (sh && a.autoreset == 0) { sh[0] = dspec->nx.slow[0]; sh[1] = atomicAdd(dspec->nx.slow + 1, 1u) + 1u; }
     }
     STAMP(3);
     for (int t = 0; t < n_steps; t++, tt++) {

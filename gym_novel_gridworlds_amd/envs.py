@@ -14,6 +14,8 @@ from `VecNovelGridworld`.
 """
 import copy
 
+import marshal as _marshal
+
 import numpy as np
 
 from . import spaces
@@ -85,7 +87,7 @@ class _NovelGridworldEnv(_EnvBase):
 
     # ------------------------------------------------------------------ backend
     def _make_backend(self, spec, seed):
-        """One-env device handle.  Overridden in CPU tests with an oracle-backed stand-in."""
+        """The one place the adapter creates its one-env device handle."""
         return VecNovelGridworld(spec=spec, num_envs=1, seed=seed)
 
     def seed(self, seed=None):
@@ -105,13 +107,19 @@ class _NovelGridworldEnv(_EnvBase):
         return sp
 
     def _fingerprint(self):
-        """Cheap per-step check that the compiled spec still matches the env's public tables: identities and sizes of the
-        tables (callers rebind or grow them), the values of the small ones, and the spec's edit counter (novelty injection).
-        The full key is only rebuilt when this changes - and on every reset()."""
+        """Per-step check that the compiled spec still matches the env's public tables.  The reference reads `self.recipes`,
+        `items_id`, `actions_id` ... live on every step, and its users edit them in place between steps (a wrapper that
+        changes a recipe's output mid-episode), so identities and sizes are not enough: the small tables go in by CONTENT
+        (marshal of the nested recipe dict ~1.4 us, tuples of the id tables, hashes of the sets), plus the spec's edit
+        counters (novelty injection).  The full key is only rebuilt when this changes - and on every reset()."""
         sp = self._spec
-        return (int(self.map_size), id(self.items_id), len(self.items_id), id(self.actions_id), len(self.actions_id), id(self.items_quantity),
-                tuple(self.items_quantity.values()), id(self.entities), len(self.entities), id(self.recipes), len(self.recipes),
-                id(self.unbreakable_items), len(self.unbreakable_items), self.goal_item_to_craft, self.reward_done, self.reward_intermediate,
+        try:
+            recipes = _marshal.dumps(self.recipes)
+        except ValueError:                                   # (values marshal does not take, e.g. numpy integers)
+            recipes = repr(self.recipes)
+        return (int(self.map_size), recipes, tuple(self.items_id.items()), tuple(self.actions_id.items()),
+                tuple(self.items_quantity.items()), hash(frozenset(self.entities)), hash(frozenset(self.unbreakable_items)),
+                self.goal_item_to_craft, self.reward_done, self.reward_intermediate,
                 len(sp.novelties), id(sp.axe), id(sp.additem), id(sp.replace), id(sp.fence), id(sp.fence_pred), len(sp.reset_passes), id(sp.crate), sp.fire_wall, sp.break_increase)
 
     def _backend(self, full_check=False):

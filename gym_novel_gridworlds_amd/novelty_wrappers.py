@@ -4,9 +4,9 @@
 
 Accepts a single-env adapter (envs.py) - returns a wrapper that forwards reads to the wrapped env exactly like
 `gym.core.Wrapper` (copies action_space / observation_space at construction, `__getattr__` for reads only) - or a
-`VecNovelGridworld`, for which it returns a NEW batched env built from the edited spec."""
+`VecNovelGridworld` / `ShardedVecNovelGridworld`, which is rebuilt IN PLACE on the edited spec and returned (the
+reference's wrappers mutate the env they wrap; a shard keeps its place in the global env index space)."""
 from .novelty import apply_novelty
-from .vec_env import VecNovelGridworld
 
 
 class NoveltyWrapper(object):
@@ -122,12 +122,13 @@ class FireWall(AddItem):                                      # :1161
 
 
 def inject_novelty(env, novelty_name, difficulty='hard', novelty_arg1='', novelty_arg2=''):
-    if isinstance(env, VecNovelGridworld):
+    if callable(getattr(env, 'rebuild', None)):
+        # batched env (or a rank-local shard of one, dist.py): the edited spec is compiled into the kernels' tables IN PLACE -
+        # same object, same global env indices, same autoreset / prepared-episode / lidar settings (VecNovelGridworld.rebuild)
         import copy
         spec = copy.deepcopy(env.spec)
         apply_novelty(spec, novelty_name, difficulty, novelty_arg1, novelty_arg2)
-        return VecNovelGridworld(spec=spec, num_envs=env.num_envs, device=env.device, seed=env.seed,
-                                 autoreset=env.autoreset, horizon=env.horizon)
+        return env.rebuild(spec)
     base = getattr(env, 'unwrapped', env)
     base = getattr(base, 'env', base) if isinstance(base, NoveltyWrapper) else base
     spec = base._sync_spec()

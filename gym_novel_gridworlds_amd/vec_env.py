@@ -68,7 +68,7 @@ class StepInfo(dict):
 
 class VecNovelGridworld:
     def __init__(self, env_id='NovelGridworld-Pogostick-v1', num_envs=1, map_size=None, novelty=None, device=0,
-                 seed=0, autoreset=False, horizon=0, env_index_base=0, spec=None, reset_prefetch='auto'):
+                 seed=0, autoreset=False, horizon=0, env_index_base=0, spec=None, reset_prefetch='auto', reset_prefetch_depth=0):
         if spec is None:
             spec = make_spec(env_id, map_size)
             if novelty:
@@ -76,12 +76,21 @@ class VecNovelGridworld:
                 for nv in novs:
                     apply_novelty(spec, *nv)
         assert isinstance(spec, EnvSpec)
-        self.spec = spec
-        self.cspec = spec.compile()
         self.num_envs = int(num_envs)
         self.device = int(device)
         self.seed = int(seed)
         self.env_index_base = int(env_index_base)
+        self.autoreset, self.horizon = bool(autoreset), int(horizon)
+        # what the caller chose for the prepared next episodes ('auto' / 0 = the library's own defaults); rebuild() re-applies it
+        self._prefetch_arg, self._depth_arg = reset_prefetch, int(reset_prefetch_depth)
+        self.lidar, self.lidar_fused, self.lidar_len, self.lidar_dtype = None, False, 0, np.dtype(np.int32)   # set by lidar_configure()
+        self._h = C.c_void_p()
+        self._open(spec)
+
+    def _open(self, spec):
+        """Create the device handle for `spec` and apply this env's settings to it."""
+        self.spec = spec
+        self.cspec = spec.compile()
         self.map_size = spec.map_size
         self.n_items = len(spec.items_id)
         self.items_id = dict(spec.items_id)
@@ -90,20 +99,33 @@ class VecNovelGridworld:
         from . import spaces
         self.action_space = spaces.Discrete(spec.action_space_n)           # per env; NOT grown by axe/additem
         self.observation_space = spaces.Dict({'map': spaces.Box(low=0, high=spec.max_items, shape=(spec.map_size, spec.map_size, 1))})
-        self._h = C.c_void_p()
         L = _cabi.lib()
-        _cabi.check(L.ngw_create(C.byref(self.cspec), self.num_envs, self.device, self.seed, int(env_index_base),
+        _cabi.check(L.ngw_create(C.byref(self.cspec), self.num_envs, self.device, self.seed, self.env_index_base,
                                  C.byref(self._h)))
-        self.autoreset, self.horizon = bool(autoreset), int(horizon)
         _cabi.check(L.ngw_set_autoreset(self._h, int(self.autoreset), self.horizon))
-        self.lidar, self.lidar_fused, self.lidar_len = None, False, 0      # set by lidar_configure()
-        # 'auto' = the library's own default: ngw_set_autoreset switched prepared next episodes on (a refill every 32 steps)
+        # 'auto' = the library's own default: ngw_set_autoreset switched prepared next episodes on (a refill every 3/4 horizon)
         # unless the episodes are too short for that cadence to keep up (rows would go stale and resets simply run inline)
         self.reset_prefetch = self._default_prefetch()
-        if reset_prefetch != 'auto':
-            self.set_reset_prefetch(reset_prefetch)
+        self._prefetch_user = False
+        if self._depth_arg:
+            self.set_reset_prefetch_depth(self._depth_arg)
+        if self._prefetch_arg != 'auto':
+            self.set_reset_prefetch(self._prefetch_arg)
         self._flags_word = C.c_uint32(0)
         self._host = None                                     # host mirrors of the host API: allocated on first use
+        if self.lidar is not None:                            # the observation setup travels with the env (rebuild)
+            self.lidar_configure(self.lidar, fused=self.lidar_fused, dtype=self.lidar_dtype)
+
+    def rebuild(self, spec):
+        """The same batched env - same object, same shard of the global env index space (`env_index_base`), same autoreset /
+        horizon / prepared-episode / lidar settings - on an edited spec.  In place: the reference's novelty wrappers mutate
+        the env they wrap and keep its identity (novelty_wrappers.py:1586-1674), so a rank-local shard stays that shard.
+        The state is undefined until the next reset(), as after construction."""
+        self.close()
+        for name in VecNovelGridworld._HOST_ATTRS + ('_host', '_step_args', '_step1_args', '_step1_fn', '_last_state_views', '_lidar_host', '_view_host', '_last_actions'):
+            self.__dict__.pop(name, None)
+        self._open(spec)
+        return self
 
     _HOST_ATTRS = ('_obs', '_reward', '_done', '_act_pinned', '_sel_host', '_steps_host', '_result', '_cost', '_msg', '_arg', '_flags_np')
 
@@ -153,6 +175,10 @@ class VecNovelGridworld:
 
     def set_stream(self, hip_stream_ptr):
         _cabi.check(_cabi.lib().ngw_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def stream_order(self, other_stream_ptr, handle_waits):
+        """Order this env's stream and another HIP stream behind each other without a host wait (include/ngw.h ngw_stream_order)."""
+        _cabi.check(_cabi.lib().ngw_stream_order(self._h, C.c_void_p(int(other_stream_ptr)) if other_stream_ptr else None, int(bool(handle_waits))))
 
     # ------------------------------------------------------------------ reference surface, batched
     def reset(self, mask=None, copy=False):
@@ -277,6 +303,27 @@ class VecNovelGridworld:
         _cabi.check(_cabi.lib().ngw_set_reset_prefetch(self._h, int(every_n_steps)))
         self.reset_prefetch = int(every_n_steps)
         self._prefetch_user = True
+        self._prefetch_arg = int(every_n_steps)
+
+    def set_reset_prefetch_depth(self, depth):
+        """How many episodes ahead are kept prepared per env: 1, 2, 4 or 8; 0 = automatic (the default: 1, growing by itself when
+        envs end episodes faster than a refill comes round).  include/ngw.h ngw_set_reset_prefetch_depth; results do not depend on it."""
+        _cabi.check(_cabi.lib().ngw_set_reset_prefetch_depth(self._h, int(depth)))
+        self._depth_arg = int(depth)
+
+    @property
+    def refill_cadence(self):
+        """Batched steps between two refills right now (0 = prepared episodes off): under the default setting the library adapts it
+        to how fast episodes end (diagnostic entry point ngw_debug_refill_cadence)."""
+        f = _cabi.lib().ngw_debug_refill_cadence
+        f.argtypes, f.restype = [C.c_void_p], C.c_int
+        return int(f(self._h))
+
+    @property
+    def reset_prefetch_depth(self):
+        v = C.c_int32()
+        _cabi.check(_cabi.lib().ngw_get_reset_prefetch_depth(self._h, C.byref(v)))
+        return int(v.value)
 
     def rollout(self, n_steps, action_seed=1234, t0=0):
         """Fused mode: n_steps steps in one launch with on-device uniform actions."""

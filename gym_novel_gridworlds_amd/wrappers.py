@@ -82,8 +82,10 @@ def limit_actions_vec(venv, limited_actions):
     spec.craft_actions_id = {a: i for a, i in limited.items() if a.startswith('Craft_')}
     spec.select_actions_id = {a: i for a, i in limited.items() if a.startswith('Select_')}
     spec.action_space_n = len(limited)
+    # (the prepared-episode settings travel as the caller CHOSE them: 'auto' stays adaptive on the derived env)
     new = VecNovelGridworld(spec=spec, num_envs=venv.num_envs, device=venv.device, seed=venv.seed, autoreset=venv.autoreset,
-                            horizon=venv.horizon, env_index_base=venv.env_index_base, reset_prefetch=venv.reset_prefetch)
+                            horizon=venv.horizon, env_index_base=venv.env_index_base, reset_prefetch=venv._prefetch_arg,
+                            reset_prefetch_depth=venv._depth_arg)
     if venv.lidar is not None:                              # the observation setup travels with the env
         new.lidar_configure(venv.lidar, fused=venv.lidar_fused, dtype=venv.lidar_dtype)
     return new

@@ -226,7 +226,17 @@ int ngw_set_autoreset(ngw_handle* h, int autoreset, int horizon);
 int ngw_set_reset_prefetch(ngw_handle* h, int32_t every_n_steps);
 /* The refill cadence in effect (0 = prepared episodes off): what ngw_set_reset_prefetch set, or the default ngw_set_autoreset chose. */
 int ngw_get_reset_prefetch(ngw_handle* h, int32_t* every_n_steps);
+/* How many episodes ahead are prepared per env: depth 1, 2, 4 or 8 (a power of two; shadow memory grows with it), 0 = automatic
+ * (the default: 1, growing to 2 and 4 by itself when envs end episodes faster than a refill comes round - FireWall kills within
+ * a few steps - so that a reset still finds a prepared row; see adapt_cadence in ngw_abi.cpp).  Results do not depend on it. */
+int ngw_set_reset_prefetch_depth(ngw_handle* h, int32_t depth);
+int ngw_get_reset_prefetch_depth(ngw_handle* h, int32_t* depth);
 int ngw_set_stream(ngw_handle* h, void* hip_stream);
+/* Order the handle's stream and another hipStream_t of the same device behind each other WITHOUT a host wait (one event
+ * record + one stream wait): handle_waits != 0 - work submitted to the handle after this call runs after everything
+ * `other_stream` holds now; handle_waits == 0 - the other way round.  What dist.py uses around the one collective (pack /
+ * unpack launches on the handle's stream, RCCL on torch's current stream); NULL = the default stream. */
+int ngw_stream_order(ngw_handle* h, void* other_stream, int handle_waits);
 
 /* reset(): pogostick_v1_env.py:86-157 (+ AddItem.reset).  mask = NULL resets all envs, else mask[i] != 0. */
 int ngw_reset(ngw_handle* h, const uint8_t* mask_host);
@@ -292,7 +302,10 @@ void* ngw_host_alloc(uint64_t bytes);
 int ngw_host_free(void* p);
 
 /* Device pointers of the observation / output buffers (fixed for the handle's lifetime; contents are the state
- * after the last enqueued step and are updated in place by the next one). */
+ * after the last enqueued step and are updated in place by the next one).  For handles of at most one wavefront (<= 64 envs:
+ * the single-env gym.Env adapter) these are GPU-ADDRESSABLE HOST memory (page-locked, mapped): valid in kernels and in
+ * hipMemcpy like any device pointer, but every access crosses PCIe - batch at least 65 envs (or set NGW_HOST_STATE=0 in the
+ * environment before ngw_create) when the observation is consumed on the device. */
 int ngw_obs_device_ptrs(ngw_handle* h, void** map, void** loc, void** facing, void** inv);
 int ngw_out_device_ptrs(ngw_handle* h, void** reward, void** done, void** info);
 int ngw_sync(ngw_handle* h);

@@ -352,6 +352,14 @@ class OracleVec:
     def sync(self):
         pass
 
+    def rebuild(self, spec):
+        """inject_novelty on the stand-in: the same env (seed, global env indices, settings) on the edited spec."""
+        from oracle.ngw_oracle import Oracle
+        o = self.o
+        self.spec = spec
+        self.o = Oracle(spec.compile(), self.num_envs, seed=o.seed, env_index_base=o.base, autoreset=o.autoreset, horizon=o.horizon)
+        return self
+
     def lidar_configure(self, lidar_config=None, num_beams=8, fused=False, dtype=None):
         from gym_novel_gridworlds_amd.lidar import LidarConfig
         self.lidar = lidar_config if lidar_config is not None else LidarConfig(self.spec, num_beams)
@@ -509,3 +517,47 @@ def g6_check(cfg, freq, hist, agent, n):
         assert np.nonzero(ha)[0].tolist() == np.nonzero(hb)[0].tolist(), "%s: the count is a constant in the reference" % cfg
     mean_a, mean_b = (ha * np.arange(len(ha))).sum() / na, (hb * np.arange(len(hb))).sum() / n
     return mean_a, mean_b
+
+
+def oracle_sharded(**kw):
+    """ShardedVecNovelGridworld whose local envs run on the CPU oracle (CPU-only suite: gloo ranks, no GPU): the product class
+    with its three device hooks replaced - the local env, the payload pack and the unpack - by host code over the same bytes."""
+    import torch
+    from gym_novel_gridworlds_amd.dist import ShardedVecNovelGridworld
+
+    class OracleSharded(ShardedVecNovelGridworld):
+        def _make_local(self, device=None, spec=None, **k):
+            k = {a: b for a, b in k.items() if a in ('num_envs', 'seed', 'autoreset', 'horizon', 'env_index_base')}
+            return OracleVec(spec, **k)
+
+        def payload_layout(self):
+            n, S, K = self.num_envs, self.spec.map_size, len(self.spec.items_id)
+            offs = [0]
+            for w in (S * S, 8, 4, 4 * K, 4, 1, 4):
+                offs.append(offs[-1] + ((n * w + 15) & ~15))
+            return offs
+
+        def packed_observation(self):
+            offs = self.payload_layout()
+            o, out = self.local.device_observation(), self.local.device_outputs()
+            buf = torch.zeros(offs[7], dtype=torch.uint8)
+            parts = [o['map'], o['agent_location'], o['agent_facing_id'], o['inventory_items_quantity'], out['reward'], out['done'], out['info']]
+            for off, t in zip(offs, parts):
+                b = t.contiguous().reshape(-1).view(torch.uint8)
+                buf[off:off + b.numel()] = b
+            return buf
+
+        def unpack(self, payloads, world=None):
+            world = self.world if world is None else world
+            n, offs = self.num_envs, self.payload_layout()
+            pl = payloads.reshape(world, offs[7])
+            out = {}
+            for name, off, (sh, dt), (sh1, _) in zip(self.FIELDS, offs, self._field_shapes(n * world), self._field_shapes(n)):
+                nbytes = int(torch.tensor([], dtype=dt).element_size())
+                for d in sh1:
+                    nbytes *= d
+                out[name] = pl[:, off:off + nbytes].contiguous().view(dt).reshape(sh)
+            out['done'] = out['done'].bool()
+            return out
+
+    return OracleSharded(**kw)

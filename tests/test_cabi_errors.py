@@ -95,3 +95,33 @@ def test_limited_actions_env_keeps_shard_and_observation_setup():
     ref = VecNovelGridworld(num_envs=128, seed=3, autoreset=True, horizon=100, env_index_base=4096)
     w.reset(); ref.reset()
     assert all((w.get_state()[k] == ref.get_state()[k]).all() for k in ('map', 'loc', 'facing'))   # same episodes as the shard it came from
+
+
+def test_inject_novelty_on_a_batched_env_keeps_shard_and_observation_setup():
+    """inject_novelty(VecNovelGridworld) rebuilds the SAME env in place (the reference's wrappers mutate the env they wrap,
+    novelty_wrappers.py:1586-1674): global env index base, prepared-episode cadence / depth and the lidar setup stay, the old
+    handle is closed, and the states equal an oracle batch keyed by the same global indices."""
+    import numpy as np
+    from gym_novel_gridworlds_amd import inject_novelty
+    from oracle.ngw_oracle import Oracle
+    import ngw_testlib as T
+    v = VecNovelGridworld(num_envs=300, seed=4, env_index_base=7000, autoreset=True, horizon=30, reset_prefetch=7, reset_prefetch_depth=2)
+    v.lidar_configure(num_beams=4, fused=True, dtype=np.int16)
+    old_handle = v._h.value
+    w = inject_novelty(v, 'axe', 'medium', 'wooden', '')
+    assert w is v and v._h.value and v._h.value != old_handle
+    assert w.env_index_base == 7000 and w.reset_prefetch == 7 and w.reset_prefetch_depth == 2
+    assert w.lidar_fused and w.lidar_dtype == np.dtype(np.int16) and 'wooden_axe' in w.items_id
+    spec = T.build_spec('axe10')
+    o = Oracle(spec.compile(), 300, seed=4, env_index_base=7000, autoreset=True, horizon=30)
+    w.reset(); o.reset()
+    rs = np.random.RandomState(1)
+    for t in range(70):
+        a = rs.randint(0, len(spec.actions_id), size=300).astype(np.int32)
+        w.step(a); o.step(a)
+    st = w.get_state()
+    assert (st['map'] == o.st.map).all() and (st['loc'] == o.st.loc).all() and (st['inv'] == o.st.inv).all() and (st['episode'] == o.st.episode).all()
+    assert w.lidar_observation().shape == (300, w.lidar_len)
+    w2 = inject_novelty(w, 'breakincrease', 'hard', '', '')          # a stack: still the same object
+    assert w2 is v and w2.env_index_base == 7000
+    v.close()

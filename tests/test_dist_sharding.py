@@ -1,5 +1,7 @@
-"""N > 1 path on CPU: two gloo ranks, envs sharded by global index, observation gather == one unsharded batch.
-The local backend is the oracle-backed stand-in (tests only); the product path uses VecNovelGridworld on each GPU."""
+"""N > 1 path on CPU: two gloo ranks, envs sharded by global index, observation gather / all_gather == one unsharded batch,
+also after every rank has called inject_novelty() on its shard.  The local envs are the oracle-backed stand-in of
+tests/ngw_testlib.py (a subclass of the product class with its device hooks replaced); the product path is
+VecNovelGridworld on each GPU (tests/test_multi_gpu_rehearsal.py runs that on the GPU box)."""
 import os
 import socket
 
@@ -10,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import ngw_testlib as T
-from gym_novel_gridworlds_amd.dist import ShardedVecNovelGridworld, shard_range
+from gym_novel_gridworlds_amd.dist import shard_range
 
 N, STEPS = 96, 40
 
@@ -23,17 +25,21 @@ def _free_port():
     return port
 
 
-def _factory(spec=None, **kw):
-    kw = {k: v for k, v in kw.items() if k in ('num_envs', 'seed', 'autoreset', 'horizon', 'env_index_base')}
-    return T.OracleVec(spec, **kw)
-
-
-def _worker(rank, world, port, cfg, q):
+def _worker(rank, world, port, cfg, q, inject):
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        spec = T.build_spec(cfg)
-        env = ShardedVecNovelGridworld(global_num_envs=N, spec=spec, seed=3, autoreset=True, horizon=12, local_factory=_factory)
+        from gym_novel_gridworlds_amd import inject_novelty
+        env_id, S, nov = T.CFGS[cfg]
+        if inject:                                       # the shard is built plain; every rank injects the novelty on its own shard
+            from gym_novel_gridworlds_amd import make_spec
+            env = T.oracle_sharded(global_num_envs=N, spec=make_spec(env_id, S), seed=3, autoreset=True, horizon=12)
+            first = env.first
+            same = inject_novelty(env, *nov)
+            assert same is env and env.first == first and env.local.o.base == first      # same object, same global env indices
+        else:
+            env = T.oracle_sharded(global_num_envs=N, spec=T.build_spec(cfg), seed=3, autoreset=True, horizon=12)
+        spec = env.spec
         assert (env.first, env.num_envs) == shard_range(N, world, rank)
         env.reset()
         rs = np.random.RandomState(0)
@@ -41,24 +47,27 @@ def _worker(rank, world, port, cfg, q):
             a = rs.randint(0, len(spec.actions_id), size=N).astype(np.int32)      # same global action batch on every rank
             env.step(a[env.first:env.first + env.num_envs])
         got = env.gather_observation(dst=0)
+        every = env.all_gather_observation()                                       # ... and the same stack on every rank
         if rank == 0:
+            assert all((got[k] == every[k]).all() for k in got)
             q.put({k: v.numpy() for k, v in got.items()})
         else:
             assert got is None
+            q.put({k: v.numpy() for k, v in every.items()})
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('cfg', ['pogo10', 'axe10'])
-def test_two_rank_sharding_and_gather_match_single_batch(cfg):
+@pytest.mark.parametrize('cfg,inject', [('pogo10', False), ('axe10', False), ('axe10', True), ('add12m', True)])
+def test_two_rank_sharding_and_gather_match_single_batch(cfg, inject):
     ctx = mp.get_context('spawn')
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg, q, inject)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get()
+    gots = [q.get(), q.get()]
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -70,11 +79,14 @@ def test_two_rank_sharding_and_gather_match_single_batch(cfg):
         ref.step(rs.randint(0, len(spec.actions_id), size=N).astype(np.int32))
     st = ref.o.st
     S = spec.map_size
-    assert (got['map'] == st.map.reshape(N, S, S)).all() and (got['agent_location'] == st.loc).all()
-    assert (got['agent_facing_id'] == st.facing).all() and (got['inventory_items_quantity'] == st.inv).all()
-    assert (got['reward'] == ref.o.reward).all() and (got['done'] == ref.o.done.astype(bool)).all()
-    assert (got['info'].view(np.uint32) == ref.o.info).all()
+    for got in gots:                                     # rank 0's gather and rank 1's all_gather
+        assert (got['map'] == st.map.reshape(N, S, S)).all() and (got['agent_location'] == st.loc).all()
+        assert (got['agent_facing_id'] == st.facing).all() and (got['inventory_items_quantity'] == st.inv).all()
+        assert (got['reward'] == ref.o.reward).all() and (got['done'] == ref.o.done.astype(bool)).all()
+        assert (got['info'].view(np.uint32) == ref.o.info).all()
     assert st.episode.max() >= 3
+    assert len({tuple(st.loc[i]) for i in range(N)}) > 8                  # (ranks that all restarted at global env 0 would repeat each other)
+    assert not (st.map[:N // 2] == st.map[N // 2:]).all()
 
 
 def test_shard_range_requires_even_split():

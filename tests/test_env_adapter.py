@@ -128,3 +128,23 @@ def test_public_map_editing_helpers():
     np.random.seed(2)
     new = base.remap_action({'Forward': 0, 'Left': 1, 'Right': 2}, 0)
     assert sorted(new.values()) == [0, 1, 2] and new != {'Forward': 0, 'Left': 1, 'Right': 2}
+
+
+def test_in_place_table_edits_between_steps_take_effect_at_once():
+    """The reference reads self.recipes (and the id tables) live on every step: an edit that keeps a table's identity and
+    size - a wrapper that raises a recipe's output mid-episode - must show in the very next step, not at the next reset()."""
+    env = T.make_adapter_env('pogo10', 'oracle')
+    env.reset()
+    env.inventory_items_quantity['tree_log'] = 5
+    craft = env.actions_id['Craft_plank']
+    env.step(craft)
+    assert env.inventory_items_quantity['plank'] == 4                                   # pogostick_v1_env.py:455-474
+    env.recipes['plank']['output']['plank'] = 9
+    env.step(craft)
+    assert env.inventory_items_quantity['plank'] == 13
+    env.recipes['plank']['input']['tree_log'] = 2
+    obs, reward, done, info = env.step(craft)
+    assert env.inventory_items_quantity['plank'] == 22 and env.inventory_items_quantity['tree_log'] == 1
+    env.unbreakable_items.add('tree_log')                                              # same size? no - but same identity
+    env.unbreakable_items.discard('wall'); env.unbreakable_items.add('wall')
+    env.close()

@@ -60,7 +60,9 @@ def one_case(rs, cfg, case):
     prefetch = rs.choice(['auto', 0, 3, 16])
     prefetch = prefetch if prefetch == 'auto' else int(prefetch)
     seed, base = int(rs.randint(0, 2 ** 31)), int(rs.randint(0, 10 ** 6))
-    v = VecNovelGridworld(spec=spec, num_envs=n, seed=seed, autoreset=autoreset, horizon=horizon, reset_prefetch=prefetch, env_index_base=base)
+    depth = int(rs.choice([0, 0, 1, 2, 4]))                 # prepared episodes per env (0 = automatic)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=seed, autoreset=autoreset, horizon=horizon, reset_prefetch=prefetch, env_index_base=base,
+                          reset_prefetch_depth=depth)
     o = Oracle(spec.compile(), n, seed=seed, autoreset=autoreset, horizon=horizon, env_index_base=base)
     lid = None
     if rs.randint(0, 3) == 0:                               # one case in three runs with the fused lidar epilogue
@@ -68,7 +70,7 @@ def one_case(rs, cfg, case):
         lc = LidarConfig(spec, int(rs.choice([4, 8])))
         v.lidar_configure(lc, fused=True)
         lid = (lc.compile(spec), S, len(spec.items_id))
-    tag = '%s case %d (n=%d H=%d auto=%d prefetch=%s lidar=%d)' % (cfg, case, n, horizon, autoreset, prefetch, lid is not None)
+    tag = '%s case %d (n=%d H=%d auto=%d prefetch=%s depth=%d lidar=%d)' % (cfg, case, n, horizon, autoreset, prefetch, depth, lid is not None)
     if not both_reset(v, o, None, tag):
         v.close()
         return

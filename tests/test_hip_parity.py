@@ -130,16 +130,21 @@ def test_fused_rollout_matches_oracle(cfg, n, steps):
     assert v.error_flags() == 0
 
 
-@pytest.mark.parametrize('cfg,n,steps,horizon,every', [('pogo10', 4096, 260, 50, 8), ('pogo10', 3000, 120, 7, 1), ('fire10h', 4096, 200, 50, 4),
-                                                       ('add32', 256, 60, 25, 16), ('bow20', 1000, 120, 30, 64), ('pogo13', 777, 100, 20, 3),
-                                                       ('fencer10m', 1500, 120, 30, 5)])
-def test_prepared_next_episodes_are_bit_identical(cfg, n, steps, horizon, every):
-    """ngw_set_reset_prefetch: resets served from the shadow rows (staggered episode ends, instant deaths, explicit masked
-    resets, a stale row after set_state(episode=...), fused rollout, graph replay) give exactly the oracle's states."""
+@pytest.mark.parametrize('cfg,n,steps,horizon,every,depth', [('pogo10', 4096, 260, 50, 8, 1), ('pogo10', 3000, 120, 7, 1, 1), ('fire10h', 4096, 200, 50, 4, 1),
+                                                             ('add32', 256, 60, 25, 16, 1), ('bow20', 1000, 120, 30, 64, 1), ('pogo13', 777, 100, 20, 3, 1),
+                                                             ('fencer10m', 1500, 120, 30, 5, 1),
+                                                             ('pogo10', 3000, 120, 7, 16, 4), ('fire10h', 4096, 200, 50, 16, 4), ('fire10h', 2000, 150, 30, 9, 2),
+                                                             ('add32', 256, 60, 12, 30, 4), ('bow20', 1000, 120, 9, 20, 2), ('fencer10m', 1500, 120, 10, 25, 8),
+                                                             ('axe10', 1000, 150, 11, 30, 4), ('pogo13', 777, 100, 6, 20, 4)])
+def test_prepared_next_episodes_are_bit_identical(cfg, n, steps, horizon, every, depth):
+    """ngw_set_reset_prefetch (+ _depth: several episodes ahead per env): resets served from the shadow rows (staggered episode
+    ends, instant deaths, several episode ends of one env between two refills, explicit masked resets, a stale row after
+    set_state(episode=...), fused rollout, graph replay) give exactly the oracle's states."""
     import torch
     spec = T.build_spec(cfg)
     A = len(spec.actions_id)
-    v = VecNovelGridworld(spec=spec, num_envs=n, seed=21, autoreset=True, horizon=horizon, reset_prefetch=every)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=21, autoreset=True, horizon=horizon, reset_prefetch=every, reset_prefetch_depth=depth)
+    assert v.reset_prefetch_depth == depth
     o = Oracle(spec.compile(), n, seed=21, autoreset=True, horizon=horizon)
     v.reset(); o.reset()
     stag = (np.arange(n) * 7919 % horizon).astype(np.int32)            # episode ends spread over the batch
@@ -654,7 +659,8 @@ def test_big_batch_host_step_uses_one_block_and_matches_oracle():
 
 def test_refill_cadence_adapts_to_short_episodes_and_results_stay_exact():
     """Default prepared-episode setting: under FireWall an env ends several episodes between two refills, the stale rows are
-    counted on the device and the host shortens the refill cadence (75 -> ... -> 2) - without changing a single result."""
+    counted on the device and the host first keeps more episodes prepared per env (2, then 4), then shortens the refill
+    cadence - without changing a single result."""
     import ctypes
     from gym_novel_gridworlds_amd import _cabi
     spec = T.build_spec('fire10h')
@@ -674,7 +680,13 @@ def test_refill_cadence_adapts_to_short_episodes_and_results_stay_exact():
         _, reward, done, info = v.step(a); o.step(a)
         assert (reward == o.reward).all() and (done == o.done.astype(bool)).all(), t
     assert_state_equal(v, o, 'fire10h adaptive cadence')
-    assert lib.ngw_debug_refill_cadence(v._h) < start
+    # the host first prepares more episodes ahead per env (depth 1 -> 2 -> 4), then refills more often
+    assert v.reset_prefetch_depth > 1 or lib.ngw_debug_refill_cadence(v._h) < start
+    for t in range(600):
+        a = rs.randint(0, A, size=n).astype(np.int32)
+        v.step(a); o.step(a)
+    assert_state_equal(v, o, 'fire10h adaptive depth and cadence')
+    assert v.reset_prefetch_depth == 4 and lib.ngw_debug_refill_cadence(v._h) <= start   # (2 048 envs: four rows ahead are enough at 75 steps)
     v.rollout(300, action_seed=8, t0=0); assert o.rollout(300, 8, 0) == 0
     assert_state_equal(v, o, 'fire10h adaptive cadence, fused')
     assert v.error_flags() == 0

@@ -26,16 +26,26 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, cfg, q):
+def _worker(rank, world, port, cfg, q, inject):
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     import torch
     import torch.distributed as dist
+    from gym_novel_gridworlds_amd import inject_novelty, make_spec
     from gym_novel_gridworlds_amd.dist import ShardedVecNovelGridworld, shard_range
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        spec = T.build_spec(cfg)
-        env = ShardedVecNovelGridworld(global_num_envs=N, spec=spec, seed=3, autoreset=True, horizon=12, device=0)
+        env_id, S, nov = T.CFGS[cfg]
+        if inject:                                       # every rank injects the novelty on its own shard, lidar and prepared episodes set before
+            env = ShardedVecNovelGridworld(global_num_envs=N, spec=make_spec(env_id, S), seed=3, autoreset=True, horizon=12, device=0,
+                                           reset_prefetch=5, reset_prefetch_depth=2)
+            env.local.lidar_configure(num_beams=4, fused=True)
+            same = inject_novelty(env, *nov)
+            assert same is env and env.local.env_index_base == env.first == shard_range(N, world, rank)[0]
+            assert env.local.reset_prefetch == 5 and env.local.reset_prefetch_depth == 2 and env.local.lidar_fused
+        else:
+            env = ShardedVecNovelGridworld(global_num_envs=N, spec=T.build_spec(cfg), seed=3, autoreset=True, horizon=12, device=0)
+        spec = env.spec
         assert (env.first, env.num_envs) == shard_range(N, world, rank)
         env.reset()
         rs = np.random.RandomState(0)
@@ -44,27 +54,29 @@ def _worker(rank, world, port, cfg, q):
             env.step(a[env.first:env.first + env.num_envs])
         got = env.gather_observation(dst=0)
         got2 = env.gather_observation(dst=0)                                       # buffers are reused: same answer
+        every = env.all_gather_observation()
         if rank == 0:
-            assert all((got[k] == got2[k]).all() for k in got)
+            assert all((got[k] == got2[k]).all() for k in got) and all((got[k] == every[k]).all() for k in got)
             q.put({k: v.cpu().numpy() for k, v in got.items()})
         else:
             assert got is None
+            q.put({k: v.cpu().numpy() for k, v in every.items()})
         dist.barrier()
         env.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('cfg', ['pogo10', 'axe10', 'bow20'])
-def test_two_ranks_on_one_gpu_match_one_oracle_batch(cfg):
+@pytest.mark.parametrize('cfg,inject', [('pogo10', False), ('axe10', False), ('bow20', False), ('axe10', True), ('add12m', True)])
+def test_two_ranks_on_one_gpu_match_one_oracle_batch(cfg, inject):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg, q, inject)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get()
+    gots = [q.get(), q.get()]
     for p in procs:
         p.join(180)
         assert p.exitcode == 0
@@ -76,11 +88,17 @@ def test_two_ranks_on_one_gpu_match_one_oracle_batch(cfg):
         ref.step(rs.randint(0, len(spec.actions_id), size=N).astype(np.int32))
     st = ref.o.st
     S = spec.map_size
-    assert (got['map'] == st.map.reshape(N, S, S)).all() and (got['agent_location'] == st.loc).all()
-    assert (got['agent_facing_id'] == st.facing).all() and (got['inventory_items_quantity'] == st.inv).all()
-    assert (got['reward'] == ref.o.reward).all() and (got['done'] == ref.o.done.astype(bool)).all()
-    assert (got['info'].view(np.uint32) == ref.o.info).all()
+    for got in gots:                                     # rank 0's gather and rank 1's all_gather
+        assert (got['map'] == st.map.reshape(N, S, S)).all() and (got['agent_location'] == st.loc).all()
+        assert (got['agent_facing_id'] == st.facing).all() and (got['inventory_items_quantity'] == st.inv).all()
+        assert (got['reward'] == ref.o.reward).all() and (got['done'] == ref.o.done.astype(bool)).all()
+        assert (got['info'].view(np.uint32) == ref.o.info).all()
     assert st.episode.max() >= 3
+
+
+def test_dist_module_has_no_device_wide_synchronisation():
+    src = open(os.path.join(ROOT, 'gym_novel_gridworlds_amd', 'dist.py')).read()
+    assert 'cuda.synchronize' not in src and '.sync()' not in src.split('# ------------------------------------------------------------------ the one collective')[1]
 
 
 def test_bench_starts_its_own_ranks():
