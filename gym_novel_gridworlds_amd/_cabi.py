@@ -23,7 +23,7 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_get_lidar', 'ngw_lidar_device_ptr', 'ngw_host_alloc', 'ngw_host_free', 'ngw_agent_view',
            'ngw_get_agent_view', 'ngw_agent_view_device_ptr', 'ngw_set_reset_prefetch', 'ngw_step_host', 'ngw_lidar_set_output', 'ngw_rollout_actions',
            'ngw_pack_layout', 'ngw_pack_obs', 'ngw_unpack_obs', 'ngw_rollout_outputs', 'ngw_episode_stats', 'ngw_host_step_layout', 'ngw_step_device_many',
-           'ngw_set_reset_prefetch_depth', 'ngw_get_reset_prefetch_depth', 'ngw_stream_order']
+           'ngw_set_reset_prefetch_depth', 'ngw_get_reset_prefetch_depth', 'ngw_stream_order', 'ngw_host_mirror_invalidate']
 
 _lib = None
 
@@ -78,6 +78,8 @@ def lib():
     L.ngw_destroy.argtypes = [vp]
     L.ngw_set_autoreset.argtypes = [vp, C.c_int, C.c_int]
     L.ngw_set_stream.argtypes = [vp, vp]
+    if hasattr(L, 'ngw_host_mirror_invalidate'):
+        L.ngw_host_mirror_invalidate.argtypes = [vp]
     if hasattr(L, 'ngw_stream_order'):
         L.ngw_stream_order.argtypes = [vp, vp, C.c_int]
     if hasattr(L, 'ngw_set_reset_prefetch'):           # absent only in older builds loaded through NGW_LIB (A/B runs)

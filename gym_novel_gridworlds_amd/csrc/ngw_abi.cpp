@@ -54,6 +54,13 @@ struct ngw_handle {
     uint8_t* zc_host = nullptr;       // small batches: actions + packed outputs in host memory the GPU addresses directly
     uint8_t* zc_dev = nullptr;
     uint8_t* step_stage = nullptr;        // ngw_step_host, one-block layout: every output packed on the device, ONE copy out
+    // ngw_step_host, delta refresh: device-side shadows of the map / inventory / selected rows the caller's block holds, the
+    // block they describe (host pointer + its mapped device address), and whether it still mirrors the device state
+    uint8_t* shadow[3] = {nullptr, nullptr, nullptr};
+    const void* mirror_block = nullptr;
+    uint8_t* mirror_dev = nullptr;
+    bool mirror_valid = false;
+    int host_delta = 1;                   // NGW_HOST_DELTA=0: every ngw_step_host copies the whole observation (A/B)
     std::vector<void*> allocs;
     std::vector<void*> host_allocs;       // state of a single-wavefront handle kept in GPU-addressable host memory (hostres)
     uint8_t* mask_pin = nullptr; uint8_t* mask_pin_dev = nullptr;   // ngw_reset's mask: two page-locked halves the kernel reads in place
@@ -483,6 +490,7 @@ int launch_refill(ngw_handle* h) {
 }
 
 int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, const uint8_t* mask_dev, uint64_t action_seed, int64_t t0) {
+    h->mirror_valid = false;                          // (ngw_step_host's delta path sets it again after its own launch)
     NgwLaunch a = h->proto;
     a.b = h->b;
     a.mode = mode;
@@ -540,13 +548,25 @@ int rollout_chunks(ngw_handle* h, int mode, int32_t n_steps, const int32_t* acti
     return NGW_OK;
 }
 
+// One page-locked block for everything ngw_step_host returns.  Sections (index: 0 map, 1 agent_location, 2 agent_facing_id,
+// 3 inventory, 4 reward, 5 done, 6 info words, 7 error flags, 8 selected, 9 step_count) are padded to 256 bytes and lie in
+// memory in the order map | inventory | selected | agent_location | agent_facing_id | reward | done | info | flags | step_count:
+// the first three change by a few bytes per step and are refreshed by deltas, the rest is one contiguous copy.
+constexpr int HS_ORDER[10] = {0, 3, 8, 1, 2, 4, 5, 6, 7, 9};
+constexpr int HS_DENSE_FIRST = 1;                       // section index (agent_location) the contiguous dense part starts with
+void host_step_layout(const ngw_handle* h, uint64_t off[11]) {
+    const uint64_t n = (uint64_t)h->n, S2 = (uint64_t)h->proto.S2, K = (uint64_t)h->proto.K;
+    const uint64_t bytes[10] = {n * S2, n * 8, n * 4, n * K * 4, n * 4, n, n * 4, 4, n, n * 4};
+    uint64_t o = 0;
+    for (int k = 0; k < 10; k++) { const int i = HS_ORDER[k]; off[i] = o; o += (bytes[i] + 255) & ~(uint64_t)255; }
+    off[10] = o;
+}
+
 // Are the output arrays of ngw_step_host the sections of one block laid out as ngw_host_step_layout says (base = map)?
 bool one_block(const ngw_handle* h, const void* map, const void* loc, const void* facing, const void* inv, const void* reward, const void* done,
                const void* flags, const void* selected, const void* step_count) {
-    const uint64_t n = (uint64_t)h->n, S2 = (uint64_t)h->proto.S2, K = (uint64_t)h->proto.K;
-    const uint64_t bytes[10] = {n * S2, n * 8, n * 4, n * K * 4, n * 4, n, n * 4, 4, n, n * 4};
-    uint64_t off[10], o = 0;
-    for (int i = 0; i < 10; i++) { off[i] = o; o += (bytes[i] + 255) & ~(uint64_t)255; }
+    uint64_t off[11];
+    host_step_layout(h, off);
     const uint8_t* b = static_cast<const uint8_t*>(map);
     const void* const got[10] = {map, loc, facing, inv, reward, done, nullptr, flags, selected, step_count};
     for (int i = 1; i < 10; i++)
@@ -600,6 +620,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     if (const char* v = getenv("NGW_LEAN")) h->lean = atoi(v) != 0;
     if (const char* v = getenv("NGW_FAST_RESET")) h->fast_reset = atoi(v);
     if (const char* v = getenv("NGW_ADAPT_PREFETCH")) h->adapt = atoi(v) != 0;
+    if (const char* v = getenv("NGW_HOST_DELTA")) h->host_delta = atoi(v) != 0;
     {
         int min_s2 = 256;                                  // 16 x 16 and larger (measured: see DESIGN.md)
         if (const char* v = getenv("NGW_NOSTAGE")) min_s2 = atoi(v);
@@ -1074,19 +1095,15 @@ int ngw_get_step_out(ngw_handle* h, int32_t* reward, uint8_t* done, uint8_t* res
     return NGW_OK;
 }
 
-/* One page-locked block for everything ngw_step_host returns: sections padded to 256 bytes, in the order map | agent_location |
- * agent_facing_id | inventory | reward | done | info words | error flags | selected | step_count; offsets11[10] = block size. */
-static void host_step_layout(const ngw_handle* h, uint64_t off[11]) {
-    const uint64_t n = (uint64_t)h->n, S2 = (uint64_t)h->proto.S2, K = (uint64_t)h->proto.K;
-    const uint64_t bytes[10] = {n * S2, n * 8, n * 4, n * K * 4, n * 4, n, n * 4, 4, n, n * 4};
-    uint64_t o = 0;
-    for (int i = 0; i < 10; i++) { off[i] = o; o += (bytes[i] + 255) & ~(uint64_t)255; }
-    off[10] = o;
-}
-
 int ngw_host_step_layout(ngw_handle* h, uint64_t* offsets11) {
     if (!h || !offsets11) return fail(NGW_E_INVALID_ARG, "NULL argument");
     host_step_layout(h, offsets11);
+    return NGW_OK;
+}
+
+int ngw_host_mirror_invalidate(ngw_handle* h) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    h->mirror_valid = false;
     return NGW_OK;
 }
 
@@ -1146,24 +1163,59 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
         if (error_flags) *error_flags = *h->b.flags_host;             // sticky: ngw_error_flags reads and clears it (with the device word)
         if (want_info) info_words = h->b.info;
     } else if (total > NGW_ZERO_COPY_BYTES && map && one_block(h, map, loc, facing, inv, reward, done, error_flags, selected, step_count)) {
-        // Big batch whose output arrays are the sections of ONE page-locked block (ngw_host_step_layout): the device packs
-        // everything into a staging payload with one launch and ONE copy brings it across PCIe - nine separate copies pay
-        // their fixed cost nine times (65 536 envs: 489 -> ~300 us per step).
+        // Big batch whose output arrays are the sections of ONE page-locked block (ngw_host_step_layout).  The caller keeps that
+        // block from call to call (VecNovelGridworld's host mirrors), so it already holds the previous step's observation:
+        //   * map, inventory and selected rows change by a few bytes per env and step.  The device keeps a shadow of what the
+        //     block holds; one launch compares, 16 bytes at a time, and writes only the pieces that differ - to the shadow and
+        //     straight into the block across PCIe (~1 % of the 9 MB a full copy moves at 65 536 envs);
+        //   * pose, reward, done, info, flags and step_count change for (nearly) every env: they are packed into a staging
+        //     payload with one launch and ONE copy brings them across (26 B per env).
+        // A step costs 1.7 MB + the deltas instead of 10 MB of PCIe traffic.  The first call on a block, and the first one after
+        // anything else touched the state (ngw_reset, ngw_set_state, device steps, rollouts, graph replays), copies everything
+        // and re-seeds the shadows; NGW_HOST_DELTA=0 makes every call do that.
         uint64_t off[11];
         host_step_layout(h, off);
         if (!h->step_stage) { if (int rc = dev_alloc(h, &h->step_stage, (size_t)off[10])) return rc; }
+        const bool delta = h->host_delta && h->mirror_valid && h->mirror_block == map;
         HIP_TRY(hipMemcpyAsync(h->actions_dev, actions_host, n * sizeof(int32_t), hipMemcpyDefault, h->stream));
         if (int rc = launch(h, NGW_MODE_STEP, 1, h->actions_dev, nullptr, 0, 0)) return rc;
         const void* const srcs[10] = {h->b.map, h->b.loc, h->b.facing, h->b.inv, h->b.reward, h->b.done, h->b.info, h->b.flags, h->b.selected, h->b.step_count};
         const uint64_t nb[10] = {n * S2, n * 8, n * 4, n * K * 4, n * 4, n, n * 4, 4, n, n * 4};
+        constexpr int SPARSE[3] = {0, 3, 8};                      // map, inventory, selected: the sections refreshed by deltas
         NgwPack p = {};
         for (int r = 0; r < 10; r++) {
-            p.src[r] = static_cast<const uint8_t*>(srcs[r]); p.dst[r] = h->step_stage + off[r]; p.nbytes[r] = nb[r];
+            if (delta && (r == 0 || r == 3 || r == 8)) continue;
+            p.src[p.n_regions] = static_cast<const uint8_t*>(srcs[r]); p.dst[p.n_regions] = h->step_stage + off[r]; p.nbytes[p.n_regions] = nb[r];
+            p.n_regions++;
         }
-        p.n_regions = 10;
-        HIP_TRY(ngw_pack_launch(&p, h->stream));
-        HIP_TRY(hipMemcpyAsync(map, h->step_stage, (size_t)off[10], hipMemcpyDefault, h->stream));
+        if (delta) {
+            NgwDiff d = {};
+            for (int k = 0; k < 3; k++) {
+                const int r = SPARSE[k];
+                d.cur[k] = static_cast<const uint8_t*>(srcs[r]); d.shadow[k] = h->shadow[k]; d.host[k] = h->mirror_dev + off[r]; d.nbytes[k] = nb[r];
+            }
+            d.n_regions = 3;
+            HIP_TRY(ngw_diff_launch(&d, h->stream));
+            HIP_TRY(ngw_pack_launch(&p, h->stream));
+            const uint64_t d0 = off[HS_DENSE_FIRST];
+            HIP_TRY(hipMemcpyAsync(reinterpret_cast<uint8_t*>(map) + d0, h->step_stage + d0, (size_t)(off[10] - d0), hipMemcpyDefault, h->stream));
+        } else {
+            HIP_TRY(ngw_pack_launch(&p, h->stream));
+            HIP_TRY(hipMemcpyAsync(map, h->step_stage, (size_t)off[10], hipMemcpyDefault, h->stream));
+            if (h->host_delta) {                                      // (re-)seed the shadows: the block mirrors the state from here on
+                void* dev = nullptr;
+                bool ok = hipHostGetDevicePointer(&dev, map, 0) == hipSuccess && dev;
+                if (!ok) (void)hipGetLastError();                     // (a block that is not mapped into the GPU's address space: full copies)
+                for (int k = 0; k < 3 && ok; k++) {
+                    const int r = SPARSE[k];
+                    if (!h->shadow[k]) ok = dev_alloc(h, &h->shadow[k], (size_t)((nb[r] + 255) & ~(uint64_t)255)) == NGW_OK;
+                    if (ok) HIP_TRY(hipMemcpyAsync(h->shadow[k], srcs[r], (size_t)nb[r], hipMemcpyDeviceToDevice, h->stream));
+                }
+                h->mirror_block = ok ? map : nullptr; h->mirror_dev = static_cast<uint8_t*>(dev);
+            }
+        }
         HIP_TRY(hipStreamSynchronize(h->stream));
+        h->mirror_valid = h->host_delta && h->mirror_block == map;
         if (want_info) info_words = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(map) + off[6]);
     } else if (total <= NGW_ZERO_COPY_BYTES) {
         // Small batch: no copy calls at all.  The kernel reads the actions from, and a pack kernel writes every output into,
@@ -1331,6 +1383,7 @@ int ngw_set_state(ngw_handle* h, int64_t first, int64_t count, const int8_t* map
         }
     }
     HIP_TRY(hipSetDevice(h->device));
+    h->mirror_valid = false;
     H2D(h->b.map + f * S2, map, n * S2);
     H2D(h->b.loc + f * 2, loc, n * 2 * sizeof(int32_t));
     H2D(h->b.facing + f, facing, n * sizeof(int32_t));
@@ -1608,6 +1661,7 @@ int ngw_graph_launch(ngw_handle* h, int32_t reps) {
             const int32_t* acts = h->graph_actions; const int64_t stride = h->graph_stride; const int32_t k = h->graph_steps;
             if (int rc = capture_graph(h, acts, stride, k)) return rc;
         }
+        h->mirror_valid = false;
         HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
     }
     return NGW_OK;

@@ -230,6 +230,20 @@ struct NgwPack {
 extern "C"
 #endif
 hipError_t ngw_pack_launch(const struct NgwPack* p, hipStream_t stream);
+/* Delta refresh of the host mirrors (ngw_step_host on big batches): per region the live array, the device-side shadow of what
+ * the host holds, and the host mirror itself as a mapped pointer; pieces of 16 bytes that differ are written to both. */
+#define NGW_DIFF_MAX 4
+struct NgwDiff {
+    const uint8_t* cur[NGW_DIFF_MAX];
+    uint8_t* shadow[NGW_DIFF_MAX];
+    uint8_t* host[NGW_DIFF_MAX];
+    uint64_t nbytes[NGW_DIFF_MAX];
+    int32_t n_regions;
+};
+#ifdef __cplusplus
+extern "C"
+#endif
+hipError_t ngw_diff_launch(const struct NgwDiff* p, hipStream_t stream);
 #ifdef __cplusplus
 extern "C"
 #endif

@@ -1216,6 +1216,29 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const NgwLidarDev* _
                 a.l_i16 != 0, tid);   // out is padded to n_pad rows
 }
 
+// Delta refresh of a host mirror (NgwDiff, ngw_step_host): region blockIdx.y is compared, 16 bytes at a time, with the shadow
+// copy of what the host holds; only pieces that differ are stored - to the shadow, and straight into the host's page-locked
+// mirror across PCIe (mapped memory).  A step changes a few bytes of an env's map / inventory, so this moves ~1 % of what a
+// full copy moves.  Regions are 16-byte aligned on all three sides; a tail shorter than 16 bytes goes by bytes.
+__global__ __launch_bounds__(256) void ngw_diff_kernel(const NgwDiff p) {
+    const int r = blockIdx.y;
+    const uint64_t nb = p.nbytes[r];
+    const uint8_t* c = p.cur[r];
+    uint8_t* s = p.shadow[r];
+    uint8_t* h = p.host[r];
+    const uint64_t stride = (uint64_t)gridDim.x * 256u, t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t n16 = nb >> 4;
+    for (uint64_t i = t; i < n16; i += stride) {
+        const u32x4 a = reinterpret_cast<const u32x4*>(c)[i], b = reinterpret_cast<const u32x4*>(s)[i];
+        if (a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w) {
+            reinterpret_cast<u32x4*>(s)[i] = a;
+            reinterpret_cast<u32x4*>(h)[i] = a;
+        }
+    }
+    for (uint64_t i = (n16 << 4) + t; i < nb; i += stride)
+        if (c[i] != s[i]) { s[i] = c[i]; h[i] = c[i]; }
+}
+
 // Region copies (NgwPack): region blockIdx.y, grid-stride over 16-byte pieces; tails and unaligned regions go by bytes.
 // The destination may be host memory mapped into the GPU's address space (the stores then travel over PCIe).
 __global__ __launch_bounds__(256) void ngw_pack_kernel(const NgwPack p) {
@@ -1268,6 +1291,17 @@ extern "C" hipError_t ngw_pack_launch(const NgwPack* p, hipStream_t stream) {
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(ngw_pack_kernel, dim3((unsigned)blocks, (unsigned)p->n_regions), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t ngw_diff_launch(const NgwDiff* p, hipStream_t stream) {
+    if (p->n_regions < 1) return hipSuccess;
+    uint64_t most = 0;
+    for (int r = 0; r < p->n_regions; r++) most = p->nbytes[r] > most ? p->nbytes[r] : most;
+    uint64_t blocks = (most / 16u + 255u) / 256u;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ngw_diff_kernel, dim3((unsigned)blocks, (unsigned)p->n_regions), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
 

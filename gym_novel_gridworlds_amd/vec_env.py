@@ -25,45 +25,54 @@ class _DevArray:
 
 
 class StepInfo(dict):
-    """info of a batched step: 'result' bool[N], 'step_cost_code', 'message_code', 'message_arg' - and 'step_cost' f64[N], which is
-    looked up from the codes when it is first asked for (a 65 536-element gather per step costs more than the step kernel; few
-    callers read it).  Behaves as a dict that has the key."""
+    """info of a batched step: 'result' bool[N], 'step_cost_code', 'message_code', 'message_arg' - and 'step_cost' f64[N].  Fields
+    that are not there yet are made when they are first asked for: 'step_cost' is looked up from the codes (a 65 536-element
+    gather per step costs more than the step kernel; few callers read it), and on big batches all four code arrays are
+    decoded from the packed info words ('_words', include/ngw.h NGW_INFO_*) only then - the C-side decode of 65 536 words
+    costs 40 us per step, and a rollout loop reads reward and done.  Behaves as a dict that has the keys."""
     __slots__ = ()
+    LAZY = ('result', 'step_cost_code', 'message_code', 'message_arg', 'step_cost')
 
     def __missing__(self, key):
-        if key == 'step_cost':
-            v = _COST_F64[dict.__getitem__(self, 'step_cost_code')]
+        if key in StepInfo.LAZY:
+            if key == 'step_cost':
+                v = _COST_F64[self['step_cost_code']]
+            else:
+                w = dict.__getitem__(self, '_words')
+                v = {'result': lambda: (w & 1).astype(np.bool_), 'step_cost_code': lambda: ((w >> 2) & 63).astype(np.uint8),
+                     'message_code': lambda: ((w >> 8) & 255).astype(np.uint16), 'message_arg': lambda: (w >> 16).astype(np.uint16)}[key]()
             dict.__setitem__(self, key, v)
             return v
         raise KeyError(key)
 
     def __contains__(self, key):
-        return key == 'step_cost' or dict.__contains__(self, key)
+        return key in StepInfo.LAZY or dict.__contains__(self, key)
 
     def get(self, key, default=None):
         return self[key] if key in self else default
 
     def _all(self):
-        self['step_cost']
+        for k in StepInfo.LAZY:
+            self[k]
         return self
 
     def keys(self):
-        return dict.keys(self._all())
+        return [k for k in dict.keys(self._all()) if k != '_words']
 
     def items(self):
-        return dict.items(self._all())
+        return [(k, v) for k, v in dict.items(self._all()) if k != '_words']
 
     def values(self):
-        return dict.values(self._all())
+        return [v for k, v in dict.items(self._all()) if k != '_words']
 
     def __iter__(self):
-        return dict.__iter__(self._all())
+        return iter(self.keys())
 
     def __len__(self):
-        return dict.__len__(self._all())
+        return len(self.keys())
 
     def copy(self):
-        return StepInfo(dict(dict.items(self)))
+        return StepInfo(dict(self.items()))
 
 
 class VecNovelGridworld:
@@ -127,7 +136,7 @@ class VecNovelGridworld:
         self._open(spec)
         return self
 
-    _HOST_ATTRS = ('_obs', '_reward', '_done', '_act_pinned', '_sel_host', '_steps_host', '_result', '_cost', '_msg', '_arg', '_flags_np')
+    _HOST_ATTRS = ('_obs', '_reward', '_done', '_act_pinned', '_sel_host', '_steps_host', '_result', '_cost', '_msg', '_arg', '_flags_np', '_info_words')
 
     def __getattr__(self, name):
         # The host mirrors (10 MB page-locked at 65 536 envs, 157 B per env) exist only for the host API; a handle that is
@@ -148,6 +157,8 @@ class VecNovelGridworld:
                     _obs={'map': sec(0, (N, S, S), np.int8), 'agent_location': sec(1, (N, 2), np.int32),
                           'agent_facing_id': sec(2, (N,), np.int32), 'inventory_items_quantity': sec(3, (N, K), np.int32)},
                     _reward=sec(4, (N,), np.int32), _done=sec(5, (N,), np.uint8), _flags_np=sec(7, (1,), np.uint32),
+                    # the packed info words of the last step(): big batches (the one-block path of ngw_step_host) decode them lazily
+                    _info_words=sec(6, (N,), np.uint32) if self._one_block_path() else None,
                     _sel_host=sec(8, (N,), np.uint8), _steps_host=sec(9, (N,), np.int32),     # selected item / step_count after the last step()
                     _act_pinned=_cabi.pinned_array((N,), np.int32),
                     _result=np.zeros(N, np.uint8), _cost=np.zeros(N, np.uint8), _msg=np.zeros(N, np.uint16), _arg=np.zeros(N, np.uint16))
@@ -206,20 +217,40 @@ class VecNovelGridworld:
         args = cache.get(bool(with_obs))
         if args is None:                                             # the host arrays never move: the argument list is built once
             p = _cabi._ptr
+            lazy = with_obs and self._info_words is not None         # big batch, one-block path: info decoded on demand from the words
             args = cache[bool(with_obs)] = (
                 self._h, p(self._act_pinned, np.int32), p(o['map'], np.int8) if with_obs else None, p(o['agent_location'], np.int32),
                 p(o['agent_facing_id'], np.int32), p(o['inventory_items_quantity'], np.int32), p(self._reward, np.int32),
-                p(self._done, np.uint8), p(self._result, np.uint8), p(self._cost, np.uint8), p(self._msg, np.uint16), p(self._arg, np.uint16),
+                p(self._done, np.uint8), None if lazy else p(self._result, np.uint8), None if lazy else p(self._cost, np.uint8),
+                None if lazy else p(self._msg, np.uint16), None if lazy else p(self._arg, np.uint16),
                 p(self._flags_np, np.uint32), p(self._sel_host, np.uint8), p(self._steps_host, np.int32))
         rc = _cabi.lib().ngw_step_host(*args)                        # actions in, launch, observation + outputs out: one sync
         if rc:
             _cabi.check(rc)
         self._last_actions = a
         obs = None if not with_obs else ({k: v.copy() for k, v in o.items()} if copy else o)
-        reward, done, info = self._step_out_views(copy)
+        if with_obs and self._info_words is not None:
+            reward, done = (self._reward.copy(), self._done.view(np.bool_).copy()) if copy else (self._reward, self._done.view(np.bool_))
+            info = StepInfo({'_words': self._info_words.copy() if copy else self._info_words})
+        else:
+            reward, done, info = self._step_out_views(copy)
         if self._flags_np[0]:
             self._raise_flags()
         return obs, reward, done, info
+
+    def _one_block_path(self):
+        """Does ngw_step_host take its one-block path (pack + one copy, delta refresh) for this env's full step()?  The rule of
+        ngw_abi.cpp: more than one wavefront of envs and more output bytes than the zero-copy limit (NGW_ZC_BYTES, 256 KiB)."""
+        import os
+        n, S2, K = self.num_envs, self.map_size ** 2, self.n_items
+        total = sum((b + 255) & ~255 for b in (n * S2, n * 8, n * 4, n * K * 4, n * 4, n, 4, n, n * 4))
+        zc = int(os.environ.get('NGW_ZC_BYTES', 256 << 10)) or 1
+        return n > 64 and total > zc
+
+    def refresh_host(self):
+        """The next step() copies the whole observation to the host again instead of only what changed since the last step()
+        (include/ngw.h ngw_host_step_layout) - call it after writing into the host arrays step() returned."""
+        _cabi.check(_cabi.lib().ngw_host_mirror_invalidate(self._h))
 
     def step1(self, action):
         """step() of a one-env handle for the gym.Env adapter: same C-ABI call, but the argument list is built once and the

@@ -259,9 +259,18 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
                   uint8_t* selected /* item id, 0 = '' */, int32_t* step_count);
 /* Big batches: when the output arrays handed to ngw_step_host are the sections of ONE page-locked block laid out as this call
  * says (offsets11[0..9] = byte offsets of map | agent_location | agent_facing_id | inventory | reward | done | info words
- * (internal) | error flags | selected | step_count from the block's start, each section padded to 256 bytes; offsets11[10] =
- * block size; allocate it with ngw_host_alloc), the device packs every output with one launch and ONE copy crosses PCIe. */
+ * (internal) | error flags | selected | step_count from the block's start, each section padded to 256 bytes - in memory the
+ * sections lie in the order map, inventory, selected, then the rest; offsets11[10] = block size; allocate it with
+ * ngw_host_alloc) AND the caller hands in the same block call after call (it is his mirror of the observation), a step moves
+ * only what changed: the pose / reward / done / info / step_count sections with ONE copy (26 B per env), and of the map,
+ * inventory and selected rows only the 16-byte pieces that differ from what the block already holds - the device keeps a
+ * shadow of the block's content and writes the differing pieces straight into it across PCIe.  The first call on a block, and
+ * the first one after anything else touched the state (ngw_reset, ngw_set_state, device steps, rollouts, graph replays) or
+ * after ngw_host_mirror_invalidate, copies the whole observation; NGW_HOST_DELTA=0 in the environment makes every call do so.
+ * The block must not be written by the caller between calls. */
 int ngw_host_step_layout(ngw_handle* h, uint64_t* offsets11);
+/* The next ngw_step_host copies the whole observation again (e.g. after the caller wrote into his block). */
+int ngw_host_mirror_invalidate(ngw_handle* h);
 /* Fused bench mode: T steps in one launch with on-device uniform actions
  * a(t, env) = (word (t & 3) of philox(action_seed; t >> 2, env) * A) >> 32; state stays in LDS/registers between
  * steps and every step's changes are written through to the observation buffers. */

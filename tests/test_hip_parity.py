@@ -657,6 +657,54 @@ def test_big_batch_host_step_uses_one_block_and_matches_oracle():
     assert_state_equal(v, o, 'one-block host steps')
 
 
+@pytest.mark.parametrize('cfg,n,horizon', [('pogo10', 40000, 9), ('axe10', 20000, 40), ('add32', 4096, 15), ('pogo13', 30000, 11), ('crate10m', 20000, 25)])
+def test_host_step_delta_refresh_matches_oracle(cfg, n, horizon):
+    """ngw_step_host on a big batch moves only what changed (include/ngw.h ngw_host_step_layout): the host observation equals
+    the oracle's after EVERY step - through in-step resets, entity pick-ups and crates, odd row sizes - and after everything
+    that invalidates the mirror in between (explicit resets, device steps, a fused rollout, state injection, refresh_host)."""
+    import torch
+    spec = T.build_spec(cfg)
+    A = len(spec.actions_id)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=16, autoreset=True, horizon=horizon)
+    o = Oracle(spec.compile(), n, seed=16, autoreset=True, horizon=horizon)
+    v.reset(); o.reset()
+    stag = (np.arange(n) * 7919 % horizon).astype(np.int32)
+    v.set_state(0, step_count=stag); o.st.step_count[:] = stag
+    rs = np.random.RandomState(2)
+
+    def host_equals_oracle(obs, where):
+        assert (obs['map'].reshape(n, -1) == o.st.map).all() and (obs['agent_location'] == o.st.loc).all(), where
+        assert (obs['agent_facing_id'] == o.st.facing).all() and (obs['inventory_items_quantity'] == o.st.inv).all(), where
+        ls = v.last_state()
+        assert (ls['selected'] == o.st.selected).all() and (ls['step_count'] == o.st.step_count).all(), where
+
+    for t in range(60):
+        if t == 20:
+            mask = (np.arange(n) % 7 == 3).astype(np.uint8)
+            v.reset(mask); o.reset(mask)
+        if t == 30:
+            acts = torch.randint(0, A, (3, n), dtype=torch.int32, device='cuda')
+            torch.cuda.synchronize()
+            v.step_device_many(acts.data_ptr(), n, 3)
+            for i in range(3):
+                o.step(acts[i].cpu().numpy())
+        if t == 40:
+            v.rollout(7, action_seed=5, t0=0); o.rollout(7, 5, 0)
+        if t == 45:
+            inv = o.st.inv.copy(); inv[::4, 2] += 3
+            v.set_state(0, inv=inv); o.st.inv[:] = inv
+        if t == 50:
+            v._obs['map'][...] = 0                                      # the caller scribbles over the block ...
+            v.refresh_host()                                            # ... and says so
+        a = rs.randint(0, A, size=n).astype(np.int32)
+        obs, reward, done, info = v.step(a); o.step(a)
+        assert (reward == o.reward).all() and (done == o.done.astype(bool)).all(), t
+        assert (info['message_code'] == o.msg_code).all() and (info['message_arg'] == o.msg_arg).all(), t
+        host_equals_oracle(obs, '%s step %d' % (cfg, t))
+    assert o.st.episode.min() >= 2 and v.error_flags() == 0
+    assert_state_equal(v, o, cfg + ' delta host steps')
+
+
 def test_refill_cadence_adapts_to_short_episodes_and_results_stay_exact():
     """Default prepared-episode setting: under FireWall an env ends several episodes between two refills, the stale rows are
     counted on the device and the host first keeps more episodes prepared per env (2, then 4), then shortens the refill
