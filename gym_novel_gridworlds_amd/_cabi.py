@@ -23,7 +23,7 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_get_lidar', 'ngw_lidar_device_ptr', 'ngw_host_alloc', 'ngw_host_free', 'ngw_agent_view',
            'ngw_get_agent_view', 'ngw_agent_view_device_ptr', 'ngw_set_reset_prefetch', 'ngw_step_host', 'ngw_lidar_set_output', 'ngw_rollout_actions',
            'ngw_pack_layout', 'ngw_pack_obs', 'ngw_unpack_obs', 'ngw_rollout_outputs', 'ngw_episode_stats', 'ngw_host_step_layout', 'ngw_step_device_many',
-           'ngw_set_reset_prefetch_depth', 'ngw_get_reset_prefetch_depth', 'ngw_stream_order', 'ngw_host_mirror_invalidate']
+           'ngw_set_reset_prefetch_depth', 'ngw_get_reset_prefetch_depth', 'ngw_stream_order', 'ngw_host_mirror_invalidate', 'ngw_reset_host']
 
 _lib = None
 
@@ -85,6 +85,8 @@ def lib():
     if hasattr(L, 'ngw_set_reset_prefetch'):           # absent only in older builds loaded through NGW_LIB (A/B runs)
         L.ngw_set_reset_prefetch.argtypes = [vp, i32]
     L.ngw_reset.argtypes = [vp, vp]
+    if hasattr(L, 'ngw_reset_host'):
+        L.ngw_reset_host.argtypes = [vp] + [vp] * 8
     L.ngw_step.argtypes = [vp, vp]
     L.ngw_step_device.argtypes = [vp, vp]
     if hasattr(L, 'ngw_step_device_many'):

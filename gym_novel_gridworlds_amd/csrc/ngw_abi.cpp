@@ -374,6 +374,7 @@ int launch_reset_fast(ngw_handle* h, int mode, const uint8_t* mask_dev, bool* ta
     if (h->rf_nw < 0 || h->lidar_fused) return NGW_OK;
     NgwResetFast a = h->rf;
     a.main = h->b; a.nx = h->prefetch_every > 0 ? h->nx : NgwNx{}; a.mode = mode; a.reset_mask = mask_dev; a.stamps = h->proto.stamps;
+    a.seq = mode == NGW_MODE_RESET ? h->launch_seq : 0u;
     HIP_TRY(ngw_reset_fast_launch(h->dspec, &a, h->rf_nw, h->rf_additem, (unsigned)(h->n_pad / NGW_EPB), h->rf_lds, h->stream));
     *taken = true;
     return NGW_OK;
@@ -585,6 +586,11 @@ void drop_graph(ngw_handle* h) {
 }  // namespace
 
 extern "C" {
+
+#define D2H(dst, src, bytes)                                                                             \
+    do {                                                                                                 \
+        if (dst) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDefault, h->stream));        \
+    } while (0)
 
 int ngw_abi_version(void) { return NGW_ABI_VERSION; }
 int ngw_spec_size(void) { return (int)sizeof(ngw_spec); }
@@ -925,6 +931,53 @@ int ngw_reset(ngw_handle* h, const uint8_t* mask_host) {
     return rc;
 }
 
+int ngw_reset_host(ngw_handle* h, const uint8_t* mask_host, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv, uint8_t* selected,
+                   int32_t* step_count, uint32_t* error_flags) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)h->n, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
+    if (h->hostres && !mask_host) {
+        // State in GPU-addressable host memory: ONE launch, completion polled on the word the reset kernel writes when its stores
+        // are out (the refill that re-prepares the consumed episode follows on the stream and is NOT waited for), results read in place.
+        h->step_seq = h->step_seq + 1u ? h->step_seq + 1u : 1u;
+        h->launch_seq = h->step_seq;
+        const int lrc = launch(h, NGW_MODE_RESET, 1, nullptr, nullptr, 0, 0);
+        h->launch_seq = 0;
+        if (lrc) return lrc;
+        volatile uint32_t* sp = h->b.flags_host + NGW_SEQ_WORD;
+        bool seen = false;
+        for (uint32_t spin = 0; spin < (1u << 21); spin++) {
+            if (*sp == h->step_seq) { seen = true; break; }
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#else
+            __asm__ __volatile__("" ::: "memory");
+#endif
+        }
+        if (!seen) HIP_TRY(hipStreamSynchronize(h->stream));
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (map) memcpy(map, h->b.map, n * S2);
+        if (loc) memcpy(loc, h->b.loc, n * 8);
+        if (facing) memcpy(facing, h->b.facing, n * 4);
+        if (inv) memcpy(inv, h->b.inv, n * K * 4);
+        if (selected) memcpy(selected, h->b.selected, n);
+        if (step_count) memcpy(step_count, h->b.step_count, n * 4);
+        if (error_flags) *error_flags = *h->b.flags_host;             // sticky: ngw_error_flags reads and clears it (with the device word)
+        return NGW_OK;
+    }
+    if (int rc = ngw_reset(h, mask_host)) return rc;
+    D2H(map, h->b.map, n * S2);
+    D2H(loc, h->b.loc, n * 2 * sizeof(int32_t));
+    D2H(facing, h->b.facing, n * sizeof(int32_t));
+    D2H(inv, h->b.inv, n * K * sizeof(int32_t));
+    D2H(selected, h->b.selected, n);
+    D2H(step_count, h->b.step_count, n * sizeof(int32_t));
+    if (error_flags) HIP_TRY(hipMemcpyAsync(error_flags, h->b.flags, sizeof(uint32_t), hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (error_flags && h->b.flags_host) *error_flags |= *h->b.flags_host;
+    return NGW_OK;
+}
+
 int ngw_step(ngw_handle* h, const int32_t* actions_host) {
     if (!h || !actions_host) return fail(NGW_E_INVALID_ARG, "NULL argument");
     const int A = h->spec.n_actions;
@@ -1054,10 +1107,6 @@ static size_t zero_copy_bytes() {
 }
 #define NGW_ZERO_COPY_BYTES zero_copy_bytes()
 
-#define D2H(dst, src, bytes)                                                                             \
-    do {                                                                                                 \
-        if (dst) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDefault, h->stream));        \
-    } while (0)
 
 int ngw_get_obs(ngw_handle* h, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");

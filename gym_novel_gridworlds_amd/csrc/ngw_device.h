@@ -188,6 +188,7 @@ struct NgwResetFast {            // kernel arguments (by value)
     int32_t mode;                // NGW_MODE_RESET / NGW_MODE_REFILL
     int32_t S, S2, K, CW, n_place, wall_item;
     int32_t additem_item, additem_span;   // the subset pass: item written, width of its percent range
+    uint32_t seq;                // host-resident handles: written to flags_host[NGW_SEQ_WORD] when an explicit reset's stores are out (0 = do not)
     int32_t pass_wall;           // the subset pass replaces WALL cells (ReplaceItem / FireWall of the ring) instead of filling air cells
     int32_t n_inv_start;
     uint32_t inv_start_items, inv_start_qtys;   // 4 bytes each

@@ -1129,7 +1129,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     }
     if (flags) atomicOr(a.b.flags, flags);
     raise_host_flags(a.b.flags_host, flags);
-    if (MODE == NGW_MODE_STEP) signal_host_seq(a.b.flags_host, a.seq);
+    if (MODE == NGW_MODE_STEP || MODE == NGW_MODE_RESET) signal_host_seq(a.b.flags_host, a.seq);
 #ifdef NGW_STAMPS
     STAMP(5);
     __builtin_amdgcn_s_waitcnt(0);                                                 // every store acknowledged

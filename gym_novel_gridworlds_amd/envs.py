@@ -88,7 +88,8 @@ class _NovelGridworldEnv(_EnvBase):
     # ------------------------------------------------------------------ backend
     def _make_backend(self, spec, seed):
         """The one place the adapter creates its one-env device handle."""
-        return VecNovelGridworld(spec=spec, num_envs=1, seed=seed)
+        # (prepared next episodes, refilled only after an explicit reset: reset() then copies a row instead of running the placement loop)
+        return VecNovelGridworld(spec=spec, num_envs=1, seed=seed, reset_prefetch=1 << 20)
 
     def seed(self, seed=None):
         """The reference ignores seed() (global np.random); here it keys the device's per-episode Philox streams."""
@@ -257,8 +258,13 @@ class _NovelGridworldEnv(_EnvBase):
         self.last_reward = 0
         self.last_done = False
         vec = self._backend(full_check=True)
-        vec.reset()                                          # AssertionError(PLACEMENT_MESSAGE) when items do not fit
-        self._pull(vec)
+        reset1 = getattr(vec, 'reset1', None)
+        if reset1 is not None:                               # device handle: one C-ABI call that also brings the state back
+            reset1()                                         # AssertionError(PLACEMENT_MESSAGE) when items do not fit
+            self._pull(vec, vec.last_state())
+        else:
+            vec.reset()
+            self._pull(vec)
         obs = self.get_observation()
         self.update_block_in_front()
         return obs

@@ -131,7 +131,7 @@ class VecNovelGridworld:
         the env they wrap and keep its identity (novelty_wrappers.py:1586-1674), so a rank-local shard stays that shard.
         The state is undefined until the next reset(), as after construction."""
         self.close()
-        for name in VecNovelGridworld._HOST_ATTRS + ('_host', '_step_args', '_step1_args', '_step1_fn', '_last_state_views', '_lidar_host', '_view_host', '_last_actions'):
+        for name in VecNovelGridworld._HOST_ATTRS + ('_host', '_step_args', '_step1_args', '_step1_fn', '_reset1_args', '_last_state_views', '_lidar_host', '_view_host', '_last_actions'):
             self.__dict__.pop(name, None)
         self._open(spec)
         return self
@@ -201,6 +201,22 @@ class VecNovelGridworld:
         _cabi.check(_cabi.lib().ngw_reset(self._h, _cabi._ptr(m, np.uint8)))
         self._raise_flags()
         return self.get_observation(copy)
+
+    def reset1(self):
+        """reset() of a one-env handle for the gym.Env adapter: one C-ABI call (ngw_reset_host) that fills the host mirrors
+        last_state() shows; a placement that cannot succeed raises like reset()."""
+        args = self.__dict__.get('_reset1_args')
+        if args is None:
+            assert self.num_envs == 1
+            o, p = self._obs, _cabi._ptr
+            args = self._reset1_args = (self._h, None, p(o['map'], np.int8), p(o['agent_location'], np.int32), p(o['agent_facing_id'], np.int32),
+                                        p(o['inventory_items_quantity'], np.int32), p(self._sel_host, np.uint8), p(self._steps_host, np.int32),
+                                        p(self._flags_np, np.uint32))
+        rc = _cabi.lib().ngw_reset_host(*args)
+        if rc:
+            _cabi.check(rc)
+        if self._flags_np[0]:
+            self._raise_flags()
 
     def step(self, actions, copy=False, with_obs=True):
         """step(action_id) for every env: (obs, reward[N] i32, done[N] bool, info) with host arrays.

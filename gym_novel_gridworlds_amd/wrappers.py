@@ -9,7 +9,7 @@ the limited ids), so there is no per-step translation at all."""
 import copy
 import os
 import pickle
-from datetime import datetime
+import datetime as _datetime
 
 
 from . import spaces
@@ -17,56 +17,73 @@ from .novelty_wrappers import NoveltyWrapper
 from .vec_env import VecNovelGridworld
 
 
+# What a trajectory entry holds: (key in the pickled dict, attribute of the wrapped env it is read from), in the reference's
+# key order (wrappers.py:29-45); the twelfth key, "last_done", is read through the wrapper itself.
+_TRAJECTORY_FIELDS = (("map_size", "map_size"), ("map", "map"), ("agent_location", "agent_location"),
+                      ("agent_facing_str", "agent_facing_str"), ("block_in_front_id", "block_in_front_id"), ("items_id", "items_id"),
+                      ("items_quantity", "items_quantity"), ("inventory_items_quantity", "inventory_items_quantity"),
+                      ("action_str", "actions_id"), ("last_action", "last_action"))
+_TRAJECTORY_FILE = "%Y-%m-%d-%H-%M-%S"                       # + "_<env_id>.bin" (wrappers.py:49)
+
+
 class SaveTrajectories(NoveltyWrapper):
-    """Reference wrappers.py:9-54: after every step append a snapshot of the env's state; `save()` pickles the list to
-    `<save_path>/<timestamp>_<env_id>.bin`.  Host-side bookkeeping over the single-env adapter's attributes (the values
-    are references to the live objects, exactly as in the reference, so entries alias `env.map` until it is rebound)."""
+    """Reference wrappers.py:9-54: every step appends a snapshot of the env's public state, `save()` pickles the list to
+    `<save_path>/<timestamp>_<env_id>.bin`.  Host-side bookkeeping over the single-env adapter: the snapshot's values are the
+    live objects (as in the reference, entries alias `env.map` until the env rebinds it)."""
 
     def __init__(self, env, save_path):
-        super().__init__(env)
-        self.save_path = save_path
-        os.makedirs(self.save_path, exist_ok=True)
-        self.state_trajectories = []
-
-    def step(self, action_id):
-        obs, reward, done, info = self.env.step(action_id)
-        self.state_trajectories.append(self.get_state())
-        return obs, reward, done, info
+        NoveltyWrapper.__init__(self, env)
+        os.makedirs(save_path, exist_ok=True)
+        self.save_path, self.state_trajectories = save_path, []
 
     def get_state(self):
-        env = self.env
-        return {"map_size": env.map_size, "map": env.map, "agent_location": env.agent_location,           # :29-45
-                "agent_facing_str": env.agent_facing_str, "block_in_front_id": env.block_in_front_id,
-                "items_id": env.items_id, "items_quantity": env.items_quantity,
-                "inventory_items_quantity": env.inventory_items_quantity,
-                "action_str": env.actions_id, "last_action": env.last_action, "last_done": self.last_done}
+        wrapped = self.env
+        snapshot = {key: getattr(wrapped, attribute) for key, attribute in _TRAJECTORY_FIELDS}
+        snapshot["last_done"] = self.last_done
+        return snapshot
+
+    def step(self, action_id):
+        result = self.env.step(action_id)
+        self.state_trajectories.append(self.get_state())
+        return result
 
     def save(self):
-        path = os.path.join(self.save_path,
-                            datetime.now().strftime("%Y-%m-%d-%H-%M-%S") + "_{env}.bin".format(env=self.env.env_id))
+        name = "%s_%s.bin" % (_datetime.datetime.now().strftime(_TRAJECTORY_FILE), self.env.env_id)
+        path = os.path.join(self.save_path, name)
         with open(path, 'wb') as f:
-            pickle.dump(self.state_trajectories, f)
+            f.write(pickle.dumps(self.state_trajectories))
         print("Trajectories saved at: ", path)
         return path
 
 
+# The two AssertionError texts of the reference's LimitActions.step (wrappers.py:76-80); the first one really reads "maxaction"
+# (two string literals joined without a space).
+_BAD_LIMITED_ID = "Action ID {id} is not valid, maxaction ID is {top}"
+_NOT_AN_ACTION = "{name} is not a valid action for {env_id}"
+
+
 class LimitActions(NoveltyWrapper):
+    """Reference wrappers.py:57-85: the agent sees `len(limited_actions)` action ids, limited id i = the i-th name of
+    sorted(limited_actions).  A step is two table look-ups - limited id -> name in `limited_actions_id` (the FIRST name
+    holding that id, in table order: `remapaction` may install a table of its own), name -> the env's id in `actions_id`,
+    read through the wrapper stack so that a remapped or extended action table below is honoured."""
+
     def __init__(self, env, limited_actions):
-        super().__init__(env)
+        NoveltyWrapper.__init__(self, env)
         self.limited_actions = limited_actions
-        self.limited_actions_id = {action: i for i, action in enumerate(sorted(self.limited_actions))}   # wrappers.py:67
-        self.action_space = spaces.Discrete(len(self.limited_actions_id))
+        self.set_limited_actions_id(dict(zip(sorted(limited_actions), range(len(limited_actions)))))
+        self.action_space = spaces.Discrete(len(limited_actions))
 
     def set_limited_actions_id(self, limited_actions_id):
         self.limited_actions_id = limited_actions_id
 
     def step(self, action_id):
-        assert action_id in self.limited_actions_id.values(), "Action ID " + str(action_id) + " is not valid, max" \
-                                                              "action ID is " + str(len(self.limited_actions_id) - 1)
-        last_action = list(self.limited_actions_id.keys())[list(self.limited_actions_id.values()).index(action_id)]
-        assert last_action in self.actions_id, last_action + " is not a valid action for " + self.env_id
-        action_id = self.actions_id[last_action]
-        return self.env.step(action_id)
+        table = self.limited_actions_id
+        name = next((candidate for candidate, limited in table.items() if limited == action_id), None)
+        assert name is not None, _BAD_LIMITED_ID.format(id=action_id, top=len(table) - 1)
+        env_actions = self.actions_id
+        assert name in env_actions, _NOT_AN_ACTION.format(name=name, env_id=self.env_id)
+        return self.env.step(env_actions[name])
 
 
 def limit_actions_vec(venv, limited_actions):

@@ -240,6 +240,11 @@ int ngw_stream_order(ngw_handle* h, void* other_stream, int handle_waits);
 
 /* reset(): pogostick_v1_env.py:86-157 (+ AddItem.reset).  mask = NULL resets all envs, else mask[i] != 0. */
 int ngw_reset(ngw_handle* h, const uint8_t* mask_host);
+/* ngw_reset + the state it produced, in ONE call (any output may be NULL): what reset() of the host API returns.  For handles of at
+ * most one wavefront (the single-env gym.Env adapter) it waits for the reset kernel alone - not for the refill launch that
+ * re-prepares the consumed episode behind it - by polling a word the kernel writes when its stores are out. */
+int ngw_reset_host(ngw_handle* h, const uint8_t* mask_host, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv, uint8_t* selected,
+                   int32_t* step_count, uint32_t* error_flags);
 /* step(action_id): pogostick_v1_env.py:230-367 / AxeMedium.step.  Host actions are validated first
  * (NGW_E_INVALID_ACTION, nothing stepped - the reference raises before touching state). */
 int ngw_step(ngw_handle* h, const int32_t* actions_host);

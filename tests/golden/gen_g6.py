@@ -25,7 +25,9 @@ SEED = 20261004
 
 
 def main():
-    only = sys.argv[1:]
+    check = '--check' in sys.argv[1:]
+    only = [a for a in sys.argv[1:] if a != '--check']
+    bad = []
     for cfg, (n, item) in G6.items():
         if only and cfg not in only:
             continue
@@ -46,9 +48,19 @@ def main():
             hist[int(m.sum())] += 1
             r, c = base.agent_location
             agent[int(r) * S + int(c)] += 1
-        np.savez_compressed(os.path.join(HERE, 'g6_%s.npz' % cfg), n=np.int64(n), item=np.int64(item_id), freq=freq.astype(np.int32),
-                            hist=hist.astype(np.int32), agent=agent.astype(np.int32), seed=np.int64(SEED))
+        new = dict(n=np.int64(n), item=np.int64(item_id), freq=freq.astype(np.int32), hist=hist.astype(np.int32), agent=agent.astype(np.int32),
+                   seed=np.int64(SEED))
+        path = os.path.join(HERE, 'g6_%s.npz' % cfg)
+        if check:                                        # compare with the committed file instead of writing it
+            old = dict(np.load(path))
+            bad += ['g6_%s: %s differs' % (cfg, k) for k in new if k not in old or not np.array_equal(new[k], old[k])]
+        else:
+            np.savez_compressed(path, **new)
         print(cfg, 'resets', n, 'item', item, item_id, 'mean cells', float(freq.sum()) / n)
+    if check:
+        if bad:
+            sys.exit('FIXTURE CHECK FAILED:\n  ' + '\n  '.join(bad))
+        print('fixture check ok: G6')
 
 
 if __name__ == '__main__':

@@ -674,8 +674,36 @@ PLAN = {  # cfg: (reset seeds, traces, steps per trace, single-step cases, solve
 }
 
 
+CHECK = {'on': False, 'bad': []}
+
+
+def emit(name, out):
+    """Write a fixture - or, with --check, compare what was just generated with the committed file: same keys, same dtypes,
+    shapes and values (a hand-edited or stale .npz shows up here)."""
+    path = os.path.join(OUT, name + '.npz')
+    if not CHECK['on']:
+        np.savez_compressed(path, **out)
+        return
+    try:
+        old = dict(np.load(path))
+    except OSError as e:
+        CHECK['bad'].append('%s: %s' % (name, e))
+        return
+    for k in sorted(set(out) | set(old)):
+        if k not in old or k not in out:
+            CHECK['bad'].append('%s: key %s only in the %s' % (name, k, 'generated data' if k in out else 'committed file'))
+            continue
+        a, b = np.asarray(out[k]), old[k]
+        if a.dtype != b.dtype or a.shape != b.shape or not np.array_equal(a, b):
+            CHECK['bad'].append('%s: %s differs (%s %s vs committed %s %s)' % (name, k, a.dtype, a.shape, b.dtype, b.shape))
+
+
 def main():
-    only = sys.argv[1:]
+    """gen_golden.py [--check] [cfg ...]: regenerate (or, with --check, verify in memory) the fixtures of the named
+    configurations, or of all of them."""
+    args = sys.argv[1:]
+    CHECK['on'] = '--check' in args
+    only = [a for a in args if a != '--check']
     strings = Strings()
     sfile = os.path.join(OUT, 'spec.json')
     spec = json.load(open(sfile)) if (only and os.path.exists(sfile)) else {}
@@ -694,23 +722,39 @@ def main():
         gen_single_steps(cfg, nss, out, strings)
         got = gen_solved(cfg, nso, out, strings) if nso else 0
         spec['cfgs'][cfg].update(n_reset_seeds=nrs, n_traces=ntr, trace_len=T, n_single=nss, n_solved=got)
-        np.savez_compressed(os.path.join(OUT, cfg + '.npz'), **out)
+        emit(cfg, out)
         summary[cfg] = dict(done_steps_in_traces=dones, solved=got,
-                            bytes=os.path.getsize(os.path.join(OUT, cfg + '.npz')))
+                            bytes=os.path.getsize(os.path.join(OUT, cfg + '.npz')) if os.path.exists(os.path.join(OUT, cfg + '.npz')) else 0)
         print(cfg, summary[cfg], flush=True)
     if not only or 'c1loop' in only:
         out = {}
         gen_c1loop(6, out, strings)
-        np.savez_compressed(os.path.join(OUT, 'c1loop.npz'), **out)
+        emit('c1loop', out)
         spec['novelty_arg_errors'] = novelty_arg_errors()
         spec['novelty_arg_errors2'] = novelty_arg_errors2()
         lim = {}
         gen_limit(lim, strings, spec)
-        np.savez_compressed(os.path.join(OUT, 'limit.npz'), **lim)
+        emit('limit', lim)
         spec['exhaustion'] = exhaustion_cases()
     spec['messages'] = strings.lst
     spec['generator'] = {'numpy': np.__version__, 'python': sys.version.split()[0],
                          'reference': 'gtatiya/gym-novel-gridworlds v1.2 (setup.py) at /root/reference'}
+    if CHECK['on']:
+        committed = json.load(open(sfile))
+        for k in sorted(set(spec) | set(committed)):
+            if k in ('generator',):
+                continue
+            if k == 'cfgs':
+                for c in spec['cfgs']:
+                    if json.dumps(spec['cfgs'][c], sort_keys=True) != json.dumps(committed['cfgs'].get(c), sort_keys=True):
+                        CHECK['bad'].append('spec.json: cfgs[%s] differs' % c)
+            elif not only and json.dumps(spec.get(k), sort_keys=True) != json.dumps(committed.get(k), sort_keys=True):
+                CHECK['bad'].append('spec.json: %s differs' % k)
+        if CHECK['bad']:
+            print('FIXTURE CHECK FAILED:\n  ' + '\n  '.join(CHECK['bad'][:40]))
+            sys.exit(1)
+        print('fixture check ok: %s' % (', '.join(only) if only else 'every configuration'))
+        return
     json.dump(spec, open(sfile, 'w'), indent=1, sort_keys=True)
     print('messages:', len(strings.lst))
 

@@ -1,4 +1,6 @@
 """Parity of the HIP path (through the C-ABI) against the golden vectors and the CPU oracle.  Needs an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -376,14 +378,39 @@ def test_invalid_device_action_sets_flag_and_leaves_env_untouched():
 def test_placement_exhaustion_raises_like_reference():
     with pytest.raises(AssertionError, match="Cannot place items, increase map size!"):
         VecNovelGridworld(num_envs=64, map_size=6).reset()
-    v = VecNovelGridworld(num_envs=200, map_size=8, seed=3)      # 16 candidates: some envs fail, some do not
-    o = Oracle(make_spec(T.POGO, 8).compile(), 200, seed=3)
-    flags = o.reset()
-    try:
-        v.reset()
-        assert flags == 0
-    except AssertionError:
-        assert flags == 2
+    # 16 candidates for 6 items: some envs run out of candidates, some do not.  The call raises (the sticky flag), and env by
+    # env the outcome is the oracle's: the envs that could place everything hold exactly the oracle's episode, the others
+    # stop where the reference's loop raised (pose drawn, the items placed so far on the map).
+    from oracle.ngw_oracle import State, lib as olib
+    import ctypes
+    n, S = 200, 8
+    spec = make_spec(T.POGO, S)
+    cs = spec.compile()
+    for fast in ('1', '2'):                                      # general kernel (the default at this size), dedicated kernel
+        old = os.environ.get('NGW_FAST_RESET')
+        os.environ['NGW_FAST_RESET'] = fast
+        try:
+            v = VecNovelGridworld(spec=spec, num_envs=n, seed=3)
+        finally:
+            if old is None:
+                del os.environ['NGW_FAST_RESET']
+            else:
+                os.environ['NGW_FAST_RESET'] = old
+        st = State(n, S, len(spec.items_id))
+        failed = np.zeros(n, bool)
+        for i in range(n):
+            failed[i] = olib().ngwo_reset_philox(ctypes.byref(cs), 3, i, 1, st.map[i], st.loc[i], st.facing[i:i + 1], st.inv[i],
+                                                 st.selected[i:i + 1], st.step_count[i:i + 1]) != 0
+        assert failed.any() and not failed.all()
+        with pytest.raises(AssertionError, match="Cannot place items, increase map size!"):
+            v.reset()
+        got = v.get_state()
+        ok = ~failed
+        assert (got['map'][ok] == st.map[ok]).all() and (got['loc'][ok] == st.loc[ok]).all() and (got['facing'][ok] == st.facing[ok]).all()
+        assert (got['inv'][ok] == st.inv[ok]).all() and (got['episode'] == 1).all()
+        assert (got['loc'][failed] == st.loc[failed]).all() and (got['facing'][failed] == st.facing[failed]).all()
+        assert (got['map'][failed] == st.map[failed]).all(), 'fast=%s: a failed env holds other items than the reference had placed' % fast
+        v.close()
 
 
 def test_graph_stepping_equals_eager_stepping():

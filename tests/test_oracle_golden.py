@@ -2,6 +2,8 @@
 imported reference (tests/golden, generator gen_golden.py).  CPU only."""
 import zlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -143,3 +145,20 @@ def test_invalid_action_is_flagged():
             assert out['flags'] == 1
             for k, v in be.state().items():
                 assert (v == before[k]).all()
+
+
+REFERENCE = '/root/reference'
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, 'gym_novel_gridworlds')), reason='the reference is only present in the build container')
+@pytest.mark.parametrize('gen', ['gen_golden.py', 'gen_g6.py'])
+def test_committed_fixtures_are_what_the_generators_make(gen):
+    """Fixture integrity: regenerate every fixture in memory from the imported, unmodified reference (`<generator> --check`) and
+    compare with the committed files - a stale or hand-edited .npz / spec.json fails here."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', MPLBACKEND='Agg',
+               PYTHONPATH=os.pathsep.join([os.path.join(root, 'oracle', 'gym_shim'), REFERENCE]))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'golden', gen), '--check'], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and 'fixture check ok' in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]

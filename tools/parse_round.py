@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Turns gpurun_out/prof_r02/ (written by tools/profile_r02.sh) into the committed summaries:
-   profiles/r02_kernel_stats.md   rocprofv3 --kernel-trace --stats of the bench command, every workload + the fused rollout
-   profiles/r02_pmc.md            HBM traffic counters (FETCH_SIZE / WRITE_SIZE, separate passes) with the calibration on a
-                                  known byte count, and the SQ counters of the C2 step kernel and of the fused rollout
+"""tools/parse_round.py <round>: turns gpurun_out/prof_<round>/ (written by tools/profile_round.sh <round>) into the committed summaries:
+   profiles/<round>_kernel_stats.md   rocprofv3 --kernel-trace --stats of the bench command (the driver's own, every workload, the fused rollout)
+   profiles/<round>_pmc.md            HBM traffic counters (FETCH_SIZE / WRITE_SIZE, separate passes) with the calibration on a
+                                  known byte count, the new-episode kernel's write traffic against its payload, and the SQ
+                                  counters of the C2 step kernel and of the fused rollout
    profiles/pmc_traffic.json      per-launch HBM bytes that bench.py reports as roofline.traffic (a constant of the kernel)
 Counter values are KiB.  gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE under-reads wide coalesced reads by 2x; the
 factor is re-measured here on the staging-only diagnostic kernel whose byte count is known exactly."""
@@ -13,9 +14,12 @@ import json
 import os
 import re
 import statistics as st
+import sys
+
+ROUND = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, 'gpurun_out', 'prof_r02')
+SRC = os.path.join(ROOT, 'gpurun_out', 'prof_' + ROUND)
 DST = os.path.join(ROOT, 'profiles')
 WL = {'C2': (65536, 353, 'Pogostick-v1 10x10, 65 536 envs'), 'C3': (65536, 953, 'Bow-v1 20x20, 65 536 envs'),
       'C4': (32768, 365, 'Pogostick-v1 + axe(medium) 10x10, 32 768 envs'), 'C5': (65536, 2213, 'Pogostick-v1 + additem(hard) 32x32, 65 536 envs')}
@@ -39,9 +43,9 @@ def bench_line(log):
 
 
 # ---------------------------------------------------------------- kernel stats
-out = ['# rocprofv3 --kernel-trace --stats summaries (round 2)\n',
+out = ['# rocprofv3 --kernel-trace --stats summaries (%s)\n' % ROUND,
        'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-side --steps 400 --warmup 100 '
-       '--workload <W> [--mode rollout]` (`tools/profile_r02.sh`; raw CSVs under `gpurun_out/prof_r02/`).\n',
+       '--workload <W> [--mode rollout]`, and the driver\'s own `python3 bench.py --gpus 1 --steps 20 --warmup 5` (`tools/profile_round.sh %s`; raw CSVs under `gpurun_out/prof_%s/`).\n' % (ROUND, ROUND),
        '**How to read the step-kernel durations.**  The step kernels of this round run 2.3-3.0 us of wave activity (in-kernel clock '
        'stamps, `tools/stamp_timeline.py`, below) inside a 4.4-4.9 us launch period when the launches are replayed back to back from a '
        'hipGraph (what `bench.py` times with a HIP event pair: the command processor prepares dispatch i+1 while dispatch i runs).  Under '
@@ -55,12 +59,12 @@ for W in ('C2', 'C3', 'C4', 'C5'):
     if ln:
         ms.append('%s %.1f' % (W, ln['ms_per_step'] * 1e3))
 out[-1] = out[-1] % ', '.join(ms)
-for W, mode in (('C2', 'step'), ('C3', 'step'), ('C4', 'step'), ('C5', 'step'), ('C2_rollout', 'rollout')):
+for W, mode in (('driver', 'step'), ('C2', 'step'), ('C3', 'step'), ('C4', 'step'), ('C5', 'step'), ('C2_rollout', 'rollout')):
     f = first('stats_%s/**/*kernel_stats.csv' % W)
     if not f:
         continue
-    base = W.split('_')[0]
-    out.append('## %s (%s), %s mode - kernel_stats.csv\n' % (W, WL[base][2], mode))
+    base = 'C2' if W == 'driver' else W.split('_')[0]
+    out.append('## %s (%s), %s mode - kernel_stats.csv\n' % ("the driver's command: 20 eager steps, 5 warm-up" if W == 'driver' else W, WL[base][2], mode))
     ln = bench_line('stats_%s.log' % W)
     if ln:
         out.append('bench line of the traced run: %.2f G env-steps/s, %.2f us per batched step, %d resets of every env in the timed region\n'
@@ -88,7 +92,7 @@ for W, mode in (('C2', 'step'), ('C3', 'step'), ('C4', 'step'), ('C5', 'step'), 
             per = [(s[i + 1] - s[i]) / 1e3 for i in range(100, len(s) - 1)]
             out.append('\nstart-to-start period of the step launches inside the replayed graph (traced): median %.2f us' % st.median(per))
     out.append('')
-open(os.path.join(DST, 'r02_kernel_stats.md'), 'w').write('\n'.join(out) + '\n')
+open(os.path.join(DST, ROUND + '_kernel_stats.md'), 'w').write('\n'.join(out) + '\n')
 
 
 # ---------------------------------------------------------------- PMC
@@ -102,9 +106,9 @@ def counters(d):
     return by
 
 
-pm = ['# HBM traffic and SQ counters (round 2)\n',
+pm = ['# HBM traffic and SQ counters (%s)\n' % ROUND,
       'rocprofv3 `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in SEPARATE passes (the TCC slots do not fit both), `--kernel-trace` only beside them; '
-      'command `python3 bench.py --no-cpu-baseline --no-side --steps 60 --warmup 10 --launch eager --workload <W>` (`tools/profile_r02.sh`).  Values are per launch, '
+      'command `python3 bench.py --no-cpu-baseline --no-side --steps 60 --warmup 10 --launch eager --workload <W>` (`tools/profile_round.sh`).  Values are per launch, '
       'median over the 70 step launches of a pass.\n']
 cal = {}
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
@@ -135,7 +139,7 @@ for W in ('C2', 'C3', 'C4', 'C5'):
         n = WL[W][0]
         pm.append('| %s | `%s` | %.1f | %.1f | %.0f | %.1f | %d |' % (W, k, fv, wv, total, total / n, WL[W][1]))
         traffic['%s_step' % W] = {'hbm_bytes_per_launch': round(total), 'env_steps_per_launch': n, 'hbm_bytes_per_env_step': round(total / n, 1),
-                                  'source': 'profiles/r02_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x%.3f)' % ff}
+                                  'source': 'profiles/%s_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x%.3f)' % (ROUND, ff)}
 pm.append('\nThe step kernels move well under the 2*S*S + 12*K + 45 bytes the survey prices for a read-pack-write design: the observation buffers are the '
           'state, updated in place, and from 16 x 16 up a step reads only the map lines around the agent (no-stage kernel).  That is why `roofline.frac` '
           'of C3 exceeds 1 on the algorithmic bytes while the kernel is nowhere near the HBM peak on the bytes it really moves '
@@ -160,7 +164,30 @@ for (k, cn), v in f_by.items():
         pm.append('`%s`: FETCH_SIZE %.1f KiB, WRITE_SIZE %.1f KiB per launch -> %.0f B = **%.1f B per env-step**: every step overwrites the same lines in L2, only the '
                   'last values leave the chip.  The fused rollout is bound by instruction issue, not by HBM (SQ counters below).\n' % (k, fv, wv, total, total / (65536 * steps)))
         traffic['C2_rollout'] = {'hbm_bytes_per_launch': round(total), 'env_steps_per_launch': 65536 * steps, 'hbm_bytes_per_env_step': round(total / (65536 * steps), 1),
-                                 'source': 'profiles/r02_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x%.3f)' % ff}
+                                 'source': 'profiles/%s_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x%.3f)' % (ROUND, ff)}
+# new-episode kernel: write traffic against its payload
+RS = {'C3': (65536, 20, 9, 'Bow-v1 20x20'), 'C5': (65536, 32, 10, 'Pogostick-v1 + additem(hard) 32x32'), 'X1': (65536, 10, 10, 'Pogostick-v1 + firewall(hard) 10x10')}
+rows = []
+for W, (n, S, K, what) in RS.items():
+    f_by, w_by = counters('pmc_reset_%s_FETCH_SIZE' % W), counters('pmc_reset_%s_WRITE_SIZE' % W)
+    for (k, cn), v in w_by.items():
+        if 'reset_fast' not in k and ', 1,' not in k:
+            continue
+        wv, fv = st.median(v), st.median(f_by.get((k, 'FETCH_SIZE'), [0]))
+        payload = n * (S * S + 4 * K + 16)
+        rows.append('| %s (%s) | `%s` | %.0f | %.0f | %.1f | %.1f | **%.2f** |' % (W, what, k, fv, wv, wv * 1024 * wf / 1e6, payload / 1e6, wv * 1024 * wf / payload))
+        traffic['%s_reset' % W] = {'write_bytes_per_launch': round(wv * 1024 * wf), 'payload_bytes_per_launch': payload, 'write_amplification': round(wv * 1024 * wf / payload, 3),
+                                   'source': 'profiles/%s_pmc.md (tools/reset_pmc.py, rocprofv3 --pmc WRITE_SIZE)' % ROUND}
+if rows:
+    pm.append('## New-episode kernel: HBM writes against the payload\n')
+    pm.append('`python3 tools/reset_pmc.py <W>`: six explicit resets of every env, prepared episodes off (every launch builds its episodes).  Payload of a launch = '
+              'N x (S*S + 4*K + 16) bytes: the map, the inventory row, pose / facing / counters.  Round 2 wrote the ring-and-air template first and scattered the items '
+              'as single bytes afterwards: 794 MB per launch at C5 for 70.8 MB of payload (11.2x), 46.6 MB at C3 for 29.6 MB (1.6x).  The rows are now composed per env '
+              'in an LDS tile and stored once, with consecutive lanes on consecutive bytes of one env.\n')
+    pm.append('| workload | kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | written MB | payload MB | written / payload |')
+    pm.append('|---|---|---|---|---|---|---|')
+    pm += rows
+    pm.append('')
 # SQ
 pm.append('## SQ counters\n')
 pm.append('Two `--pmc` passes of 7 / 6 SQ counters each (the SQ block has 8 slots).  `SQ_WAVE_CYCLES`, `SQ_WAIT_*`, `SQ_ACTIVE_INST_*` count quad-cycles.\n')
@@ -189,8 +216,17 @@ for label, dirs, pick, per in (('C2 step kernel `ngw_step_lean<0, true>` (per la
                                     'valu': round(vals.get('SQ_INSTS_VALU', 0) / waves / per, 1), 'salu': round(vals.get('SQ_INSTS_SALU', 0) / waves / per, 1),
                                     'branch': round(vals.get('SQ_INSTS_BRANCH', 0) / waves / per, 1), 'lds': round(vals.get('SQ_INSTS_LDS', 0) / waves / per, 1),
                                     'issue_share_of_wave_cycles': round(vals.get('SQ_ACTIVE_INST_ANY', 0) / vals.get('SQ_WAVE_CYCLES', 1), 3),
-                                    'source': 'profiles/r02_pmc.md (rocprofv3 --pmc SQ_*, 200-step launch)'}
-open(os.path.join(DST, 'r02_pmc.md'), 'w').write('\n'.join(pm) + '\n')
+                                    'source': 'profiles/%s_pmc.md (rocprofv3 --pmc SQ_*, 200-step launch)' % ROUND}
+open(os.path.join(DST, ROUND + '_pmc.md'), 'w').write('\n'.join(pm) + '\n')
+def _read(name):
+    try:
+        return open(os.path.join(SRC, name)).read().strip()
+    except OSError:
+        return 'unknown'
+
+
+traffic['_provenance'] = {'round': ROUND, 'commit': _read('commit.txt'), 'measured': _read('date.txt'),
+                          'how': 'tools/profile_round.sh %s on one MI355X (gpurun), parsed by tools/parse_round.py' % ROUND}
 json.dump(traffic, open(os.path.join(DST, 'pmc_traffic.json'), 'w'), indent=1)
-print('wrote profiles/r02_kernel_stats.md, profiles/r02_pmc.md, profiles/pmc_traffic.json')
+print('wrote profiles/%s_kernel_stats.md, profiles/%s_pmc.md, profiles/pmc_traffic.json' % (ROUND, ROUND))
 print(json.dumps(traffic, indent=1))

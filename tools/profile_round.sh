@@ -1,29 +1,44 @@
 #!/bin/bash
-# Profiling recipe of a round (run on the GPU box through gpurun, from the repo root):
-#   1. rocprofv3 --kernel-trace --stats of the default bench command (step mode) and of the fused rollout
-#   2. HBM traffic counters in SEPARATE passes (FETCH_SIZE, then WRITE_SIZE; TCC slots do not fit both) for both modes
-#   4. kernel traces of the staggered-episode-ends regime, inline resets vs prepared next episodes
-#   3. the same counters on the staging-only diagnostic kernel at 1 Mi envs (working set > Infinity Cache) whose byte
-#      count is known exactly: calibrates FETCH_SIZE (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md §HBM)
-# Outputs land in gpurun_out/prof_$TAG/ ; tools/parse_profiles.py turns them into profiles/*.md + pmc_traffic.json.
-set -e
-TAG=${1:-r01}
-OUT=gpurun_out/prof_$TAG
-rm -rf $OUT
-mkdir -p $OUT
+# Profiling recipe of a round: tools/profile_round.sh <round, e.g. r03>  (run on the GPU box through gpurun, from the repo root; ~7 minutes):
+#   0. rocprofv3 --kernel-trace --stats of the DRIVER's command (python3 bench.py --gpus 1 --steps 20 --warmup 5)
+#   1. rocprofv3 --kernel-trace --stats of the bench command, every workload (step mode) + the fused rollout at C2
+#   2. HBM traffic counters in SEPARATE passes (FETCH_SIZE, then WRITE_SIZE: the TCC slots do not fit both), step mode of
+#      every workload + the C2 rollout, and the same counters on the staging-only diagnostic kernel at 1 Mi envs whose byte
+#      count is known exactly (calibrates FETCH_SIZE: gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md §HBM)
+#   3. SQ counters (wave cycles, waiting, issue mix) of the C2 step kernel and of the C2 fused rollout
+#   4. FETCH_SIZE / WRITE_SIZE of the new-episode kernel (explicit resets of every env, prepared episodes off): C3, C5, X1
+# Outputs land in gpurun_out/prof_<round>/ ; tools/parse_round.py <round> turns them into profiles/<round>_*.md + profiles/pmc_traffic.json.
+ROUND=${1:-r03}
+OUT=gpurun_out/prof_$ROUND
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="python3 bench.py --no-cpu-baseline --no-stagger --steps 400 --warmup 100"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_step -- $B > $OUT/stats_step.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_rollout -- $B --mode rollout > $OUT/stats_rollout.log 2>&1
-P="python3 bench.py --no-cpu-baseline --no-stagger --steps 60 --warmup 10 --launch eager"
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_step_$c -- $P > $OUT/pmc_step_$c.log 2>&1
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_rollout_$c -- $P --mode rollout > $OUT/pmc_rollout_$c.log 2>&1
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_calib_$c -- python3 tools/dbg_launch.py calib > $OUT/pmc_calib_$c.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_driver -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-side > $OUT/stats_driver.log 2>&1 || echo "stats driver failed"
+B="python3 bench.py --no-cpu-baseline --no-side --steps 400 --warmup 100"
+for W in C2 C3 C4 C5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -- $B --workload $W > $OUT/stats_$W.log 2>&1 || echo "stats $W failed"
 done
-# 4. staggered episode ends: inline resets vs prepared next episodes (ngw_set_reset_prefetch), kernel trace of each
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_stagger_inline -- python3 tools/stagger_rate.py > $OUT/stats_stagger_inline.log 2>&1
-export NGW_PREFETCH=32
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_stagger_prefetch -- python3 tools/stagger_rate.py > $OUT/stats_stagger_prefetch.log 2>&1
-unset NGW_PREFETCH
-echo profile_round done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_C2_rollout -- $B --mode rollout > $OUT/stats_C2_rollout.log 2>&1 || echo "stats rollout failed"
+P="python3 bench.py --no-cpu-baseline --no-side --steps 60 --warmup 10 --launch eager"
+for c in FETCH_SIZE WRITE_SIZE; do
+  for W in C2 C3 C4 C5; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${W}_$c -- $P --workload $W > $OUT/pmc_${W}_$c.log 2>&1 || echo "pmc $W $c failed"
+  done
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_C2rollout_$c -- $P --mode rollout > $OUT/pmc_C2rollout_$c.log 2>&1 || echo "pmc rollout $c failed"
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_calib_$c -- python3 tools/dbg_launch.py calib > $OUT/pmc_calib_$c.log 2>&1 || echo "pmc calib $c failed"
+done
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/sq_step_$i -- $P > $OUT/sq_step_$i.log 2>&1 || echo "sq step $i failed"
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/sq_rollout_$i -- python3 bench.py --no-cpu-baseline --no-side --steps 200 --warmup 20 --mode rollout --reset-prefetch 0 > $OUT/sq_rollout_$i.log 2>&1 || echo "sq rollout $i failed"
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  for W in C3 C5 X1; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_reset_${W}_$c -- python3 tools/reset_pmc.py $W > $OUT/pmc_reset_${W}_$c.log 2>&1 || echo "pmc reset $W $c failed"
+  done
+done
+git rev-parse --short HEAD > $OUT/commit.txt 2>/dev/null || echo unknown > $OUT/commit.txt
+date -u +%Y-%m-%dT%H:%MZ > $OUT/date.txt
+find $OUT -name "*.db" -delete 2>/dev/null
+du -sh $OUT
+echo profile_$ROUND done

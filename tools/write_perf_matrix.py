@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
-"""gpurun_out/matrix_r02/ (tools/perf_matrix_r02.sh) -> profiles/r02_perf_matrix.md"""
-import json, os
+"""tools/write_perf_matrix.py <round>: gpurun_out/matrix_<round>/ (tools/perf_matrix.sh <round>) -> profiles/<round>_perf_matrix.md.
+A log that holds a Python traceback is an ERROR here (exit 1): a matrix with a crash where a measurement should be is not evidence."""
+import json, os, sys
+ROUND = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-d = os.path.join(ROOT, 'gpurun_out', 'matrix_r02') + '/'
-out = ['# Performance matrix of round 2 (one MI355X; `tools/perf_matrix_r02.sh`)\n',
+d = os.path.join(ROOT, 'gpurun_out', 'matrix_' + ROUND) + '/'
+out = ['# Performance matrix of %s (one MI355X; `tools/perf_matrix.sh %s`)\n' % (ROUND, ROUND),
        'Every JSON block below is the line `bench.py` printed (default flags unless stated), trimmed to the measured fields.\n']
 
 
 def trim(x):
     r = x['roofline']
     o = {'value_G': round(x['value'] / 1e9, 2), 'us_per_step': round(x['ms_per_step'] * 1e3, 2), 'n_gpus': x['n_gpus'], 'steps': x['steps'],
-         'resets_in_timed_region': x['resets_in_timed_region'], 'roofline_frac': r['frac'], 'kernel_us_avg': round(r['kernel_ms_avg'] * 1e3, 3),
-         'traffic_bytes': r.get('traffic'), 'frac_on_measured_traffic': r.get('frac_of_peak_on_measured_traffic')}
+         'resets_in_timed_region': x['resets_in_timed_region'], 'roofline_frac': r['frac'], 'roofline_bytes_model': r.get('bytes_model'),
+         'kernel_us_avg': round(r['kernel_ms_avg'] * 1e3, 3), 'traffic_bytes': r.get('traffic'),
+         'frac_on_measured_traffic': r.get('frac_of_peak_on_measured_traffic'), 'prepared_episodes': x.get('prepared_episodes')}
+    if 'frac_on_survey_8d_bytes' in r:
+        o['survey_8d_bytes_over_time_over_peak'] = r['frac_on_survey_8d_bytes']
     if 'gather' in x:
         o['gather'] = {k: x['gather'][k] for k in ('ms', 'GBps_into_root', 'payload_bytes_per_rank', 'ranks', 'backend')}
     if 'fused_rollout' in x:
@@ -32,10 +37,8 @@ def trim(x):
 
 for f, title in [('bench_C2', 'C2 `python bench.py`'), ('bench_C3', 'C3 `--workload C3`'), ('bench_C4', 'C4 `--workload C4`'), ('bench_C5', 'C5 `--workload C5`'),
                  ('bench_C2_driver_style', 'C2 driver-style `--steps 20 --warmup 5` (eager launches below 100 steps)'),
-                 ('bench_X1_lean1', 'X1 FireWall hard (`--workload X1 --no-side`): lean kernel with the wrapper predicates'),
-                 ('bench_X1_lean0', "X1, round 1's general kernel (`NGW_LEAN=0`)"),
-                 ('bench_X2_lean1', 'X2 FenceRestriction hard'), ('bench_X2_lean0', 'X2, general kernel'),
-                 ('bench_X3_lean1', 'X3 Crate hard'), ('bench_X3_lean0', 'X3, general kernel'),
+                 ('bench_X1', 'X1 FireWall hard (`--workload X1`: 3 000 untimed eager steps first, so that the handle has adapted; 1.5 % of the envs die per step)'),
+                 ('bench_X2', 'X2 FenceRestriction hard'), ('bench_X3', 'X3 Crate hard'),
                  ('bench_2rank_C4', '2 ranks on ONE GPU (rehearsal of the N > 1 path; the ranks share the GPU, so per-rank rates halve): `python bench.py --gpus 2 --dist-backend gloo --single-device --workload C4 --steps 400`'),
                  ('bench_2rank_C5', '2 ranks on ONE GPU: `... --workload C5 --steps 400`')]:
     try:
@@ -45,15 +48,19 @@ for f, title in [('bench_C2', 'C2 `python bench.py`'), ('bench_C3', 'C3 `--workl
     out.append('## %s\n\n```json\n%s\n```\n' % (title, json.dumps(trim(x))))
 for f, title in [('reset_time.log', 'Reset launches (`tools/reset_time.py`, HIP events, eager; dedicated kernel where it applies)'),
                  ('reset_time_general.log', 'Reset launches, general kernel only (`NGW_FAST_RESET=0`)'),
-                 ('reset_time_u16.log', "C5 reset launches with the shuffle array as u16 (`NGW_RESET_PACK=0`: one wave per CU)"),
                  ('short_run.log', 'A 20-step region fence to fence, eager vs one graph replay (`tools/short_run.py`)'),
-                 ('stamps_reset.log', 'In-kernel timeline of the new-episode kernel at C5 (`tools/stamp_reset.py`, stamps build)'),
-                 ('stamps_reset_u16.log', 'The same with the u16 shuffle array (`NGW_RESET_PACK=0`)'),
+                 ('stamps_reset.log', 'In-kernel timelines of the new-episode kernel (`tools/stamp_reset.py C3 C5 X1`, stamps build)'),
+                 ('api_delta.log', 'Host API at 65 536 envs, delta refresh (`tools/api_mode_rate.py`)'),
+                 ('api_full_copy.log', 'Host API at 65 536 envs, whole observation every step (`NGW_HOST_DELTA=0`)'),
                  ('churn_X1.log', 'FireWall hard, eager loop: cadence the handle adapts to, resets that miss their prepared episode (`tools/churn_probe.py X1`)'),
                  ('lidar.log', 'LidarInFront observation (`tools/lidar_rate.py`, C2, 8 beams)'),
                  ('adapter.log', 'Single-env adapter (`tools/adapter_latency.py`)'), ('api.log', 'Host API by batch size (`tools/api_latency.py`)'),
                  ('stamps.log', 'In-kernel timelines of one step launch (`tools/stamp_timeline.py`, stamps build)'),
                  ('stamps_general.log', "The same for round 1's general kernel at C2 (`NGW_LEAN=0`)")]:
     if os.path.exists(d + f):
-        out.append('## %s\n\n```\n%s\n```\n' % (title, ''.join(ln for ln in open(d + f) if 'amdgpu.ids' not in ln).strip()))
-open(os.path.join(ROOT, 'profiles', 'r02_perf_matrix.md'), 'w').write('\n'.join(out))
+        text = ''.join(ln for ln in open(d + f) if 'amdgpu.ids' not in ln).strip()
+        if 'Traceback (most recent call last)' in text:
+            sys.exit('%s holds a traceback: fix the run, do not commit the matrix\n%s' % (f, text[-1500:]))
+        out.append('## %s\n\n```\n%s\n```\n' % (title, text))
+open(os.path.join(ROOT, 'profiles', ROUND + '_perf_matrix.md'), 'w').write('\n'.join(out))
+print('wrote profiles/%s_perf_matrix.md' % ROUND)
