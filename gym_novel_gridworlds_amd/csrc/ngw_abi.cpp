@@ -105,6 +105,7 @@ struct ngw_handle {
     int nostage = 0;                      // lean kernel without map staging (S*S >= 256, or NGW_NOSTAGE=<min S*S>; 0 = never)
     NgwLaunch ns_proto{};                 // its launch prototype (small LDS layout)
     size_t ns_lds = 0;
+    bool general_ok = true;               // false: the map is too big for the kernels that keep a wave's 64 maps in LDS (general kernel, fused rollouts, fused lidar)
     int lean = 1;                         // plain configurations step through ngw_step_lean (NGW_LEAN=0 in the environment: general kernel, A/B)
     int ext = 0;                          // spec uses FireWall / FenceRestriction / Crate step predicates -> EXT kernels
     int8_t* view_out = nullptr;           // AgentMap windows
@@ -513,8 +514,12 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
         HIP_TRY(ngw_launch(h->dspec, &q, h->map_mode, 4 | 8 | (h->ext ? 2 : 0), grid, h->ns_lds, h->stream));
         taken = true;
     }
-    if (!taken)
+    if (!taken) {
+        if (!h->general_ok)
+            return fail(NGW_E_INVALID_ARG, "map_size %d: this call keeps a wavefront's 64 maps in LDS (fused rollouts, the fused lidar epilogue, "
+                                           "NGW_LEAN=0) and they need more than 160 KiB; per-launch steps and resets are available", h->proto.S);
         HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, (h->lidar_fused ? 1 : 0) | (h->ext ? 2 : 0) | (h->lean ? 4 : 0), grid, h->lds_bytes, h->stream));
+    }
     if (h->prefetch_every > 0 && (mode == NGW_MODE_STEP || mode == NGW_MODE_RESET || mode == NGW_MODE_ROLLOUT || mode == NGW_MODE_ROLLOUT_ACT)) {
         // Prepared next episodes: every `prefetch_every` batched steps (and right after an explicit reset) one more launch
         // refills the shadow rows that resets have consumed since.  Same stream, so it is ordered between the steps.
@@ -780,9 +785,18 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     const uint32_t div = ((S2 & 3) == 0) ? (uint32_t)(S2 / 4) : (uint32_t)S2;
     p.magic = (uint32_t)((0x100000000ull + div - 1) / div);
     p.CW = ((S - 4) * (S - 4) + 31) / 32;
-    if (int rc = layout_lds(h)) return bail(rc);
+    if (int rc = layout_lds(h)) {
+        // Maps beyond ~46 x 46 do not fit the kernels that keep a wave's 64 maps in LDS.  The no-stage step kernel and the
+        // dedicated new-episode kernel do not need them there: such a handle steps and resets, and refuses what it cannot run.
+        if (!(h->lean && h->nostage)) return bail(rc);
+        h->general_ok = false;
+        h->lds_bytes = 0; p.perm_lds = 0; h->off_rng = 0xFFFFFFFFu;
+    }
     if (int rc = upload_reset_u(h)) return bail(rc);
     layout_reset_fast(h);
+    if (!h->general_ok && h->rf_nw < 0)
+        return bail(fail(NGW_E_INVALID_ARG, "map_size %d needs more than 160 KiB of LDS per wavefront for this configuration's resets "
+                                            "(reset passes that read the map, the v0 tree tap or more than 12 placed items keep the general kernel)", S));
     if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(NGW_E_HIP, "stream sync failed after allocation"));
     *out = h;
     return NGW_OK;

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import spaces
 from .spec import DIRECTION_ID, DIRECTION_STR, STEP_COSTS, EnvSpec
-from .vec_env import VecNovelGridworld
+from .vec_env import PLACEMENT_MESSAGE, VecNovelGridworld
 
 try:
     import gym as _gym
@@ -355,7 +355,8 @@ class _NovelGridworldEnv(_EnvBase):
         self.reset()
 
     # ---- public map / table editing helpers of the reference env (host attributes are the truth between calls; the next
-    #      step() pushes them to the device).  The placement and craft internals (add_item_to_map, craft) live in the kernels.
+    #      step() pushes them to the device).  reset() and step() run placement and crafting in the kernels; add_item_to_map and
+    #      craft below are the same rules as public host-side methods, for callers that use them directly.
     def remap_action(self, actions_id, start_action_id):
         """Shuffle action names with the global numpy stream until the table changes (:476-493)."""
         from .novelty import _remap_action
@@ -388,6 +389,47 @@ class _NovelGridworldEnv(_EnvBase):
                 if ent != 0 and names[ent] in self.entities:
                     self.map[rr][cc] = 0
                     self.inventory_items_quantity[names[ent]] += 1
+
+    def add_item_to_map(self, item, num_items):
+        """Public form of the placement loop (:159-181) on the host attributes, drawing from the global numpy stream like the
+        reference: a random remaining candidate; the agent's cell is dropped; a cell whose 4-neighbourhood is all air takes the
+        item; every drawn candidate leaves the list.  (reset() itself runs the same loop in the kernels, on its per-episode
+        Philox stream; the candidate list this call works on is whatever the caller left in `available_locations` - after a
+        reset() that is empty here, and the interior [2, S-3]^2 in row-major order is taken instead.)"""
+        if not self.available_locations:
+            inner = range(2, self.map_size - 2)
+            self.available_locations = [(r, c) for r in inner for c in inner]
+        candidates, grid, placed = self.available_locations, self.map, 0
+        item_id = self.items_id[item]
+        while placed != num_items:
+            assert candidates, PLACEMENT_MESSAGE
+            pick = int(np.random.choice(len(candidates), size=1)[0])
+            r, c = spot = candidates.pop(pick)
+            if spot == tuple(self.agent_location):
+                continue
+            if not (grid[r][c] or grid[r - 1][c] or grid[r + 1][c] or grid[r][c - 1] or grid[r][c + 1]):
+                grid[r][c] = item_id
+                placed += 1
+            self.not_available_locations.append(spot)
+
+    def craft(self, item_to_craft):
+        """Public form of the craft rule (:413-474) on the host attributes: (reward, result, step_cost, message).  The costs and
+        the reward are the compiled spec's per-recipe table entries - the ones the kernels use for the Craft_* actions."""
+        spec = self._sync_spec()
+        needs = self.recipes[item_to_craft]['input']
+        have = self.inventory_items_quantity
+        cost_missing, cost_no_table, cost_ok = spec.craft_costs.get(item_to_craft, (0, 0, 0))
+        short = [name for name, q in needs.items() if have.get(name, -1) < q]
+        if short:
+            return -1, False, cost_missing, "Missing items: " + ", ".join("%s %s" % (needs[name], name) for name in short)
+        if len(needs) > 1:
+            self.update_block_in_front()
+            if self.block_in_front_str != 'crafting_table':
+                return -1, False, cost_no_table, 'Need to be in front of crafting_table'
+        for name, q in needs.items():
+            have[name] -= q
+        have[item_to_craft] += self.recipes[item_to_craft]['output'][item_to_craft]
+        return spec.recipe_rewards.get(item_to_craft, spec.craft_reward), True, cost_ok, 'Crafted ' + item_to_craft
 
     def render(self, mode='human', title=None):
         raise NotImplementedError("rendering is outside the batched hot path (SURVEY.md §2 row 12)")

@@ -148,3 +148,35 @@ def test_in_place_table_edits_between_steps_take_effect_at_once():
     env.unbreakable_items.add('tree_log')                                              # same size? no - but same identity
     env.unbreakable_items.discard('wall'); env.unbreakable_items.add('wall')
     env.close()
+
+
+def test_public_craft_and_add_item_to_map_follow_the_step_rules():
+    """craft() / add_item_to_map() as public methods (pogostick_v1_env.py:159-181, :413-474): craft() returns what a Craft_*
+    step reports - checked against the golden injected single steps of the reference - and add_item_to_map() places items on
+    cells whose 4-neighbourhood is air, never on the agent, and raises the reference's assertion when the candidates run out."""
+    g = T.golden('pogo10')
+    env = T.make_adapter_env('pogo10', 'oracle')
+    env.reset()
+    spec = env._spec
+    names = spec.item_names
+    crafts = {v: k[len('Craft_'):] for k, v in env.actions_id.items() if k.startswith('Craft_')}
+    seen = set()
+    for c in range(len(g['ss_action'])):
+        a = int(g['ss_action'][c])
+        if a not in crafts or g['ss_done'][c]:
+            continue
+        T.adapter_inject(env, spec, g['ss_pre_map'][c], g['ss_pre_loc'][c], g['ss_pre_facing'][c], g['ss_pre_sel'][c], g['ss_pre_inv'][c])
+        reward, result, cost, message = env.craft(crafts[a])
+        assert (reward, result, message) == (int(g['ss_reward'][c]), bool(g['ss_result'][c]), T.messages()[g['ss_msg'][c]]), (c, crafts[a])
+        assert cost == g['ss_cost'][c] and (type(cost) is int) == bool(g['ss_cost_is_int'][c])
+        assert [env.inventory_items_quantity[n] for n in names] == list(g['ss_post_inv'][c])
+        seen.add((crafts[a], result, message.split(':')[0]))
+    assert len(seen) >= 8                                     # every recipe, missing / no table / crafted
+    env.reset()
+    before = int((env.map == env.items_id['tree_log']).sum())
+    np.random.seed(4)
+    env.add_item_to_map('tree_log', 2)
+    m = env.map
+    assert int((m == env.items_id['tree_log']).sum()) == before + 2 and m[env.agent_location] == 0
+    with pytest.raises(AssertionError, match='Cannot place items, increase map size!'):
+        env.add_item_to_map('tree_log', 50)

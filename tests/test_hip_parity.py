@@ -555,9 +555,33 @@ def test_extreme_map_sizes_match_oracle(env_id, S):
     assert_state_equal(v, o, '%s S=%d' % (env_id, S))
 
 
-def test_map_size_beyond_lds_budget_is_rejected():
+def test_maps_beyond_the_lds_budget_step_and_reset_but_refuse_fused_rollouts():
+    """Beyond ~46 x 46 a wave's 64 maps no longer fit in LDS.  The no-stage step kernel and the dedicated new-episode kernel do
+    not keep them there: such a handle resets and steps (equal to the oracle, autoreset and prepared episodes included) and
+    refuses the calls that would need the maps in LDS; configurations whose resets need the general kernel are refused at creation."""
+    from gym_novel_gridworlds_amd import apply_novelty
+    for S, nov in ((60, None), (52, ('additem', 'easy', 'arrow', '')), (64, ('firewall', 'medium', '', ''))):
+        spec = make_spec(T.POGO, S)
+        if nov:
+            apply_novelty(spec, *nov)
+        A, n = len(spec.actions_id), 300
+        v = VecNovelGridworld(spec=spec, num_envs=n, seed=9, autoreset=True, horizon=20, reset_prefetch=7)
+        o = Oracle(spec.compile(), n, seed=9, autoreset=True, horizon=20)
+        v.reset(); assert o.reset() == 0
+        assert_state_equal(v, o, 'S=%d reset' % S)
+        rs = np.random.RandomState(3)
+        for t in range(50):
+            a = rs.randint(0, A, size=n).astype(np.int32)
+            _, reward, done, info = v.step(a); o.step(a)
+            assert (reward == o.reward).all() and (done == o.done.astype(bool)).all(), (S, t)
+        assert_state_equal(v, o, 'S=%d stepped' % S)
+        with pytest.raises(ValueError, match='LDS'):
+            v.rollout(5)
+        v.close()
+    spec = make_spec(T.POGO, 60)
+    apply_novelty(spec, 'fence', 'easy', 'oak', '')                 # a pass that reads the map: general kernel only
     with pytest.raises(ValueError, match='LDS'):
-        VecNovelGridworld(num_envs=64, map_size=60)
+        VecNovelGridworld(spec=spec, num_envs=64)
 
 
 @pytest.mark.parametrize('cfg,n,T_,horizon,prefetch,supplied', [('pogo10', 2048, 150, 40, 0, False), ('axe10', 1000, 230, 100, 'auto', False),
