@@ -50,3 +50,21 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith(('.py', '.cpp', '.hip', '.h')):
                 text = open(os.path.join(dirpath, f)).read()
                 assert 'ngw_oracle' not in text and 'from oracle' not in text and 'import oracle' not in text, f
+
+
+def test_step_info_decodes_the_packed_words_on_demand():
+    """StepInfo of a big batch carries the packed info words (include/ngw.h NGW_INFO_*) and decodes a field when it is read."""
+    import numpy as np
+    from gym_novel_gridworlds_amd.vec_env import StepInfo
+    from gym_novel_gridworlds_amd.spec import STEP_COSTS
+    rs = np.random.RandomState(0)
+    result, done, cost = rs.randint(0, 2, 100), rs.randint(0, 2, 100), rs.randint(0, len(STEP_COSTS), 100)
+    msg, arg = rs.randint(0, 16, 100), rs.randint(0, 1 << 12, 100)
+    words = (result | (done << 1) | (cost << 2) | (msg << 8) | (arg << 16)).astype(np.uint32)
+    info = StepInfo({'_words': words})
+    assert 'result' in info and 'step_cost' in info and '_words' not in info.keys() and len(info) == 5
+    assert (info['result'] == result.astype(bool)).all() and info['result'].dtype == np.bool_
+    assert (info['step_cost_code'] == cost).all() and (info['message_code'] == msg).all() and (info['message_arg'] == arg).all()
+    assert (info['step_cost'] == np.array([float(STEP_COSTS[c]) for c in cost])).all()
+    assert set(dict(info.items())) == {'result', 'step_cost_code', 'message_code', 'message_arg', 'step_cost'}
+    assert info.get('nothing', 7) == 7 and set(info.copy()) == set(info)
