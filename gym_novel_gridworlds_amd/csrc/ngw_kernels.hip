@@ -506,8 +506,10 @@ __device__ __forceinline__ void pieces_lds(u32x4 (&buf)[PB], const NgwLaunch& a,
         u32x4* l4 = reinterpret_cast<u32x4*>(lds_map);
 #pragma unroll
         for (int j = 0; j < PB; j++) {
-            const int p = base + tid + EPB * j;
-            if (TO_LDS) { if (p < npieces) l4[p] = buf[j]; } else buf[j] = l4[min(p, npieces - 1)];
+            // (pieces_load clamps its addresses the same way: a slot beyond the chunk holds the LAST piece and stores it to the
+            //  last piece's place again - no exec-mask bracket per piece)
+            const int p = min(base + tid + EPB * j, npieces - 1);
+            if (TO_LDS) l4[p] = buf[j]; else buf[j] = l4[p];
         }
     } else if (MAPMODE == NGW_MAP_DWORD) {                                         // dword granularity, padded stride
         const uint32_t S2dw = (uint32_t)a.S2 >> 2, MSdw = (uint32_t)a.MS >> 2;
