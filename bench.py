@@ -186,11 +186,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if args.dist_backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL on ROCm
-        else:
-            dist.init_process_group('gloo')
+        # RCCL (torch's `nccl` backend on ROCm) with a probe collective; a start-up failure is re-raised with the rank / device map
+        from gym_novel_gridworlds_amd.dist import init_process_group
+        init_process_group(args.dist_backend, local_rank)
 
     from gym_novel_gridworlds_amd import apply_novelty, make_spec
     from gym_novel_gridworlds_amd.dist import ShardedVecNovelGridworld

@@ -54,7 +54,8 @@ class ShardedVecNovelGridworld:
     """Rank-local view of `global_num_envs` environments sharded over the ranks of a torch.distributed group."""
 
     def __init__(self, env_id='NovelGridworld-Pogostick-v1', global_num_envs=65536, map_size=None, novelty=None, seed=0,
-                 autoreset=False, horizon=0, spec=None, device=None, group=None, reset_prefetch='auto', reset_prefetch_depth=0):
+                 autoreset=False, horizon=0, spec=None, device=None, group=None, reset_prefetch='auto', reset_prefetch_depth=0,
+                 exchange_always=False):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -67,6 +68,9 @@ class ShardedVecNovelGridworld:
                                       reset_prefetch=reset_prefetch, reset_prefetch_depth=reset_prefetch_depth)
         self.spec = self.local.spec
         self._payload = self._recv = self._global = None        # gather buffers, allocated on first use
+        # a one-rank group normally skips the collective (its stack is its own payload); True runs it anyway - a one-GPU box can
+        # then exercise the RCCL calls themselves (tests/test_multi_gpu_rehearsal.py)
+        self.exchange_always = bool(exchange_always)
 
     def _make_local(self, device=None, **kw):
         """This rank's envs on its GPU."""
@@ -164,7 +168,7 @@ class ShardedVecNovelGridworld:
 
     def _stack(self, dst):
         mine = self.packed_observation()
-        if self.world == 1:
+        if self.world == 1 and not (self.exchange_always and self.dist.is_initialized()):
             return self.unpack(mine, 1)
         host_side = self.dist.get_backend(self.group) == 'gloo' and mine.is_cuda          # gloo moves host tensors
         send = mine.cpu() if host_side else mine            # (.cpu() waits for torch's stream, which waits for the pack)

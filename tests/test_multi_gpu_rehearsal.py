@@ -96,6 +96,55 @@ def test_two_ranks_on_one_gpu_match_one_oracle_batch(cfg, inject):
     assert st.episode.max() >= 3
 
 
+def _rccl_worker(port, q):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    os.environ['RANK'], os.environ['WORLD_SIZE'], os.environ['LOCAL_RANK'] = '0', '1', '0'
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch
+    from gym_novel_gridworlds_amd.dist import ShardedVecNovelGridworld, init_process_group
+    torch.cuda.set_device(0)
+    dist = init_process_group('nccl', 0)                       # RCCL communicator + probe all_reduce, loud on failure
+    try:
+        spec = T.build_spec('axe10')
+        env = ShardedVecNovelGridworld(global_num_envs=N, spec=spec, seed=3, autoreset=True, horizon=12, device=0, exchange_always=True)
+        env.reset()
+        rs = np.random.RandomState(0)
+        for t in range(STEPS):
+            env.step(rs.randint(0, len(spec.actions_id), size=N).astype(np.int32))
+        got = env.gather_observation(dst=0)                    # torch.distributed.gather of a DEVICE payload over RCCL
+        every = env.all_gather_observation()                   # all_gather_into_tensor, same
+        torch.cuda.synchronize()
+        assert all((got[k] == every[k]).all() for k in got)
+        q.put({k: v.cpu().numpy() for k, v in got.items()})
+        env.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_rccl_group_runs_the_device_collectives():
+    """The RCCL branch of the observation stack on the one GPU a box has: a one-rank `nccl` process group (torch's nccl backend IS
+    RCCL on ROCm), device payloads through torch.distributed.gather / all_gather_into_tensor, pack and unpack launches ordered
+    against torch's stream by events - the same calls N ranks make, minus the xGMI hop.  (Two RCCL ranks cannot share one GPU.)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    p.join(240)
+    assert p.exitcode == 0
+    got = q.get()
+    spec = T.build_spec('axe10')
+    ref = T.OracleVec(spec, N, seed=3, autoreset=True, horizon=12)
+    ref.reset()
+    rs = np.random.RandomState(0)
+    for t in range(STEPS):
+        ref.step(rs.randint(0, len(spec.actions_id), size=N).astype(np.int32))
+    st = ref.o.st
+    assert (got['map'] == st.map.reshape(N, spec.map_size, spec.map_size)).all() and (got['agent_location'] == st.loc).all()
+    assert (got['inventory_items_quantity'] == st.inv).all() and (got['reward'] == ref.o.reward).all()
+    assert (got['done'] == ref.o.done.astype(bool)).all() and (got['info'].view(np.uint32) == ref.o.info).all()
+
+
 def test_dist_module_has_no_device_wide_synchronisation():
     src = open(os.path.join(ROOT, 'gym_novel_gridworlds_amd', 'dist.py')).read()
     assert 'cuda.synchronize' not in src and '.sync()' not in src.split('# ------------------------------------------------------------------ the one collective')[1]
