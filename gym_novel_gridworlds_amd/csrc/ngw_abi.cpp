@@ -61,6 +61,7 @@ struct ngw_handle {
     uint8_t* mirror_dev = nullptr;
     bool mirror_valid = false;
     int host_delta = 1;                   // NGW_HOST_DELTA=0: every ngw_step_host copies the whole observation (A/B)
+    size_t zc_bytes = (size_t)256 << 10;  // NGW_ZC_BYTES: largest ngw_step_host result written straight into mapped host memory (read at ngw_create)
     std::vector<void*> allocs;
     std::vector<void*> host_allocs;       // state of a single-wavefront handle kept in GPU-addressable host memory (hostres)
     uint8_t* mask_pin = nullptr; uint8_t* mask_pin_dev = nullptr;   // ngw_reset's mask: two page-locked halves the kernel reads in place
@@ -632,6 +633,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     if (const char* v = getenv("NGW_FAST_RESET")) h->fast_reset = atoi(v);
     if (const char* v = getenv("NGW_ADAPT_PREFETCH")) h->adapt = atoi(v) != 0;
     if (const char* v = getenv("NGW_HOST_DELTA")) h->host_delta = atoi(v) != 0;
+    if (const char* v = getenv("NGW_ZC_BYTES")) { h->zc_bytes = (size_t)atoll(v); if (!h->zc_bytes) h->zc_bytes = 1; }
     {
         int min_s2 = 256;                                  // 16 x 16 and larger (measured: see DESIGN.md)
         if (const char* v = getenv("NGW_NOSTAGE")) min_s2 = atoi(v);
@@ -1114,12 +1116,7 @@ int ngw_sync(ngw_handle* h) {
 // ngw_step_host: up to here the outputs go through mapped host memory (a kernel writing across PCIe sustains ~12 GB/s, the copy
 // engine ~26 GB/s but costs ~15 us to get going: measured crossover 256-512 KB, tools/api_latency.py with NGW_ZC_BYTES - 16 384
 // envs, 2.6 MB: 186-230 us through mapped memory, 125-140 us staged and copied)
-static size_t zero_copy_bytes() {
-    static size_t v = 0;
-    if (!v) { const char* e = getenv("NGW_ZC_BYTES"); v = e ? (size_t)atoll(e) : (size_t)256 << 10; if (!v) v = 1; }
-    return v;
-}
-#define NGW_ZERO_COPY_BYTES zero_copy_bytes()
+#define NGW_ZERO_COPY_BYTES (h->zc_bytes)
 
 
 int ngw_get_obs(ngw_handle* h, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv) {

@@ -108,6 +108,8 @@ class VecNovelGridworld:
         from . import spaces
         self.action_space = spaces.Discrete(spec.action_space_n)           # per env; NOT grown by axe/additem
         self.observation_space = spaces.Dict({'map': spaces.Box(low=0, high=spec.max_items, shape=(spec.map_size, spec.map_size, 1))})
+        import os
+        self._zc_bytes = int(os.environ.get('NGW_ZC_BYTES', 256 << 10)) or 1     # (read where ngw_create reads it)
         L = _cabi.lib()
         _cabi.check(L.ngw_create(C.byref(self.cspec), self.num_envs, self.device, self.seed, self.env_index_base,
                                  C.byref(self._h)))
@@ -257,11 +259,9 @@ class VecNovelGridworld:
     def _one_block_path(self):
         """Does ngw_step_host take its one-block path (pack + one copy, delta refresh) for this env's full step()?  The rule of
         ngw_abi.cpp: more than one wavefront of envs and more output bytes than the zero-copy limit (NGW_ZC_BYTES, 256 KiB)."""
-        import os
         n, S2, K = self.num_envs, self.map_size ** 2, self.n_items
         total = sum((b + 255) & ~255 for b in (n * S2, n * 8, n * 4, n * K * 4, n * 4, n, 4, n, n * 4))
-        zc = int(os.environ.get('NGW_ZC_BYTES', 256 << 10)) or 1
-        return n > 64 and total > zc
+        return n > 64 and total > self._zc_bytes
 
     def refresh_host(self):
         """The next step() copies the whole observation to the host again instead of only what changed since the last step()

@@ -61,8 +61,27 @@ def one_case(rs, cfg, case):
     prefetch = prefetch if prefetch == 'auto' else int(prefetch)
     seed, base = int(rs.randint(0, 2 ** 31)), int(rs.randint(0, 10 ** 6))
     depth = int(rs.choice([0, 0, 1, 2, 4]))                 # prepared episodes per env (0 = automatic)
-    v = VecNovelGridworld(spec=spec, num_envs=n, seed=seed, autoreset=autoreset, horizon=horizon, reset_prefetch=prefetch, env_index_base=base,
+    # half the cases take the big-batch form of the host step (one page-locked block, delta refresh) at these small sizes too
+    zc = os.environ.pop('NGW_ZC_BYTES', None)
+    small_block = bool(rs.randint(0, 2))
+    if small_block:
+        os.environ['NGW_ZC_BYTES'] = '2048'
+    try:
+        v = _make(spec, n, seed, autoreset, horizon, prefetch, base, depth)
+    finally:
+        os.environ.pop('NGW_ZC_BYTES', None)
+        if zc is not None:
+            os.environ['NGW_ZC_BYTES'] = zc
+    return _run_case(rs, cfg, case, spec, v, n, A, S, horizon, autoreset, prefetch, depth, seed, base, small_block)
+
+
+def _make(spec, n, seed, autoreset, horizon, prefetch, base, depth):
+    return VecNovelGridworld(spec=spec, num_envs=n, seed=seed, autoreset=autoreset, horizon=horizon, reset_prefetch=prefetch, env_index_base=base,
                           reset_prefetch_depth=depth)
+
+
+def _run_case(rs, cfg, case, spec, v, n, A, S, horizon, autoreset, prefetch, depth, seed, base, small_block):
+    import torch
     o = Oracle(spec.compile(), n, seed=seed, autoreset=autoreset, horizon=horizon, env_index_base=base)
     lid = None
     if rs.randint(0, 3) == 0:                               # one case in three runs with the fused lidar epilogue
@@ -70,7 +89,7 @@ def one_case(rs, cfg, case):
         lc = LidarConfig(spec, int(rs.choice([4, 8])))
         v.lidar_configure(lc, fused=True)
         lid = (lc.compile(spec), S, len(spec.items_id))
-    tag = '%s case %d (n=%d H=%d auto=%d prefetch=%s depth=%d lidar=%d)' % (cfg, case, n, horizon, autoreset, prefetch, depth, lid is not None)
+    tag = '%s case %d (n=%d H=%d auto=%d prefetch=%s depth=%d lidar=%d block=%d)' % (cfg, case, n, horizon, autoreset, prefetch, depth, lid is not None, small_block)
     if not both_reset(v, o, None, tag):
         v.close()
         return
@@ -90,8 +109,11 @@ def one_case(rs, cfg, case):
                 for _ in range(int(rs.randint(1, 12))):
                     a = rs.randint(0, A, size=n).astype(np.int32)
                     ostep(a)
-                    _, reward, done, info = v.step(a)
+                    obs, reward, done, info = v.step(a)
                     assert (reward == o.reward).all() and (done == o.done.astype(bool)).all() and (info['message_code'] == o.msg_code).all(), tag
+                    if not ofail[0]:
+                        assert (obs['map'].reshape(n, -1) == o.st.map).all() and (obs['inventory_items_quantity'] == o.st.inv).all(), tag + ': host observation'
+                        assert (obs['agent_location'] == o.st.loc).all() and (obs['agent_facing_id'] == o.st.facing).all(), tag + ': host observation'
             elif kind == 'dev':
                 k = int(rs.randint(1, 9))
                 an = rs.randint(0, A, size=(k, n)).astype(np.int32)
