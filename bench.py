@@ -163,6 +163,9 @@ def main():
     ap.add_argument('--adapt-steps', type=int, default=-1,
                     help='untimed eager steps before everything else, so that the handle has adapted its prepared-episode depth / refill '
                          'cadence to the workload before the graph is captured (default: 3000 for the high-churn tuning cases X*, else 0)')
+    ap.add_argument('--clock-warm-ms', type=float, default=250.0,
+                    help='keep the GPU busy this long on a SCRATCH handle before anything is measured (a fresh process finds the device in a '
+                         'low power state, and 5 warm-up steps are 25 us); 0 = off')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stagger', action='store_true', help='skip the staggered-episode-ends side measurement')
     ap.add_argument('--no-side', action='store_true', help='skip every side measurement (fused rollout, API mode, C1, stagger): tuning runs')
@@ -217,6 +220,17 @@ def main():
     def episode0():
         return int(v.get_state(0, 1)['episode'][0])
 
+    if args.clock_warm_ms > 0:
+        # device clocks: a scratch handle of the same shape runs fused rollouts until the time is up; nothing of it is measured and
+        # the measured handle `v` is not touched (its W warm-up steps and K timed steps follow exactly as the contract says)
+        from gym_novel_gridworlds_amd import VecNovelGridworld
+        scratch = VecNovelGridworld(spec=spec, num_envs=n, seed=99, autoreset=True, horizon=HORIZON, device=local_rank)
+        scratch.reset()
+        t_end = time.perf_counter() + args.clock_warm_ms * 1e-3
+        while time.perf_counter() < t_end:
+            scratch.rollout(200, ACTION_SEED, 0)
+            scratch.sync()
+        scratch.close()
     adapt_steps = args.adapt_steps if args.adapt_steps >= 0 else (3000 if args.workload.startswith('X') else 0)
     if adapt_steps and args.mode == 'step':
         # a live loop adapts by itself (ngw_abi.cpp adapt_cadence: deeper prepared episodes, then more frequent refills, when envs end
@@ -468,7 +482,7 @@ def main():
         total = n * world * steps
         line = {
             'metric': 'env-steps/sec', 'value': round(total / dt, 1), 'unit': 'env-steps/s', 'n_gpus': world,
-            'steps': steps, 'warmup': warmup, 'adapt_steps': adapt_steps if args.mode == 'step' else 0,
+            'steps': steps, 'warmup': warmup, 'adapt_steps': adapt_steps if args.mode == 'step' else 0, 'clock_warm_ms': args.clock_warm_ms,
             'prepared_episodes': {'refill_every': v.refill_cadence, 'depth': v.reset_prefetch_depth}, 'ms_per_step': round(dt / steps * 1e3, 6), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8/int32', 'data': 'synthetic',
             'config': {'workload': desc, 'name': args.workload, 'envs_per_gpu': n, 'global_envs': n * world,
