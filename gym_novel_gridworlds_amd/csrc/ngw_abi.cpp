@@ -89,6 +89,8 @@ struct ngw_handle {
     // between refills - FireWall kills within a few steps) are counted on the device; the refill launch copies the count to a
     // host word and the host halves the cadence while it keeps growing, and doubles it back after four quiet refills.
     int cadence = 0, quiet = 0, noisy = 0, adapt = 1;
+    int quiet_need = 4;                   // quiet refills before the cadence is doubled back (grows when a doubling had to be undone)
+    bool probing = false;                 // the last change was a doubling
     uint32_t slow_seen = 0, refill_seen = 0, refill_count = 0;   // reports read / refill launches issued
     bool capturing = false;
     bool adapted = false;                 // adapt_cadence changed depth or cadence: a captured graph is stale (ngw_graph_launch re-captures it)
@@ -344,7 +346,7 @@ void layout_reset_fast(ngw_handle* h) {
     a.off_dom = off; if (subset) off += NBW;
     a.off_mcol = off; if (subset) off += NBW * NGW_EPB;
     off = (off + 3u) & ~3u;
-    a.off_tile = off; off += 144 * NGW_EPB / 4;                                     // staging tile of the composed rows: [64][128 + 16] bytes
+    a.off_tile = off; off += (uint32_t)((S2 <= 512 ? (S2 * NGW_EPB + 15) / 16 * 16 : 144 * NGW_EPB) / 4);   // staging tile of the composed rows: the chunk's exact image up to 512-byte rows, else [64][128 + 16] bytes
     if ((size_t)off * 4 > 160 * 1024) return;
     h->rf_lds = (size_t)off * 4;
     h->rf_nw = nw; h->rf_additem = subset ? 1 : 0;
@@ -363,6 +365,8 @@ void layout_reset_fast(ngw_handle* h) {
     a.magicW = W ? (uint32_t)((0x100000000ull + W - 1) / W) : 0;
     a.magicS = (uint32_t)((0x100000000ull + (uint32_t)S - 1) / (uint32_t)S);
     a.sub_nb = nb; a.sub_fields = 32 / nb;
+    a.img = S2 <= 512 ? 1 : 0;
+    a.magicS2 = (uint32_t)((0x100000000ull + (uint32_t)S2 - 1) / (uint32_t)S2);
     {
         const int tail = S2 % 128, ush = (S2 & 15) == 0 ? 4 : ((S2 & 3) == 0 ? 2 : 0);
         const uint32_t nu = (uint32_t)((tail + (1 << ush) - 1) >> ush);
@@ -429,7 +433,8 @@ int publish_nx(ngw_handle* h, bool on) {
 // a step and the whole launch waits for it, so those resets are counted on the device and reported by every refill.  Too
 // many of them per refill - more than one step in eight of the window would be slow - and the prepared episodes first get
 // DEEPER (2, then 4 per env: an env may then end that many episodes between two refills), then refills get more frequent;
-// four quiet refills in a row make them less frequent again.  Results never depend on any of it.
+// four quiet refills in a row make them less frequent again (sixteen, sixty-four, ... after a doubling that had to be taken
+// back: no ping-pong between two cadences).  Results never depend on any of it.
 void adapt_cadence(ngw_handle* h) {
     if (h->capturing || h->prefetch_user || !h->adapt || !h->nx.slow_host) return;
     // what the last refill launch THE GPU HAS RUN reported: its number and the count of stale-row resets so far.  The host may be
@@ -453,14 +458,20 @@ void adapt_cadence(ngw_handle* h) {
                     layout_reset_fast_nx(h);
                     h->since_refill = every;                        // (every row is stale now: refill at once)
                 }
-            } else h->cadence = h->cadence / 2 < 2 ? 2 : h->cadence / 2;
+            } else {
+                h->cadence = h->cadence / 2 < 2 ? 2 : h->cadence / 2;
+                // a doubling that had to be taken back: the next attempt waits four times as long (no ping-pong between two levels)
+                if (h->probing) h->quiet_need = h->quiet_need * 4 > 4096 ? 4096 : h->quiet_need * 4;
+            }
+            h->probing = false;
             h->adapted = true;
         }
     } else {
         h->noisy = 0;
-        if (h->cadence < h->prefetch_every && (h->quiet += refills) >= 4) {
+        if (h->cadence < h->prefetch_every && (h->quiet += refills) >= h->quiet_need) {
             h->cadence = h->cadence * 2 > h->prefetch_every ? h->prefetch_every : h->cadence * 2;
             h->quiet = 0;
+            h->probing = true;
             h->adapted = true;
         }
     }
@@ -862,7 +873,7 @@ int ngw_set_reset_prefetch(ngw_handle* h, int32_t every_n_steps) {
     if (int rc = publish_nx(h, every_n_steps > 0)) return rc;
     layout_reset_fast_nx(h);
     h->prefetch_every = every_n_steps;
-    h->cadence = every_n_steps; h->quiet = 0; h->noisy = 0;
+    h->cadence = every_n_steps; h->quiet = 0; h->noisy = 0; h->quiet_need = 4; h->probing = false;
     h->prefetch_user = 1;
     h->since_refill = every_n_steps;                 // the next launch is followed by a refill
     return NGW_OK;

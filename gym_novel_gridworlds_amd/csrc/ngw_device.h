@@ -196,6 +196,8 @@ struct NgwResetFast {            // kernel arguments (by value)
     uint32_t magicS;             // ceil(2^32 / S)
     int32_t sub_nb, sub_fields;  // subset pass candidates: bits of a cell index (bit_length(S*S - 1)), fields per 32-bit word
     uint32_t magic_tail;         // ceil(2^32 / store units of the last (short) 128-byte window of a row), 0 if S*S % 128 == 0
+    uint32_t magicS2;            // ceil(2^32 / (S*S)): byte offset inside the wave's chunk -> env
+    int32_t img;                 // rows up to 512 bytes: the LDS tile is the exact image of the wave's 64 rows, stored as one coalesced run
     uint32_t off_ring, off_masks, off_placed, off_tmpl, off_dom, off_mcol, off_tile;    // LDS dword offsets
     uint64_t* stamps;            // diagnostics builds (-DNGW_STAMPS), or nullptr
 };

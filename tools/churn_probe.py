@@ -20,14 +20,14 @@ v.reset()
 acts = torch.randint(0, A, (64, n), dtype=torch.int32, device='cuda')
 torch.cuda.synchronize()
 ep0 = int(v.get_state()['episode'].sum())
-for rep in range(6):
+for rep in range(12):
     s0 = L.ngw_debug_slow_resets(v._h)
     v.timing_begin()
     for i in range(256):
         v.step_device(acts[i % 64].data_ptr())
     ms = v.timing_end()
     ep1 = int(v.get_state()['episode'].sum())
-    print('%s eager 256 steps: %.2f us per step; cadence now %d; resets %d (%.2f %% of the envs per step), of which %d missed their prepared episode'
-          % (wl, ms * 1e3 / 256, L.ngw_debug_refill_cadence(v._h), ep1 - ep0, 100.0 * (ep1 - ep0) / 256 / n, L.ngw_debug_slow_resets(v._h) - s0), flush=True)
+    print('%s eager 256 steps: %.2f us per step; cadence now %d, depth %d; resets %d (%.2f %% of the envs per step), of which %d missed their prepared episode'
+          % (wl, ms * 1e3 / 256, L.ngw_debug_refill_cadence(v._h), v.reset_prefetch_depth, ep1 - ep0, 100.0 * (ep1 - ep0) / 256 / n, L.ngw_debug_slow_resets(v._h) - s0), flush=True)
     ep0 = ep1
 v.close()
