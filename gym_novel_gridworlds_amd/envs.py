@@ -258,13 +258,8 @@ class _NovelGridworldEnv(_EnvBase):
         self.last_reward = 0
         self.last_done = False
         vec = self._backend(full_check=True)
-        reset1 = getattr(vec, 'reset1', None)
-        if reset1 is not None:                               # device handle: one C-ABI call that also brings the state back
-            reset1()                                         # AssertionError(PLACEMENT_MESSAGE) when items do not fit
-            self._pull(vec, vec.last_state())
-        else:
-            vec.reset()
-            self._pull(vec)
+        vec.reset1()                                         # one C-ABI call that also brings the state back; AssertionError(PLACEMENT_MESSAGE) when items do not fit
+        self._pull(vec, vec.last_state())
         obs = self.get_observation()
         self.update_block_in_front()
         return obs
@@ -281,15 +276,8 @@ class _NovelGridworldEnv(_EnvBase):
         self.last_action = name
         vec = self._backend()
         self._push(vec)
-        step1 = getattr(vec, 'step1', None)
-        if step1 is not None:                                # device handle: one C-ABI call, scalars back (no per-step arrays)
-            reward, done, result, cost_code, msg_code, msg_arg = step1(action_id)
-            self._pull(vec, vec.last_state())                # the call already brought the state back
-        else:                                                # oracle-backed stand-in of the CPU tests
-            _, rw, dn, info = vec.step(np.array([action_id], np.int32))
-            self._pull(vec, vec.last_state() if hasattr(vec, 'last_state') else None)
-            reward, done, result = int(rw[0]), info_done(dn), bool(info['result'][0])
-            cost_code, msg_code, msg_arg = int(info['step_cost_code'][0]), int(info['message_code'][0]), int(info['message_arg'][0])
+        reward, done, result, cost_code, msg_code, msg_arg = vec.step1(action_id)   # one C-ABI call, scalars back (no per-step arrays)
+        self._pull(vec, vec.last_state())                    # the call already brought the state back
         obs = self.get_observation()
         self.update_block_in_front()
         step_cost = STEP_COSTS[cost_code]
@@ -436,10 +424,6 @@ class _NovelGridworldEnv(_EnvBase):
 
     def close(self):
         self._close_backend()
-
-
-def info_done(done):
-    return bool(np.asarray(done).reshape(-1)[0])
 
 
 class PogostickV1Env(_NovelGridworldEnv):

@@ -331,6 +331,19 @@ class OracleVec:
         info = {'result': o.result.astype(bool), 'step_cost_code': o.cost_code, 'message_code': o.msg_code, 'message_arg': o.msg_arg}
         return None, o.reward.copy(), o.done.astype(bool), info
 
+    # the one-env entry points the gym.Env adapter drives (VecNovelGridworld.reset1 / step1 / last_state)
+    def reset1(self):
+        self.reset()
+
+    def step1(self, action):
+        _, reward, done, info = self.step(np.array([action], np.int32))
+        return (int(reward[0]), bool(done[0]), bool(info['result'][0]), int(info['step_cost_code'][0]), int(info['message_code'][0]),
+                int(info['message_arg'][0]))
+
+    def last_state(self):
+        st = self.o.st
+        return dict(map=st.map, loc=st.loc, facing=st.facing, inv=st.inv, selected=st.selected, step_count=st.step_count)
+
     def get_state(self, first=0, count=None):
         st = self.o.st
         count = self.num_envs - first if count is None else count
