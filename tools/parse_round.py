@@ -51,8 +51,11 @@ out = ['# rocprofv3 --kernel-trace --stats summaries (%s)\n' % ROUND,
        'hipGraph (what `bench.py` times with a HIP event pair: the command processor prepares dispatch i+1 while dispatch i runs).  Under '
        '`rocprofv3 --kernel-trace` every dispatch is bracketed by profiling signals and its start stamp is taken when the packet is picked '
        'up, so a kernel this short shows its whole un-overlapped dispatch: the same bench command reports %s us per batched step while it '
-       'is being traced (its own JSON line below) against 4.4 us untraced, and the per-kernel average of the trace (6.1 us at C2) sits '
-       'between the two.  Both numbers are given; `roofline.achieved` uses the untraced event-pair average, as the bench contract says.\n']
+       'is being traced (its own JSON line below) against 4.3 us untraced, and the per-kernel average of the trace sits '
+       'between the two.  Both numbers are given; `roofline.achieved` uses the untraced event-pair average, as the bench contract says.\n',
+       '**The ~1 600 `ngw_rollout_lean` + refill (`ngw_kernel<., 3, .>`) launches at the top of every table** are `bench.py`\'s 250 ms device clock '
+       'warm-up on a SCRATCH handle (`--clock-warm-ms`), before anything is measured; the measured handle\'s launches are the `ngw_step_lean` rows '
+       '(warm-up + timed steps) and the few reset / refill launches beside them.\n']
 ms = []
 for W in ('C2', 'C3', 'C4', 'C5'):
     ln = bench_line('stats_%s.log' % W)
