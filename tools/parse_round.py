@@ -61,7 +61,7 @@ for W in ('C2', 'C3', 'C4', 'C5'):
     ln = bench_line('stats_%s.log' % W)
     if ln:
         ms.append('%s %.1f' % (W, ln['ms_per_step'] * 1e3))
-out[-1] = out[-1] % ', '.join(ms)
+out[-2] = out[-2] % ', '.join(ms)                        # (the paragraph about traced vs untraced step times)
 for W, mode in (('driver', 'step'), ('C2', 'step'), ('C3', 'step'), ('C4', 'step'), ('C5', 'step'), ('C2_rollout', 'rollout')):
     f = first('stats_%s/**/*kernel_stats.csv' % W)
     if not f:
