@@ -31,24 +31,37 @@ def main():
         if nov:
             apply_novelty(spec, *nov)
         A = len(spec.actions_id)
-        v = VecNovelGridworld(spec=spec, num_envs=n, device=0, seed=0, autoreset=True, horizon=100, reset_prefetch=0)
+        stagger = os.environ.get('NGW_STAGGER') == '1'   # episode ends spread over the batch, rows prepared: the cold path in the sampled launch
+        v = VecNovelGridworld(spec=spec, num_envs=n, device=0, seed=0, autoreset=True, horizon=100, reset_prefetch=(1 << 20) if stagger else 0)   # (rows prepared by reset(); no refill launch among the sampled steps)
         v.reset()
+        if stagger:
+            v.set_state(0, step_count=(np.arange(n) * 7919 % 100).astype(np.int32))
         grid = (n + 63) // 64
         stamps = torch.zeros((grid, 16), dtype=torch.int64, device='cuda')
         acts = torch.randint(0, A, (40, n), dtype=torch.int32, device='cuda')
         torch.cuda.synchronize()
         _cabi.check(L.ngw_debug_set_stamps(v._h, C.c_void_p(stamps.data_ptr())))
-        v.graph_build(acts.data_ptr(), n, 40)
-        v.graph_launch(1)
-        v.sync()
-        v.timing_begin()
-        v.graph_launch(1)
-        ms = v.timing_end()
+        if stagger:                                      # eager launches: a captured graph with prepared episodes ends in a refill launch
+            for i in range(30):
+                v.step_device(acts[i].data_ptr())
+            v.sync()
+            stamps.zero_()
+            torch.cuda.synchronize()
+            v.timing_begin()
+            v.step_device(acts[30].data_ptr())
+            ms = v.timing_end() * 40
+        else:
+            v.graph_build(acts.data_ptr(), n, 40)
+            v.graph_launch(1)
+            v.sync()
+            v.timing_begin()
+            v.graph_launch(1)
+            ms = v.timing_end()
         st = stamps.cpu().numpy()
         rt, cy = st[:, :8].astype(np.float64), st[:, 8:].astype(np.float64)
         t0 = rt[:, 0].min()
         names = LEAN if rt[:, 7].max() > 0 else NAMES           # the lean kernel fills all eight slots
-        print('== %s: %s; %d waves; event time per launch %.2f us' % (wl, desc, grid, ms / 40 * 1e3))
+        print('== %s%s: %s; %d waves; event time per launch %.2f us' % (wl, ' (staggered episode ends)' if stagger else '', desc, grid, ms / 40 * 1e3))
         print('%-16s %8s %8s %8s %8s %8s   (us after the first wave entered)' % ('stamp', 'min', 'p10', 'median', 'p90', 'max'))
         for i, nm in enumerate(names):
             x = (rt[:, i] - t0) * 0.01
@@ -58,6 +71,9 @@ def main():
         for i in range(1, last + 1):
             d = cy[:, i] - cy[:, i - 1]
             print('  %-16s -> %-16s %8.0f %8.0f' % (names[i - 1], names[i], np.median(d), np.percentile(d, 90)))
+        if stagger and last >= 6:                        # the cold path sits between 'outputs begin' and 'outputs issued'
+            d = cy[:, 6] - cy[:, 5]
+            print('  outputs begin -> outputs issued, percentiles 10/25/50/75/90/99: ' + ' '.join('%.0f' % np.percentile(d, q) for q in (10, 25, 50, 75, 90, 99)))
         life = cy[:, last] - cy[:, 0]
         print('  wave life %.0f cycles median; clock ~%.2f GHz' % (np.median(life), np.median(life / np.maximum((rt[:, last] - rt[:, 0]) * 10.0, 1.0))))
         _cabi.check(L.ngw_debug_set_stamps(v._h, None))
