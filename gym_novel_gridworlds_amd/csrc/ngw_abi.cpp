@@ -1206,6 +1206,11 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
             if (!h->zc_host) return NGW_E_HIP;
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zc_dev), h->zc_host, 0));
         }
+#ifdef NGW_HOSTTRACE
+        static double tA = 0, tB = 0, tC = 0, tD = 0; static int tn = 0;
+        auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
+        const double t0 = now();
+#endif
         memcpy(h->zc_host, actions_host, n * sizeof(int32_t));
         // The kernel writes this launch's sequence number to host memory once its stores are out: polling that word costs a
         // PCIe write's latency, a stream synchronisation several microseconds (and would also wait for a refill launch that
@@ -1215,6 +1220,9 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
         const int lrc = launch(h, NGW_MODE_STEP, 1, reinterpret_cast<const int32_t*>(h->zc_dev), nullptr, 0, 0);
         h->launch_seq = 0;
         if (lrc) return lrc;
+#ifdef NGW_HOSTTRACE
+        const double t1 = now();
+#endif
         {
             volatile uint32_t* sp = h->b.flags_host + NGW_SEQ_WORD;
             bool seen = false;
@@ -1229,10 +1237,18 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
             if (!seen) HIP_TRY(hipStreamSynchronize(h->stream));
             __atomic_thread_fence(__ATOMIC_ACQUIRE);                                // the state reads below stay behind the poll
         }
+#ifdef NGW_HOSTTRACE
+        const double t2 = now();
+#endif
         for (int r = 0; r < INFO; r++)
             if (outs[r].host && r != 6) memcpy(outs[r].host, outs[r].dev, outs[r].bytes);
         if (error_flags) *error_flags = *h->b.flags_host;             // sticky: ngw_error_flags reads and clears it (with the device word)
         if (want_info) info_words = h->b.info;
+#ifdef NGW_HOSTTRACE
+        const double t3 = now();
+        tA += t1 - t0; tB += t2 - t1; tC += t3 - t2; (void)tD;
+        if (++tn == 1000) { fprintf(stderr, "[hosttrace] launch %.2f us, wait %.2f us, copy-out %.2f us\n", tA / tn, tB / tn, tC / tn); tA = tB = tC = 0; tn = 0; }
+#endif
     } else if (total > NGW_ZERO_COPY_BYTES && map && one_block(h, map, loc, facing, inv, reward, done, error_flags, selected, step_count)) {
         // Big batch whose output arrays are the sections of ONE page-locked block (ngw_host_step_layout).  The caller keeps that
         // block from call to call (VecNovelGridworld's host mirrors), so it already holds the previous step's observation:

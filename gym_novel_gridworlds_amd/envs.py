@@ -14,7 +14,6 @@ from `VecNovelGridworld`.
 """
 import copy
 
-import marshal as _marshal
 
 import numpy as np
 
@@ -107,25 +106,19 @@ class _NovelGridworldEnv(_EnvBase):
         sp.reward_intermediate, sp.reward_done = self.reward_intermediate, self.reward_done
         return sp
 
-    def _fingerprint(self):
-        """Per-step check that the compiled spec still matches the env's public tables.  The reference reads `self.recipes`,
-        `items_id`, `actions_id` ... live on every step, and its users edit them in place between steps (a wrapper that
-        changes a recipe's output mid-episode), so identities and sizes are not enough: the small tables go in by CONTENT
-        (marshal of the nested recipe dict ~1.4 us, tuples of the id tables, hashes of the sets), plus the spec's edit
-        counters (novelty injection).  The full key is only rebuilt when this changes - and on every reset()."""
+    def _tables(self):
+        """What the compiled spec was built from, as the LIVE objects.  The reference reads `self.recipes`, `items_id`,
+        `actions_id` ... on every step, and its users edit them in place between steps (a wrapper that changes a recipe's
+        output mid-episode), so identities and sizes are not enough: every step compares this tuple with a deep copy taken
+        when the handle was last checked - one `==` that walks the small tables by CONTENT in C (~0.5 us; serialising them
+        for a hashable fingerprint cost 1.2 us) - plus the spec's edit counter (every novelty injection appends to it)."""
         sp = self._spec
-        try:
-            recipes = _marshal.dumps(self.recipes)
-        except ValueError:                                   # (values marshal does not take, e.g. numpy integers)
-            recipes = repr(self.recipes)
-        return (int(self.map_size), recipes, tuple(self.items_id.items()), tuple(self.actions_id.items()),
-                tuple(self.items_quantity.items()), hash(frozenset(self.entities)), hash(frozenset(self.unbreakable_items)),
-                self.goal_item_to_craft, self.reward_done, self.reward_intermediate,
-                len(sp.novelties), id(sp.axe), id(sp.additem), id(sp.replace), id(sp.fence), id(sp.fence_pred), len(sp.reset_passes), id(sp.crate), sp.fire_wall, sp.break_increase)
+        return (self.map_size, self.recipes, self.items_id, self.actions_id, self.items_quantity, self.entities, self.unbreakable_items,
+                self.goal_item_to_craft, self.reward_done, self.reward_intermediate, len(sp.novelties), sp.fire_wall, sp.break_increase)
 
     def _backend(self, full_check=False):
-        fp = self._fingerprint()
-        if self._vec is not None and fp == self._vec_fp and not full_check:
+        now = self._tables()
+        if self._vec is not None and not full_check and now == self._vec_fp:
             return self._vec
         sp = self._sync_spec()      # callers may REBIND the public tables (env.items_quantity = {...}): the spec follows the env's attributes
         key = (sp.map_size, tuple(sp.items_id.items()), tuple(sp.actions_id.items()), tuple(sp.items_quantity.items()),
@@ -151,7 +144,8 @@ class _NovelGridworldEnv(_EnvBase):
             self._dev_state_of = None
             if self._episode_base:
                 vec.set_state(0, episode=np.array([self._episode_base], np.uint32))
-        self._vec_fp = fp
+        if now != self._vec_fp:                              # (reset() re-checks the key every time: the snapshot only when a table changed)
+            self._vec_fp = copy.deepcopy(now)
         return self._vec
 
     _VEC_CACHE = 16
@@ -191,12 +185,16 @@ class _NovelGridworldEnv(_EnvBase):
         self._dev_state_of = vec
 
     def _pull(self, vec, st=None):
-        """device state -> host attributes (the map array object is kept: observations alias it)"""
+        """device state -> host attributes (the map array object is kept: observations alias it).  `st` None: the host buffers
+        the last step1() / reset1() filled; else a get_state() dict."""
         if st is None:
-            st = vec.get_state(0, 1)
+            mb, r, c, f, ib, sel, steps = vec.last_state1()
+        else:
+            mb, ib = st['map'][0].tobytes(), st['inv'][0].tobytes()
+            r, c, f = int(st['loc'][0][0]), int(st['loc'][0][1]), int(st['facing'][0])
+            sel, steps = int(st['selected'][0]), int(st['step_count'][0])
         S = self.map_size
         # most steps change neither the map nor the inventory: compare the raw rows with the last pull's before rebuilding anything
-        mb = st['map'][0].tobytes()
         if mb != self._m8 or self.map.shape != (S, S) or self._known is None or self._dev_state_of is not vec:
             if self.map.shape != (S, S):
                 self.map = np.zeros((S, S), dtype=int)
@@ -205,20 +203,18 @@ class _NovelGridworldEnv(_EnvBase):
             m64 = self.map.tobytes()
         else:
             m64 = self._known[5]
-        loc = st['loc'][0]
-        self.agent_location = (int(loc[0]), int(loc[1]))
-        self.set_agent_facing(DIRECTION_STR[int(st['facing'][0])])
+        self.agent_location = (r, c)
+        self.agent_facing_id = f
+        self.agent_facing_str = DIRECTION_STR[f]
         names = self._spec.item_names
         inv = self.inventory_items_quantity
-        ib = st['inv'][0].tobytes()
         if ib != self._i32 or self._inv_known != inv:
-            for name, q in zip(names, st['inv'][0].tolist()):
+            for name, q in zip(names, np.frombuffer(ib, np.int32).tolist()):
                 inv[name] = q
             self._i32, self._inv_known = ib, dict(inv)
-        sel = int(st['selected'][0])
         self.selected_item = names[sel] if sel else ''
-        self.step_count = int(st['step_count'][0])
-        self._known = (self.agent_location, self.agent_facing_id, self.selected_item, self.step_count, self._inv_known, m64, self.map.shape)
+        self.step_count = steps
+        self._known = (self.agent_location, f, self.selected_item, steps, self._inv_known, m64, self.map.shape)
         self._dev_state_of = vec
 
     # ------------------------------------------------------------------ reference API
@@ -259,7 +255,7 @@ class _NovelGridworldEnv(_EnvBase):
         self.last_done = False
         vec = self._backend(full_check=True)
         vec.reset1()                                         # one C-ABI call that also brings the state back; AssertionError(PLACEMENT_MESSAGE) when items do not fit
-        self._pull(vec, vec.last_state())
+        self._pull(vec)
         obs = self.get_observation()
         self.update_block_in_front()
         return obs
@@ -277,7 +273,7 @@ class _NovelGridworldEnv(_EnvBase):
         vec = self._backend()
         self._push(vec)
         reward, done, result, cost_code, msg_code, msg_arg = vec.step1(action_id)   # one C-ABI call, scalars back (no per-step arrays)
-        self._pull(vec, vec.last_state())                    # the call already brought the state back
+        self._pull(vec)                                      # the call already brought the state back
         obs = self.get_observation()
         self.update_block_in_front()
         step_cost = STEP_COSTS[cost_code]

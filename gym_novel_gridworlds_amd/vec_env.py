@@ -133,7 +133,7 @@ class VecNovelGridworld:
         the env they wrap and keep its identity (novelty_wrappers.py:1586-1674), so a rank-local shard stays that shard.
         The state is undefined until the next reset(), as after construction."""
         self.close()
-        for name in VecNovelGridworld._HOST_ATTRS + ('_host', '_step_args', '_step1_args', '_step1_fn', '_reset1_args', '_last_state_views', '_lidar_host', '_view_host', '_last_actions'):
+        for name in VecNovelGridworld._HOST_ATTRS + ('_host', '_step_args', '_step1_args', '_step1_fn', '_step1_mv', '_state1_mv', '_reset1_args', '_last_state_views', '_lidar_host', '_view_host', '_last_actions'):
             self.__dict__.pop(name, None)
         self._open(spec)
         return self
@@ -281,13 +281,30 @@ class VecNovelGridworld:
                 p(self._done, np.uint8), p(self._result, np.uint8), p(self._cost, np.uint8), p(self._msg, np.uint16), p(self._arg, np.uint16),
                 p(self._flags_np, np.uint32), p(self._sel_host, np.uint8), p(self._steps_host, np.int32))
             self._step1_fn = _cabi.lib().ngw_step_host
-        self._act_pinned[0] = action
+            # memoryviews of the one-element host buffers: indexing them yields Python ints without a numpy scalar in between
+            self._step1_mv = tuple(memoryview(x) for x in (self._act_pinned, self._reward, self._done, self._result, self._cost, self._msg,
+                                                             self._arg, self._flags_np))
+        act, reward, done, result, cost, msg, arg, flags = self._step1_mv
+        act[0] = action
         rc = self._step1_fn(*args)
         if rc:
             _cabi.check(rc)
-        if self._flags_np[0]:
+        if flags[0]:
             self._raise_flags()
-        return (int(self._reward[0]), bool(self._done[0]), bool(self._result[0]), int(self._cost[0]), int(self._msg[0]), int(self._arg[0]))
+        return (reward[0], done[0] != 0, result[0] != 0, cost[0], msg[0], arg[0])
+
+    def last_state1(self):
+        """The one env's state after the last step1() / reset1() as plain Python values - (map row bytes, r, c, facing,
+        inventory row bytes, selected item id, step_count) - read from the host buffers that call filled."""
+        mv = self.__dict__.get('_state1_mv')
+        if mv is None:
+            assert self.num_envs == 1
+            o = self._obs
+            mv = self._state1_mv = (memoryview(o['map']).cast('B'), memoryview(o['agent_location']).cast('B').cast('i'),
+                                    memoryview(o['agent_facing_id']), memoryview(o['inventory_items_quantity']).cast('B'),
+                                    memoryview(self._sel_host), memoryview(self._steps_host))
+        m, loc, fac, inv, sel, steps = mv
+        return m.tobytes(), loc[0], loc[1], fac[0], inv.tobytes(), sel[0], steps[0]
 
     def last_state(self):
         """State after the last step() as get_state() would return it, from the host buffers that call filled (no device

@@ -344,6 +344,11 @@ class OracleVec:
         st = self.o.st
         return dict(map=st.map, loc=st.loc, facing=st.facing, inv=st.inv, selected=st.selected, step_count=st.step_count)
 
+    def last_state1(self):
+        st = self.o.st
+        return (np.ascontiguousarray(st.map[0], np.int8).tobytes(), int(st.loc[0][0]), int(st.loc[0][1]), int(st.facing[0]),
+                np.ascontiguousarray(st.inv[0], np.int32).tobytes(), int(st.selected[0]), int(st.step_count[0]))
+
     def get_state(self, first=0, count=None):
         st = self.o.st
         count = self.num_envs - first if count is None else count

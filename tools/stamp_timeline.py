@@ -27,6 +27,7 @@ def main():
     L.ngw_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
     for wl in (sys.argv[1:] or ['C2']):
         env_id, S, nov, n, desc = bench.WORKLOADS[wl]
+        n = int(os.environ.get('NGW_N', n))               # (NGW_N=1: the single-env adapter's handle, state in host memory)
         spec = make_spec(env_id, S)
         if nov:
             apply_novelty(spec, *nov)
