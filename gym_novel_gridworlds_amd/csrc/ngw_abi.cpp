@@ -63,15 +63,17 @@ struct ngw_handle {
     int host_delta = 1;                   // NGW_HOST_DELTA=0: every ngw_step_host copies the whole observation (A/B)
     size_t zc_bytes = (size_t)256 << 10;  // NGW_ZC_BYTES: largest ngw_step_host result written straight into mapped host memory (read at ngw_create)
     std::vector<void*> allocs;
-    std::vector<void*> host_allocs;       // state of a single-wavefront handle kept in GPU-addressable host memory (hostres)
+    std::vector<void*> host_allocs;       // single-wavefront handles: the host mirror of the state (GPU-addressable page-locked memory)
+    NgwMirror mir = {};                   // ... its arrays (host addresses = device addresses under unified addressing)
     uint8_t* mask_pin = nullptr; uint8_t* mask_pin_dev = nullptr;   // ngw_reset's mask: two page-locked halves the kernel reads in place
     hipEvent_t mask_ev[2] = {nullptr, nullptr};
     int mask_next = 0;
     uint8_t* act_pin = nullptr;                // ngw_step's actions: two page-locked halves feeding the asynchronous copy
     hipEvent_t act_ev[2] = {nullptr, nullptr};
     int act_next = 0;
-    int hostres = 0;
+    int hostres = 0;                         // single-wavefront handle with a host mirror (NgwMirror; NGW_HOST_STATE=0 switches it off)
     uint32_t step_seq = 0, launch_seq = 0;   // hostres: sequence number the next step launch reports (launch_seq: only while ngw_step_host issues it)
+    int32_t launch_action0 = 0; bool launch_use_action0 = false;   // one-env handles: the action of the launch ngw_step_host is issuing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing pair
     hipEvent_t order_ev = nullptr;             // ngw_stream_order
     bool ev_marked = false;                    // ngw_timing_mark recorded the closing event already
@@ -206,12 +208,12 @@ int dev_alloc(ngw_handle* h, T** p, size_t count) {
     return NGW_OK;
 }
 
-// State array of a handle: device memory, or - for handles of at most one wavefront (the gym.Env adapter: n = 1) - page-locked
-// host memory the GPU addresses directly.  Such a handle steps with NO copy call and no pack launch: the kernel reads and
-// writes the few hundred bytes it touches across PCIe and the host reads the result in place after one synchronisation.
+// One array of the host mirror of a single-wavefront handle (the gym.Env adapter: n = 1): page-locked host memory the GPU
+// addresses directly.  The state itself lives in HBM; a step issued by ngw_step_host copies the wave's rows here before it
+// signals completion, so such a handle steps with NO copy call, no pack launch and no stream synchronisation - and the
+// kernel writes across PCIe but never reads (round 3 kept the state itself in host memory: 2.9 us of PCIe reads per step).
 template <typename T>
-int state_alloc(ngw_handle* h, T** p, size_t count) {
-    if (!h->hostres) return dev_alloc(h, p, count);
+int mirror_alloc(ngw_handle* h, T** p, size_t count) {
     void* q = nullptr;
     const size_t bytes = count * sizeof(T);
     HIP_TRY(hipHostMalloc(&q, bytes ? bytes : 1, hipHostMallocMapped));
@@ -219,7 +221,7 @@ int state_alloc(ngw_handle* h, T** p, size_t count) {
     h->host_allocs.push_back(q);
     void* d = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&d, q, 0));
-    if (d != q) return fail(NGW_E_HIP, "host-resident state needs unified addressing");
+    if (d != q) return fail(NGW_E_HIP, "the host mirror needs unified addressing");
     *p = static_cast<T*>(q);
     return NGW_OK;
 }
@@ -516,13 +518,14 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     a.action_seed = action_seed;
     a.t0 = t0;
     a.seq = h->launch_seq;
+    a.action0 = h->launch_action0; a.use_action0 = h->launch_use_action0 ? 1 : 0;
     const unsigned grid = (unsigned)(h->n_pad / NGW_EPB);
     bool taken = false;
     if (mode == NGW_MODE_RESET) { if (int rc = launch_reset_fast(h, NGW_MODE_RESET, mask_dev, &taken)) return rc; }
     if (!taken && mode == NGW_MODE_STEP && h->lean && h->nostage && !h->lidar_fused) {   // big maps: no-stage lean kernel
         NgwLaunch q = h->ns_proto;
         q.b = h->b; q.mode = mode; q.n_steps = 1; q.actions = actions_dev; q.autoreset = h->autoreset; q.horizon = h->horizon; q.stamps = h->proto.stamps;
-        q.seq = h->launch_seq;
+        q.seq = h->launch_seq; q.action0 = h->launch_action0; q.use_action0 = h->launch_use_action0 ? 1 : 0;
         HIP_TRY(ngw_launch(h->dspec, &q, h->map_mode, 4 | 8 | (h->ext ? 2 : 0), grid, h->ns_lds, h->stream));
         taken = true;
     }
@@ -658,18 +661,30 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
         h->hostres = h->n_pad == NGW_EPB && !(v && atoi(v) == 0);
     }
     int rc = NGW_OK;
-    if (!rc) rc = state_alloc(h, &h->b.map, np * S2);
-    if (!rc) rc = state_alloc(h, &h->b.loc, np * 2);
-    if (!rc) rc = state_alloc(h, &h->b.facing, np);
-    if (!rc) rc = state_alloc(h, &h->b.inv, np * K);
-    if (!rc) rc = state_alloc(h, &h->b.selected, np);
-    if (!rc) rc = state_alloc(h, &h->b.step_count, np);
-    if (!rc) rc = state_alloc(h, &h->b.episode, np);
-    if (!rc) rc = state_alloc(h, &h->b.reward, np);
-    if (!rc) rc = state_alloc(h, &h->b.done, np);
-    if (!rc) rc = state_alloc(h, &h->b.info, np);
+    if (!rc) rc = dev_alloc(h, &h->b.map, np * S2);
+    if (!rc) rc = dev_alloc(h, &h->b.loc, np * 2);
+    if (!rc) rc = dev_alloc(h, &h->b.facing, np);
+    if (!rc) rc = dev_alloc(h, &h->b.inv, np * K);
+    if (!rc) rc = dev_alloc(h, &h->b.selected, np);
+    if (!rc) rc = dev_alloc(h, &h->b.step_count, np);
+    if (!rc) rc = dev_alloc(h, &h->b.episode, np);
+    if (!rc) rc = dev_alloc(h, &h->b.reward, np);
+    if (!rc) rc = dev_alloc(h, &h->b.done, np);
+    if (!rc) rc = dev_alloc(h, &h->b.info, np);
     if (!rc) rc = dev_alloc(h, &h->b.flags, 1);
-    if (!rc && h->hostres) rc = state_alloc(h, &h->b.flags_host, 16);          // [0] flags, [NGW_SEQ_WORD] sequence of the last finished step
+    if (h->hostres) {
+        NgwMirror& m = h->mir;
+        if (!rc) rc = mirror_alloc(h, &m.map, np * S2);
+        if (!rc) rc = mirror_alloc(h, &m.loc, np * 2);
+        if (!rc) rc = mirror_alloc(h, &m.facing, np);
+        if (!rc) rc = mirror_alloc(h, &m.inv, np * K);
+        if (!rc) rc = mirror_alloc(h, &m.selected, np);
+        if (!rc) rc = mirror_alloc(h, &m.step_count, np);
+        if (!rc) rc = mirror_alloc(h, &m.reward, np);
+        if (!rc) rc = mirror_alloc(h, &m.done, np);
+        if (!rc) rc = mirror_alloc(h, &m.info, np);
+        if (!rc) rc = mirror_alloc(h, &h->b.flags_host, 16);                       // [0] flags, [NGW_SEQ_WORD] sequence of the last finished step
+    }
     if (!rc) rc = dev_alloc(h, &h->actions_dev, np);
     if (!rc) rc = dev_alloc(h, &h->mask_dev, np);
     if (!rc && spec->n_passes) rc = dev_alloc(h, &h->b.perm, np * S2);   // HBM fallback for maps too big for the LDS shuffle
@@ -780,6 +795,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
                 l[5] = (uint32_t)(uint8_t)(int8_t)rewc | (rbit << 8) | (slotsel << 12) | ((cost[0] & 63u) << 14) | ((cost[1] & 63u) << 20) | ((cost[2] & 63u) << 26);
             }
         }
+        hs.mir = h->mir;
         if (hipMemcpyAsync(h->dspec, &hs, sizeof(hs), hipMemcpyDefault, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess)
             return bail(fail(NGW_E_HIP, "spec upload failed"));
@@ -964,8 +980,9 @@ int ngw_reset_host(ngw_handle* h, const uint8_t* mask_host, int8_t* map, int32_t
     HIP_TRY(hipSetDevice(h->device));
     const size_t n = (size_t)h->n, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
     if (h->hostres && !mask_host) {
-        // State in GPU-addressable host memory: ONE launch, completion polled on the word the reset kernel writes when its stores
-        // are out (the refill that re-prepares the consumed episode follows on the stream and is NOT waited for), results read in place.
+        // Single-wavefront handle: ONE launch that ends by copying the wave's rows into the host mirror; completion polled on the
+        // word the reset kernel writes when its stores are out (the refill that re-prepares the consumed episode follows on the
+        // stream and is NOT waited for), results read from the mirror.
         h->step_seq = h->step_seq + 1u ? h->step_seq + 1u : 1u;
         h->launch_seq = h->step_seq;
         const int lrc = launch(h, NGW_MODE_RESET, 1, nullptr, nullptr, 0, 0);
@@ -983,12 +1000,13 @@ int ngw_reset_host(ngw_handle* h, const uint8_t* mask_host, int8_t* map, int32_t
         }
         if (!seen) HIP_TRY(hipStreamSynchronize(h->stream));
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        if (map) memcpy(map, h->b.map, n * S2);
-        if (loc) memcpy(loc, h->b.loc, n * 8);
-        if (facing) memcpy(facing, h->b.facing, n * 4);
-        if (inv) memcpy(inv, h->b.inv, n * K * 4);
-        if (selected) memcpy(selected, h->b.selected, n);
-        if (step_count) memcpy(step_count, h->b.step_count, n * 4);
+        const NgwMirror& m = h->mir;
+        if (map) memcpy(map, m.map, n * S2);
+        if (loc) memcpy(loc, m.loc, n * 8);
+        if (facing) memcpy(facing, m.facing, n * 4);
+        if (inv) memcpy(inv, m.inv, n * K * 4);
+        if (selected) memcpy(selected, m.selected, n);
+        if (step_count) memcpy(step_count, m.step_count, n * 4);
         if (error_flags) *error_flags = *h->b.flags_host;             // sticky: ngw_error_flags reads and clears it (with the device word)
         return NGW_OK;
     }
@@ -1200,7 +1218,9 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
     size_t total = 0;
     for (const Out& o : outs) if (o.host) total += (o.bytes + 255) & ~(size_t)255;
     if (h->hostres) {
-        // State in GPU-addressable host memory: actions in, ONE launch, one synchronisation, results read in place.
+        // Single-wavefront handle: ONE launch, no copy call, no stream synchronisation.  The action of a one-env handle travels
+        // in the kernel's argument block (more envs: a page-locked array the kernel reads in place), the kernel steps the
+        // state in HBM and copies the wave's rows into the host mirror, and the results are read there.
         if (!h->zc_host) {
             h->zc_host = static_cast<uint8_t*>(ngw_host_alloc(NGW_EPB * sizeof(int32_t)));
             if (!h->zc_host) return NGW_E_HIP;
@@ -1217,8 +1237,9 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
         // follows the step on the stream).  Bounded: after ~20 ms without the word the stream is synchronised the usual way.
         h->step_seq = h->step_seq + 1u ? h->step_seq + 1u : 1u;
         h->launch_seq = h->step_seq;
-        const int lrc = launch(h, NGW_MODE_STEP, 1, reinterpret_cast<const int32_t*>(h->zc_dev), nullptr, 0, 0);
-        h->launch_seq = 0;
+        h->launch_use_action0 = n == 1; h->launch_action0 = actions_host[0];
+        const int lrc = launch(h, NGW_MODE_STEP, 1, n == 1 ? h->actions_dev : reinterpret_cast<const int32_t*>(h->zc_dev), nullptr, 0, 0);
+        h->launch_seq = 0; h->launch_use_action0 = false;
         if (lrc) return lrc;
 #ifdef NGW_HOSTTRACE
         const double t1 = now();
@@ -1240,10 +1261,12 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
 #ifdef NGW_HOSTTRACE
         const double t2 = now();
 #endif
+        const NgwMirror& m = h->mir;
+        const void* const mirrors[INFO] = {m.map, m.loc, m.facing, m.inv, m.reward, m.done, nullptr, m.selected, m.step_count};
         for (int r = 0; r < INFO; r++)
-            if (outs[r].host && r != 6) memcpy(outs[r].host, outs[r].dev, outs[r].bytes);
+            if (outs[r].host && r != 6) memcpy(outs[r].host, mirrors[r], outs[r].bytes);
         if (error_flags) *error_flags = *h->b.flags_host;             // sticky: ngw_error_flags reads and clears it (with the device word)
-        if (want_info) info_words = h->b.info;
+        if (want_info) info_words = m.info;
 #ifdef NGW_HOSTTRACE
         const double t3 = now();
         tA += t1 - t0; tB += t2 - t1; tC += t3 - t2; (void)tD;

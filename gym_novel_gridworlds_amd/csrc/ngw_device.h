@@ -30,7 +30,7 @@ struct NgwBufs {
     uint8_t* done;        /* [n_pad] */
     uint32_t* info;       /* [n_pad] packed, see NGW_INFO_* */
     uint32_t* flags;      /* [1] sticky NGW_F_* */
-    uint32_t* flags_host; /* single-wavefront handles whose state lives in GPU-addressable host memory: the same word there, or nullptr */
+    uint32_t* flags_host; /* single-wavefront handles (host mirror, NgwMirror): the same word in GPU-addressable host memory, or nullptr */
     uint16_t* perm;       /* [S*S][n_pad] shuffle scratch of the subset reset passes, or nullptr */
 };
 
@@ -56,7 +56,10 @@ struct NgwLaunch {
     uint32_t magicS;             /* ceil(2^32 / S): cell / S */
     uint32_t off_inv, off_cand, off_act;    /* LDS dword offsets */
     uint64_t* stamps;            /* diagnostics builds (-DNGW_STAMPS): [grid][16] in-kernel clock stamps, or nullptr */
-    uint32_t seq;                /* host-resident handles: written to flags_host[NGW_SEQ_WORD] when the step's stores are out (0 = do not) */
+    uint32_t seq;                /* single-wavefront handles: the step refreshes the host mirror (NgwMirror) and then writes this number to
+                                  * flags_host[NGW_SEQ_WORD] (0 = neither) */
+    int32_t action0;             /* one-env handles: the step's action travels in the argument block ... */
+    int32_t use_action0;         /* ... when this is set (`actions` still points at valid device memory) */
     /* fused rollouts: per-step output rows and per-env episode accumulators (ngw_rollout_outputs), any of them nullptr */
     int32_t* row_reward;         /* [n_steps][row_stride]: reward of step t of env e at [t * row_stride + e] */
     uint8_t* row_done;           /* [n_steps][row_stride]: 1 where the step ended an episode (done, or the horizon under autoreset) */
@@ -152,6 +155,15 @@ struct NgwExtU {
 
 /* Blob kept in HBM (one per handle). */
 #define NGW_MAX_PLACE 64            /* items placed by one reset (sum of items_quantity); reference: 6-7 */
+/* Host mirror of a single-wavefront handle (the gym.Env adapter: n = 1): the same rows in page-locked host memory the GPU
+ * addresses directly.  The state itself lives in HBM like any other handle's; a step (or explicit reset) launched by
+ * ngw_step_host / ngw_reset_host copies the wave's rows here before it signals completion, so the host reads its results
+ * in place - no copy call, no stream synchronisation - and the kernel never READS across PCIe.  All nullptr: no mirror. */
+struct NgwMirror {
+    int8_t* map; int32_t* loc; int32_t* facing; int32_t* inv; uint8_t* selected; int32_t* step_count;
+    int32_t* reward; uint8_t* done; uint32_t* info;
+};
+
 struct NgwDevSpec {
     NgwStepU u;
     /* --- the two tables below are contiguous: 256 dwords copied to LDS by every wavefront */
@@ -166,6 +178,7 @@ struct NgwDevSpec {
     NgwExtU x;
     NgwNx nx;
     NgwResetU ru;
+    NgwMirror mir;
     double pctq[NGW_MAX_PASSES][64];   /* per reset pass: pct / 100.0 for pct in [pct_lo, pct_hi) as the host's IEEE double */
 };
 
@@ -188,7 +201,7 @@ struct NgwResetFast {            // kernel arguments (by value)
     int32_t mode;                // NGW_MODE_RESET / NGW_MODE_REFILL
     int32_t S, S2, K, CW, n_place, wall_item;
     int32_t additem_item, additem_span;   // the subset pass: item written, width of its percent range
-    uint32_t seq;                // host-resident handles: written to flags_host[NGW_SEQ_WORD] when an explicit reset's stores are out (0 = do not)
+    uint32_t seq;                // single-wavefront handles: refresh the host mirror, then write this to flags_host[NGW_SEQ_WORD] (0 = neither)
     int32_t pass_wall;           // the subset pass replaces WALL cells (ReplaceItem / FireWall of the ring) instead of filling air cells
     int32_t n_inv_start;
     uint32_t inv_start_items, inv_start_qtys;   // 4 bytes each

@@ -242,7 +242,8 @@ int ngw_stream_order(ngw_handle* h, void* other_stream, int handle_waits);
 int ngw_reset(ngw_handle* h, const uint8_t* mask_host);
 /* ngw_reset + the state it produced, in ONE call (any output may be NULL): what reset() of the host API returns.  For handles of at
  * most one wavefront (the single-env gym.Env adapter) it waits for the reset kernel alone - not for the refill launch that
- * re-prepares the consumed episode behind it - by polling a word the kernel writes when its stores are out. */
+ * re-prepares the consumed episode behind it - by polling a word the kernel writes when its stores (the state in HBM and its
+ * host mirror, see ngw_obs_device_ptrs) are out. */
 int ngw_reset_host(ngw_handle* h, const uint8_t* mask_host, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv, uint8_t* selected,
                    int32_t* step_count, uint32_t* error_flags);
 /* step(action_id): pogostick_v1_env.py:230-367 / AxeMedium.step.  Host actions are validated first
@@ -316,10 +317,11 @@ void* ngw_host_alloc(uint64_t bytes);
 int ngw_host_free(void* p);
 
 /* Device pointers of the observation / output buffers (fixed for the handle's lifetime; contents are the state
- * after the last enqueued step and are updated in place by the next one).  For handles of at most one wavefront (<= 64 envs:
- * the single-env gym.Env adapter) these are GPU-ADDRESSABLE HOST memory (page-locked, mapped): valid in kernels and in
- * hipMemcpy like any device pointer, but every access crosses PCIe - batch at least 65 envs (or set NGW_HOST_STATE=0 in the
- * environment before ngw_create) when the observation is consumed on the device. */
+ * after the last enqueued step and are updated in place by the next one): HBM for every handle.  Handles of at most one
+ * wavefront (<= 64 envs: the single-env gym.Env adapter) additionally keep a MIRROR of these rows in page-locked host memory
+ * the GPU addresses directly: a step issued by ngw_step_host (an explicit reset by ngw_reset_host) ends by copying the wave's
+ * rows there and writing a sequence word the host polls, so such a call is one launch with no copy call and no stream
+ * synchronisation (NGW_HOST_STATE=0 in the environment before ngw_create: no mirror, the copy calls of the big handles). */
 int ngw_obs_device_ptrs(ngw_handle* h, void** map, void** loc, void** facing, void** inv);
 int ngw_out_device_ptrs(ngw_handle* h, void** reward, void** done, void** info);
 int ngw_sync(ngw_handle* h);
