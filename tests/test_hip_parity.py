@@ -137,7 +137,9 @@ def test_fused_rollout_matches_oracle(cfg, n, steps):
                                                              ('fencer10m', 1500, 120, 30, 5, 1),
                                                              ('pogo10', 3000, 120, 7, 16, 4), ('fire10h', 4096, 200, 50, 16, 4), ('fire10h', 2000, 150, 30, 9, 2),
                                                              ('add32', 256, 60, 12, 30, 4), ('bow20', 1000, 120, 9, 20, 2), ('fencer10m', 1500, 120, 10, 25, 8),
-                                                             ('axe10', 1000, 150, 11, 30, 4), ('pogo13', 777, 100, 6, 20, 4)])
+                                                             ('axe10', 1000, 150, 11, 30, 4), ('pogo13', 777, 100, 6, 20, 4),
+                                                             # rows of more than 64 sixteen-byte chunks: the wave copies them in several rounds
+                                                             ('add36e', 200, 50, 12, 10, 2), ('add36e', 130, 40, 9, 8, 1)])
 def test_prepared_next_episodes_are_bit_identical(cfg, n, steps, horizon, every, depth):
     """ngw_set_reset_prefetch (+ _depth: several episodes ahead per env): resets served from the shadow rows (staggered episode
     ends, instant deaths, several episode ends of one env between two refills, explicit masked resets, a stale row after
@@ -657,29 +659,53 @@ def test_autoreset_switches_prepared_episodes_on_at_the_c_abi():
     assert v.error_flags() == 0
 
 
-@pytest.mark.parametrize('cfg,n,prefetch', [('pogo10', 50, 4), ('axe10', 64, 0), ('bow20', 33, 8), ('fire10h', 40, 0)])
-def test_one_wavefront_handles_with_host_resident_state_match_oracle(cfg, n, prefetch):
-    """Handles of at most 64 envs keep their state in GPU-addressable host memory (the gym.Env adapter's fast path): steps with
-    autoreset, prepared episodes, a fused rollout, masked resets and state round trips equal the oracle."""
+@pytest.mark.parametrize('cfg,n,prefetch', [('pogo10', 50, 4), ('axe10', 64, 0), ('bow20', 33, 8), ('fire10h', 40, 0),
+                                            ('pogo10', 1, 4), ('add32', 1, 2), ('pogo13', 1, 0), ('add36e', 3, 3), ('bow20', 1, 1 << 20)])
+def test_one_wavefront_handles_with_host_mirror_match_oracle(cfg, n, prefetch):
+    """Handles of at most 64 envs (the gym.Env adapter's fast path: n = 1, whose action travels in the kernel arguments) keep a
+    mirror of their state in GPU-addressable host memory that every host step / reset refreshes: the observation a step returns
+    (read from the mirror), steps with autoreset, prepared episodes, a fused rollout, masked resets and state round trips equal
+    the oracle."""
     spec = T.build_spec(cfg)
-    A = len(spec.actions_id)
+    A, S = len(spec.actions_id), spec.map_size
     v = VecNovelGridworld(spec=spec, num_envs=n, seed=9, autoreset=True, horizon=10, reset_prefetch=prefetch)
     o = Oracle(spec.compile(), n, seed=9, autoreset=True, horizon=10)
-    v.reset(); o.reset()
+
+    def check_obs(obs, where):
+        assert (obs['map'].reshape(n, -1) == o.st.map).all() and (obs['agent_location'] == o.st.loc).all(), where
+        assert (obs['agent_facing_id'] == o.st.facing).all() and (obs['inventory_items_quantity'] == o.st.inv).all(), where
+
+    obs = v.reset(); o.reset()
+    check_obs(obs, 'reset')
     rs = np.random.RandomState(2)
     for t in range(60):
         a = rs.randint(0, A, size=n).astype(np.int32)
-        _, reward, done, info = v.step(a); o.step(a)
+        obs, reward, done, info = v.step(a); o.step(a)
         assert (reward == o.reward).all() and (done == o.done.astype(bool)).all() and (info['message_code'] == o.msg_code).all(), t
+        check_obs(obs, 'step %d' % t)
         if t == 30:
             mask = (np.arange(n) % 3 == 0).astype(np.uint8)
-            v.reset(mask); o.reset(mask)
-    assert_state_equal(v, o, cfg + ' host-resident steps')
+            obs = v.reset(mask); o.reset(mask)
+            check_obs(obs, 'masked reset')
+    assert_state_equal(v, o, cfg + ' steps')
     v.rollout(37, action_seed=4, t0=3); o.rollout(37, 4, 3)
-    assert_state_equal(v, o, cfg + ' host-resident rollout')
+    assert_state_equal(v, o, cfg + ' rollout')
+    a = rs.randint(0, A, size=n).astype(np.int32)                      # the mirror follows again after launches that do not refresh it
+    obs, _, _, _ = v.step(a); o.step(a)
+    check_obs(obs, 'step after a rollout')
     st = v.get_state()
     v.set_state(0, **{k: st[k] for k in ('map', 'loc', 'facing', 'inv', 'selected', 'step_count', 'episode')})
     assert_state_equal(v, o, cfg + ' state round trip')
+    if n == 1:                                                          # the adapter's calls
+        for t in range(25):
+            act = int(rs.randint(0, A))
+            out = v.step1(act); o.step(np.array([act], np.int32))
+            assert out[0] == int(o.reward[0]) and out[1] == bool(o.done[0]) and out[4] == int(o.msg_code[0]), t
+            mb, r, c, f, ib, sel, steps = v.last_state1()
+            assert mb == o.st.map[0].astype(np.int8).tobytes() and (r, c, f) == (int(o.st.loc[0][0]), int(o.st.loc[0][1]), int(o.st.facing[0])), t
+            assert ib == o.st.inv[0].astype(np.int32).tobytes() and sel == int(o.st.selected[0]) and steps == int(o.st.step_count[0]), t
+        v.reset1(); o.reset()
+        assert v.last_state1()[0] == o.st.map[0].astype(np.int8).tobytes()
     with pytest.raises(ValueError):
         v.step(np.full(n, A, np.int32))                                 # invalid id: raised on the host, nothing stepped
     assert v.error_flags() == 0
