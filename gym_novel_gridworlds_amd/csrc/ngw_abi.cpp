@@ -349,6 +349,8 @@ void layout_reset_fast(ngw_handle* h) {
     a.off_mcol = off; if (subset) off += NBW * NGW_EPB;
     off = (off + 3u) & ~3u;
     a.off_tile = off; off += (uint32_t)((S2 <= 512 ? (S2 * NGW_EPB + 15) / 16 * 16 : 144 * NGW_EPB) / 4);   // staging tile of the composed rows: the chunk's exact image up to 512-byte rows, else [64][128 + 16] bytes
+    // (every dword counts: at 32 x 32 + AddItem the layout is 38.8 KB and four workgroups share a CU's 160 KB - one per SIMD)
+    a.off_ctab = off; off += NGW_EPB + NGW_EPB * NGW_MAX_DEPTH / 2;
     if ((size_t)off * 4 > 160 * 1024) return;
     h->rf_lds = (size_t)off * 4;
     h->rf_nw = nw; h->rf_additem = subset ? 1 : 0;
@@ -897,6 +899,7 @@ int ngw_set_reset_prefetch(ngw_handle* h, int32_t every_n_steps) {
 
 int ngw_set_reset_prefetch_depth(ngw_handle* h, int32_t depth) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    static_assert(NGW_MAX_DEPTH == 8, "the depths accepted below");
     if (depth != 0 && depth != 1 && depth != 2 && depth != 4 && depth != 8) return fail(NGW_E_INVALID_ARG, "depth must be 0 (automatic), 1, 2, 4 or 8");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));

@@ -107,6 +107,7 @@ enum { NGW_CB_FALSE = 0, NGW_CB_FRONT_NZ = 1, NGW_CB_JUMP_BLOCKED = 2, NGW_CB_NO
  * every env (depth = dmask + 1, a power of two).  The row of episode E of env e is row (E & dmask) * stride + e of every
  * array, and it is valid iff episode[row] == E; a reset whose new episode number matches copies it instead of running the
  * placement loop.  All null when the feature is off.  Read only on the cold reset path, with scalar loads from the HBM blob. */
+#define NGW_MAX_DEPTH 8          /* prepared episodes per env, at most (ngw_set_reset_prefetch_depth) */
 #define NGW_SEQ_WORD 8           /* flags_host[8]: sequence number of the last finished step launch (the host polls it instead of a stream sync) */
 struct NgwNx {
     int8_t* map;          /* [depth][n_pad][S*S] */
@@ -212,6 +213,7 @@ struct NgwResetFast {            // kernel arguments (by value)
     uint32_t magicS2;            // ceil(2^32 / (S*S)): byte offset inside the wave's chunk -> env
     int32_t img;                 // rows up to 512 bytes: the LDS tile is the exact image of the wave's 64 rows, stored as one coalesced run
     uint32_t off_ring, off_masks, off_placed, off_tmpl, off_dom, off_mcol, off_tile;    // LDS dword offsets
+    uint32_t off_ctab;           // [64] destination rows of a pass (u32) + [64 * NGW_MAX_DEPTH] stale (env, slot) pairs of a compacting refill (u16)
     uint64_t* stamps;            // diagnostics builds (-DNGW_STAMPS), or nullptr
 };
 #ifdef __cplusplus
