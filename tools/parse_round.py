@@ -26,8 +26,10 @@ WL = {'C2': (65536, 353, 'Pogostick-v1 10x10, 65 536 envs'), 'C3': (65536, 953, 
 
 
 def first(pattern):
-    f = sorted(glob.glob(os.path.join(SRC, pattern), recursive=True))
-    return f[0] if f else None
+    """The NEWEST match: gpurun merges a call's files into the local gpurun_out/ without removing older ones, so a directory
+    may hold the CSVs of several profiling runs (rocprofv3 names them by process id)."""
+    f = sorted(glob.glob(os.path.join(SRC, pattern), recursive=True), key=os.path.getmtime)
+    return f[-1] if f else None
 
 
 def short(name):
