@@ -663,12 +663,19 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
         h->hostres = h->n_pad == NGW_EPB && !(v && atoi(v) == 0);
     }
     int rc = NGW_OK;
-    if (!rc) rc = dev_alloc(h, &h->b.map, np * S2);
-    if (!rc) rc = dev_alloc(h, &h->b.loc, np * 2);
-    if (!rc) rc = dev_alloc(h, &h->b.facing, np);
-    if (!rc) rc = dev_alloc(h, &h->b.inv, np * K);
-    if (!rc) rc = dev_alloc(h, &h->b.selected, np);
-    if (!rc) rc = dev_alloc(h, &h->b.step_count, np);
+    {   // the six arrays a step's prologue reads are ONE allocation: the step kernel names them by a base + 32-bit offsets that
+        // travel in the preloaded head of its argument block (ngw_lean.inc); map rows first (the base)
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t o_map = 0, o_inv = up(np * S2), o_loc = o_inv + up(np * K * 4), o_fac = o_loc + up(np * 8), o_sel = o_fac + up(np * 4),
+                     o_stp = o_sel + up(np), total = o_stp + up(np * 4);
+        uint8_t* slab = nullptr;
+        if (!rc) rc = dev_alloc(h, &slab, total);
+        if (!rc) {
+            h->b.map = reinterpret_cast<int8_t*>(slab + o_map); h->b.inv = reinterpret_cast<int32_t*>(slab + o_inv);
+            h->b.loc = reinterpret_cast<int32_t*>(slab + o_loc); h->b.facing = reinterpret_cast<int32_t*>(slab + o_fac);
+            h->b.selected = slab + o_sel; h->b.step_count = reinterpret_cast<int32_t*>(slab + o_stp);
+        }
+    }
     if (!rc) rc = dev_alloc(h, &h->b.episode, np);
     if (!rc) rc = dev_alloc(h, &h->b.reward, np);
     if (!rc) rc = dev_alloc(h, &h->b.done, np);
