@@ -107,7 +107,7 @@ struct ngw_handle {
     NgwResetFast rf{};                    // its arguments, laid out once (layout_reset_fast)
     int rf_nw = -1, rf_additem = 0;       // rf_nw < 0: not applicable to this spec / layout
     size_t rf_lds = 0;
-    int nostage = 0;                      // lean kernel without map staging (S*S >= 256, or NGW_NOSTAGE=<min S*S>; 0 = never)
+    int nostage = 0;                      // per-launch steps through the lean kernel without map staging (every size but 10 x 10 / 6 x 6; NGW_NOSTAGE=<min S*S>: A/B)
     NgwLaunch ns_proto{};                 // its launch prototype (small LDS layout)
     size_t ns_lds = 0;
     bool general_ok = true;               // false: the map is too big for the kernels that keep a wave's 64 maps in LDS (general kernel, fused rollouts, fused lidar)
@@ -651,9 +651,16 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     if (const char* v = getenv("NGW_HOST_DELTA")) h->host_delta = atoi(v) != 0;
     if (const char* v = getenv("NGW_ZC_BYTES")) { h->zc_bytes = (size_t)atoll(v); if (!h->zc_bytes) h->zc_bytes = 1; }
     {
-        int min_s2 = 256;                                  // 16 x 16 and larger (measured: see DESIGN.md)
-        if (const char* v = getenv("NGW_NOSTAGE")) min_s2 = atoi(v);
-        h->nostage = min_s2 > 0 && spec->map_size * spec->map_size >= min_s2;
+        // Which per-launch step kernel: the one that stages the wave's maps through LDS only where that is the faster one - maps whose
+        // 64 rows arrive in ONE round of loads (S*S <= 128) and land in LDS as they are (S*S a multiple of 4 with S*S / 4 odd: the
+        // conflict-free stride needs no padding), i.e. 10 x 10 and 6 x 6.  Every other size reads its <= 14 cells in place
+        // (tools/size_sweep.py, 65 536 envs: 11 x 11 6.6 -> 4.0 us per step, 12 x 12 5.3 -> 3.9, 13 x 13 8.2 -> 4.3, 14 x 14 4.5 -> 4.1,
+        // 15 x 15 9.4 -> 4.2; at 10 x 10 the two are within 4 % of each other, either way round depending on the batch size).
+        // NGW_NOSTAGE=<min S*S> (A/B): the round-2 rule "in place from that size on" (0 = never).
+        const int s2 = spec->map_size * spec->map_size;
+        const bool straight_one_round = (s2 & 3) == 0 && ((s2 >> 2) & 1) && s2 <= 128;
+        h->nostage = !straight_one_round;
+        if (const char* v = getenv("NGW_NOSTAGE")) { const int min_s2 = atoi(v); h->nostage = min_s2 > 0 && s2 >= min_s2; }
     }
 
     const int S = spec->map_size, S2 = S * S, K = spec->n_items;
