@@ -35,6 +35,8 @@ def main():
         stagger = os.environ.get('NGW_STAGGER') == '1'   # episode ends spread over the batch, rows prepared: the cold path in the sampled launch
         v = VecNovelGridworld(spec=spec, num_envs=n, device=0, seed=0, autoreset=True, horizon=100, reset_prefetch=(1 << 20) if stagger else 0)   # (rows prepared by reset(); no refill launch among the sampled steps)
         v.reset()
+        if os.environ.get('NGW_LIDAR') == '1':          # the fused LidarInFront epilogue sits between 'outputs begin' and 'outputs issued'
+            v.lidar_configure(num_beams=8, fused=True)
         if stagger:
             v.set_state(0, step_count=(np.arange(n) * 7919 % 100).astype(np.int32))
         grid = (n + 63) // 64
