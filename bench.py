@@ -19,6 +19,11 @@ over ranks of that span (= until the slowest rank had finished its K steps).
 The JSON line carries, besides the contract's fields,
   roofline        algorithmic bytes per env-step (2*S*S + 12*K + 45) * envs per launch / the step kernel's
                   average launch duration, measured with a HIP event pair on the kernel's own stream, vs 8 TB/s HBM peak
+                  (`frac`), and the same on the wall-clock ms_per_step the driver can check (`frac_wall`)
+  repeats         the K-step region run R = 5 more times after the contract's one: median / min / max (device and wall)
+  cold_region     the same W + K steps BEFORE the device-clock warm-up (a fresh process finds the GPU in a low power state)
+  lidar           the step with the fused LidarInFront observation (what the reference's scripts train on), per row format
+  api_mode_lidar  LidarInFront(venv).step() host loop (PCIe-inclusive)
   resets_in_timed_region   the timed launches always contain auto-reset work: when K < H the episodes are started so
                   that every env reaches the horizon in the middle of the timed region
   gather          (N > 1) the one collective of the path: per-rank pack launch + torch.distributed.gather of the packed
@@ -61,13 +66,13 @@ def algorithmic_bytes(S, K):
     return 2 * S * S + 12 * K + 45
 
 
-def design_bytes(S, K):
+def design_bytes(S, K, map_in_place):
     """What THIS design has to move per env-step: the observation buffers are the state, updated in place.
-    Staged kernel (maps under 16 x 16): the map row, the inventory row and 29 B of pose / action / counters are read, ~30 B
-    are written through (outputs, pose, the changed cell / slots).  No-stage kernel (16 x 16 and up): of the map only the
-    lines a step looks at come in - the block in front, its four neighbours, two cells ahead: three map rows = three 32-byte
-    sectors - plus the same scalars, inventory row and write-through."""
-    return (S * S if S * S < 256 else 96) + 4 * K + 29 + 30
+    Staged kernel: the map row, the inventory row and 29 B of pose / action / counters are read, ~30 B are written through
+    (outputs, pose, the changed cell / slots).  In-place kernel: of the map only the lines a step looks at come in - the block in
+    front, its four neighbours, two cells ahead: three map rows = three 32-byte sectors - plus the same scalars, inventory row
+    and write-through.  Which kernel ran is asked of the handle (ngw_step_kernel_info), not re-derived here."""
+    return (96 if map_in_place else S * S) + 4 * K + 29 + 30
 
 
 def cpu_share():
@@ -166,6 +171,7 @@ def main():
     ap.add_argument('--clock-warm-ms', type=float, default=250.0,
                     help='keep the GPU busy this long on a SCRATCH handle before anything is measured (a fresh process finds the device in a '
                          'low power state, and 5 warm-up steps are 25 us); 0 = off')
+    ap.add_argument('--repeats', type=int, default=5, help='run the K-step region this many more times after the contract region (median / spread in `repeats`)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stagger', action='store_true', help='skip the staggered-episode-ends side measurement')
     ap.add_argument('--no-side', action='store_true', help='skip every side measurement (fused rollout, API mode, C1, stagger): tuning runs')
@@ -220,6 +226,25 @@ def main():
     def episode0():
         return int(v.get_state(0, 1)['episode'][0])
 
+    cold = None
+    if args.clock_warm_ms > 0 and args.mode == 'step' and not args.no_side:
+        # the contract's shape on the device as this process found it (nothing has run on it yet): W warm-up + K timed eager steps
+        g0 = torch.Generator(device='cuda')
+        g0.manual_seed(ACTION_SEED + 31 + rank)
+        kc = min(steps, 200)
+        acts0 = torch.randint(0, A, (warmup + kc, n), dtype=torch.int32, device='cuda', generator=g0)
+        torch.cuda.synchronize()
+        v.reset()
+        if warmup:
+            v.step_device_many(acts0.data_ptr(), n, warmup)
+        v.sync(); torch.cuda.synchronize()
+        t0c = time.perf_counter()
+        v.step_device_many(acts0[warmup].data_ptr(), n, kc)
+        torch.cuda.synchronize()
+        dtc = time.perf_counter() - t0c
+        cold = {'ms_per_step': round(dtc / kc * 1e3, 6), 'value': round(n * kc / dtc, 1), 'steps': kc, 'warmup': warmup,
+                'what': 'the first W + K eager steps this process ran, before the %g ms device-clock warm-up that precedes the contract region' % args.clock_warm_ms}
+        del acts0
     if args.clock_warm_ms > 0:
         # device clocks: a scratch handle of the same shape runs fused rollouts until the time is up; nothing of it is measured and
         # the measured handle `v` is not touched (its W warm-up steps and K timed steps follow exactly as the contract says)
@@ -324,7 +349,35 @@ def main():
     dev_ms = v.timing_end()
     assert v.error_flags() == 0
     resets_timed = episode0() - ep_before
+    dt_rank = dt
     dt, dev_ms = reduce_max([dt, dev_ms])
+    per_rank = None
+    if world > 1:                                         # every rank's own K-step span, gathered for the line (self-check of the sharding)
+        t = torch.zeros(world, dtype=torch.float64, device='cuda' if args.dist_backend == 'nccl' else 'cpu')
+        t[rank] = dt_rank
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank = [round(n * steps / float(x), 1) for x in t.tolist()]
+
+    # the same K-step region R more times (device already in the state the contract region left it in: episodes keep ending
+    # every H steps): one 100-us sample says little about a 4-us step
+    repeats = None
+    if args.repeats > 0 and args.mode == 'step':
+        wall, dev = [], []
+        for _ in range(args.repeats):
+            fence()
+            v.timing_begin()
+            tr0 = time.perf_counter()
+            run_timed()
+            v.timing_mark()
+            torch.cuda.synchronize()
+            wall.append((time.perf_counter() - tr0) / steps * 1e3)
+            dev.append(v.timing_end() / steps)
+        assert v.error_flags() == 0
+        wall_m, dev_m = reduce_max(sorted(wall)), reduce_max(sorted(dev))
+        med = lambda xs: xs[len(xs) // 2]
+        repeats = {'n': args.repeats, 'ms_per_step_wall': {'median': round(med(wall_m), 6), 'min': round(wall_m[0], 6), 'max': round(wall_m[-1], 6)},
+                   'ms_per_step_device': {'median': round(med(dev_m), 6), 'min': round(dev_m[0], 6), 'max': round(dev_m[-1], 6)},
+                   'value_median': round(n * world / (med(wall_m) * 1e-3), 1)}
 
     # roofline: algorithmic bytes per launch / average launch duration (device time of the timed region / launches)
     launches = 1 if args.mode == 'rollout' else steps
@@ -344,26 +397,31 @@ def main():
         return None, None
 
     if args.mode == 'step':
-        # Which byte model prices the kernel that ran.  The staged kernel (maps under 16 x 16: C2, C4 - the configuration the
-        # metric is quoted on) reads its whole map row, as SURVEY §8(d)'s read-pack-write model assumes: `achieved` is §8(d)'s
-        # figure over the launch time.  The no-stage kernel (C3, C5) never touches most of the map, so §8(d)'s 2*S*S term does
-        # not describe it (it would "exceed" the peak): there `achieved` is priced on the bytes the design has to move
-        # (design_bytes), and §8(d)'s figure is reported beside it, labelled.
-        nostage = S * S >= 256
-        D = design_bytes(S, K)
-        model_bytes = D if nostage else B
-        achieved = model_bytes * n * steps_per_launch / (launch_ms * 1e-3) / 1e9
+        # `achieved` / `frac`: SURVEY §8(d)'s algorithmic bytes per env-step x the envs of a launch over the average launch duration -
+        # the figure every round and every workload is priced on, whichever kernel ran.  The kernel that reads the map in place (every
+        # size but 10 x 10: ngw_step_kernel_info) legitimately never touches most of the 2*S*S bytes that model charges, so for it the
+        # figure can exceed 1: it says how the step compares with a read-pack-write design at the peak, not how busy HBM is.  What
+        # HBM really carries is `traffic` (PMC counters of this kernel, profiles/) and `frac_of_peak_on_measured_traffic`; the bytes
+        # this design has to move are `design_bytes_per_env_step`, a separate, labelled figure.
+        in_place = bool(v.step_reads_map_in_place)
+        D = design_bytes(S, K, in_place)
+        achieved = B * n * steps_per_launch / (launch_ms * 1e-3) / 1e9
+        wall_ms = dt / steps * 1e3
         roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel': 'ngw_step_lean',
+                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'frac_wall': round(B * n * steps_per_launch / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    'kernel': 'ngw_step_lean<%s>' % ('map read in place' if in_place else 'map staged through LDS'),
                     'kernel_ms_avg': round(launch_ms, 6), 'launches_timed': launches,
-                    'bytes_model': 'design (no-stage kernel: three map sectors + inventory row + scalars + write-through)' if nostage
-                                   else 'SURVEY 8(d) (2*S*S + 12*K + 45)',
-                    'algorithmic_bytes_per_env_step': B, 'design_bytes_per_env_step': D, 'env_steps_per_launch': n * steps_per_launch,
+                    'bytes_model': 'SURVEY 8(d) (2*S*S + 12*K + 45)',
+                    'algorithmic_bytes_per_env_step': B, 'env_steps_per_launch': n * steps_per_launch,
+                    'design_bytes_per_env_step': D,
+                    'design_bytes_note': 'what this design has to move per env-step (state updated in place; %s): not the model `frac` is priced on'
+                                         % ('three 32-byte map sectors instead of the map row' if in_place else 'the whole map row is read'),
                     'frac_on_design_bytes': round(D * n * steps_per_launch / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    'timing': 'HIP event pair on the kernel stream around the timed launches (includes inter-launch gaps and the reset launches)'}
-        if nostage:
-            roofline['frac_on_survey_8d_bytes'] = round(B * n * steps_per_launch / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            roofline['frac_on_survey_8d_bytes_note'] = 'not a roofline fraction: the kernel does not read the 2*S*S bytes this model charges'
+                    'timing': 'frac: HIP event pair on the kernel stream around the timed launches (includes inter-launch gaps and the reset launches); '
+                              'frac_wall: the same bytes over ms_per_step (host clock around the region, closed by a device-wide synchronisation)'}
+        if in_place and achieved > HBM_PEAK_GBS:
+            roofline['frac_note'] = 'above 1 because the kernel does not read the 2*S*S bytes the 8(d) model charges; see traffic / design bytes'
         tr, src = traffic_of('step', n)
         if tr:
             roofline['traffic'], roofline['traffic_source'] = tr, src
@@ -371,7 +429,7 @@ def main():
             roofline['frac_of_peak_on_measured_traffic'] = round(tr / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     else:
         # T steps per launch keep the state on chip: HBM sees a few bytes per env-step, the kernel is bound by instruction issue
-        roofline = {'bound': 'issue', 'achieved': None, 'peak': None, 'unit': None, 'frac': None, 'traffic': None, 'kernel': 'ngw_kernel<., ROLLOUT>',
+        roofline = {'bound': 'issue', 'achieved': None, 'peak': None, 'unit': None, 'frac': None, 'traffic': None, 'kernel': 'ngw_rollout_lean',
                     'kernel_ms': round(dev_ms, 4), 'note': 'fused rollout: state stays in LDS, no HBM roofline applies (see profiles/)'}
         tr, src = traffic_of('rollout', n * steps)
         if tr:
@@ -459,6 +517,52 @@ def main():
                'what': 'VecNovelGridworld.step(): int32 actions from host memory, the Dict observation (%d B per env) + reward / done / info '
                        'back to page-locked host arrays every step (ngw_step_host: one call, one synchronisation); PCIe-inclusive' % (S * S + 12 + 4 * K)}
 
+    # The step with the fused LidarInFront observation (reference observation_wrappers.py:10-80: what tests/test.py, random_action.py
+    # and the training scripts wrap the env in): one launch per batched step, the observation rows built in the step launch's
+    # own epilogue, per row format; then the wrapper's host loop.  Own handles (the observation setup is part of a handle's layout).
+    lidar = api_lidar = None
+    if side and args.mode == 'step':
+        from gym_novel_gridworlds_amd import LidarInFront, VecNovelGridworld
+        lidar = {'what': 'fused step + LidarInFront observation, %d beams, one launch per batched step (64-step hipGraph replayed; H = %d, '
+                         'prepared episodes at the default cadence), observation rows resident in HBM' % (8, HORIZON)}
+        G, reps = 64, 16
+        la = torch.randint(0, A, (G, n), dtype=torch.int32, device='cuda', generator=g)
+        torch.cuda.synchronize()
+        for key, dt_ in (('int32', np.int32), ('int16', np.int16), ('packed_u8_i16', 'packed')):
+            lv = VecNovelGridworld(spec=spec, num_envs=n, seed=0, autoreset=True, horizon=HORIZON, device=local_rank)
+            lv.lidar_configure(num_beams=8, fused=True, dtype=dt_)
+            lv.reset()
+            lv.graph_build(la.data_ptr(), n, G)
+            lv.graph_launch(4)
+            lv.sync()
+            lv.timing_begin()
+            tl = time.perf_counter()
+            lv.graph_launch(reps)
+            l_ms = lv.timing_end()
+            l_dt = time.perf_counter() - tl
+            assert lv.error_flags() == 0
+            lidar[key] = {'value': round(n * G * reps / l_dt, 1), 'unit': 'env-steps/s', 'ms_per_step': round(l_dt / (G * reps) * 1e3, 6),
+                          'kernel_ms_avg': round(l_ms / (G * reps), 6), 'row_bytes': lv.lidar_row_bytes, 'row_len': lv.lidar_len,
+                          'obs_GBps': round(lv.lidar_row_bytes * n / (l_ms / (G * reps) * 1e-3) / 1e9, 1)}
+            lv.close()
+        del la
+        wv = VecNovelGridworld(spec=spec, num_envs=n, seed=0, autoreset=True, horizon=HORIZON, device=local_rank)
+        w = LidarInFront(wv, num_beams=8)                     # (the batched wrapper's default: int16 rows, fused)
+        w.reset()
+        rs2 = np.random.RandomState(ACTION_SEED + 1)
+        hb = rs2.randint(0, A, size=(8, n)).astype(np.int32)
+        for i in range(3):
+            w.step(hb[i % 8])
+        kl = 20
+        tw = time.perf_counter()
+        for i in range(kl):
+            w.step(hb[i % 8])
+        w_dt = time.perf_counter() - tw
+        api_lidar = {'value': round(n * kl / w_dt, 1), 'unit': 'env-steps/s', 'ms_per_step': round(w_dt / kl * 1e3, 4), 'steps': kl,
+                     'what': 'LidarInFront(VecNovelGridworld).step(): int32 actions from host memory, the %d-value int16 observation (%d B per env) + reward / done / '
+                             'info back to host arrays every step; PCIe-inclusive' % (wv.lidar_len, wv.lidar_row_bytes)}
+        wv.close()
+
     # the one collective of the path, timed on its own: pack launch per rank + gather to rank 0 + unpack launch there
     gather = None
     if world > 1 or not args.no_side:
@@ -490,10 +594,23 @@ def main():
                        'reset_prefetch': v.reset_prefetch,
                        'mode': ('one launch per batched step (%s), actions in HBM' % ('hipGraph replay' if use_graph else 'eager')) if args.mode == 'step'
                                else 'fused rollout: all steps in one launch, actions generated in-kernel',
-                       'parallelism': 'envs sharded x%d, no collective in the step path' % world},
+                       'parallelism': 'envs sharded x%d, no collective in the step path' % world,
+                       'dist': {'backend': (args.dist_backend + (' (RCCL)' if args.dist_backend == 'nccl' else '')) if world > 1 else None,
+                                'world_size_initialised': dist.get_world_size() if world > 1 else 1,
+                                'global_env_index_range_of_rank0': [0, n], 'single_device_rehearsal': bool(args.single_device)}},
             'resets_in_timed_region': resets_timed,
             'roofline': roofline,
         }
+        if per_rank:
+            line['per_rank_value'] = per_rank          # every rank's own n * K / its K-step span (the line's value uses the slowest)
+        if repeats:
+            line['repeats'] = repeats
+        if cold:
+            line['cold_region'] = cold
+        if lidar:
+            line['lidar'] = lidar
+        if api_lidar:
+            line['api_mode_lidar'] = api_lidar
         if gather:
             line['gather'] = gather
         if fused:

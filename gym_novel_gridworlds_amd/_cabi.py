@@ -23,7 +23,8 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_get_lidar', 'ngw_lidar_device_ptr', 'ngw_host_alloc', 'ngw_host_free', 'ngw_agent_view',
            'ngw_get_agent_view', 'ngw_agent_view_device_ptr', 'ngw_set_reset_prefetch', 'ngw_step_host', 'ngw_lidar_set_output', 'ngw_rollout_actions',
            'ngw_pack_layout', 'ngw_pack_obs', 'ngw_unpack_obs', 'ngw_rollout_outputs', 'ngw_episode_stats', 'ngw_host_step_layout', 'ngw_step_device_many',
-           'ngw_set_reset_prefetch_depth', 'ngw_get_reset_prefetch_depth', 'ngw_stream_order', 'ngw_host_mirror_invalidate', 'ngw_reset_host']
+           'ngw_set_reset_prefetch_depth', 'ngw_get_reset_prefetch_depth', 'ngw_stream_order', 'ngw_host_mirror_invalidate', 'ngw_reset_host',
+           'ngw_lidar_row_layout', 'ngw_step_kernel_info']
 
 _lib = None
 
@@ -118,6 +119,10 @@ def lib():
     L.ngw_lidar_fuse.argtypes = [vp, C.c_int]
     if hasattr(L, 'ngw_lidar_set_output'):
         L.ngw_lidar_set_output.argtypes = [vp, C.c_int]
+    if hasattr(L, 'ngw_step_kernel_info'):
+        L.ngw_step_kernel_info.argtypes = [vp, C.POINTER(C.c_int32)]
+    if hasattr(L, 'ngw_lidar_row_layout'):
+        L.ngw_lidar_row_layout.argtypes = [vp] + [C.POINTER(C.c_int32)] * 4
     L.ngw_get_lidar.argtypes = [vp, vp]
     L.ngw_lidar_device_ptr.argtypes = [vp, C.POINTER(vp)]
     L.ngw_agent_view.argtypes = [vp, C.c_int]

@@ -81,8 +81,9 @@ struct ngw_handle {
     NgwLidarDev* lidar_cfg = nullptr;     // device tables
     int32_t* lidar_out = nullptr;
     int lidar_len = 0, lidar_cap = 0;         // lidar_cap: row length lidar_out was allocated for
-    int lidar_bits = 32;                  // element width of the lidar observation (ngw_lidar_set_output)
-    uint32_t lidar_magic = 0, lidar_off_tab = 0, lidar_off_tile = 0, lidar_off_map = 0;
+    int lidar_bits = 16;                  // row format of the lidar observation (ngw_lidar_set_output): 32, 16 (the default) or 8 = packed
+    int lidar_world = 0;                  // the ray table is one world-frame table rotated by the facing (NgwLidarDev::woff)
+    NgwLaunch lidar_proto{};              // the stand-alone lidar launch: its own LDS layout
     int lidar_fused = 0, lidar_range = 0, lidar_beams = 0, lidar_chan = 0, lidar_ninv = 0;
     size_t lidar_lds = 0;
     NgwNx nx = {};                        // prepared next episodes (ngw_set_reset_prefetch); all null = off
@@ -96,6 +97,7 @@ struct ngw_handle {
     uint32_t slow_seen = 0, refill_seen = 0, refill_count = 0;   // reports read / refill launches issued
     bool capturing = false;
     bool adapted = false;                 // adapt_cadence changed depth or cadence: a captured graph is stale (ngw_graph_launch re-captures it)
+    bool adapt_error = false;             // growing the prepared-episode depth failed (out of memory): the depth stays, the next refill notes it once
     int prefetch_user = 0;                // the caller chose the cadence (ngw_set_reset_prefetch): ngw_set_autoreset leaves it alone
     int depth = 1, depth_user = 0;        // prepared episodes per env (power of two); depth_user: chosen through ngw_set_reset_prefetch_depth
     int32_t* row_reward = nullptr;        // fused rollouts: the caller's output rows (ngw_rollout_outputs)
@@ -111,7 +113,6 @@ struct ngw_handle {
     NgwLaunch ns_proto{};                 // its launch prototype (small LDS layout)
     size_t ns_lds = 0;
     bool general_ok = true;               // false: the map is too big for the kernels that keep a wave's 64 maps in LDS (general kernel, fused rollouts, fused lidar)
-    int lean = 1;                         // plain configurations step through ngw_step_lean (NGW_LEAN=0 in the environment: general kernel, A/B)
     int ext = 0;                          // spec uses FireWall / FenceRestriction / Crate step predicates -> EXT kernels
     int8_t* view_out = nullptr;           // AgentMap windows
     int view_size = 0;
@@ -232,8 +233,21 @@ void dev_free(ngw_handle* h, void* p) {
     (void)hipFree(p);
 }
 
-// LDS carve-up of the step kernel (dword offsets).  With the lidar epilogue fused the maps sit behind a guard (ray
-// offsets prefetched beyond a hit may leave the lane's own map) and the ray table + observation tile follow the rest.
+// Row format of the LidarInFront observation (NGW_LFMT_*): bytes per row and where its inventory tail starts.
+void lidar_format(const ngw_handle* h, NgwLaunch& p) {
+    const int nb = h->lidar_beams * h->lidar_chan, ni = h->lidar_ninv;
+    p.l_fmt = h->lidar_bits == 32 ? NGW_LFMT_I32 : (h->lidar_bits == 16 ? NGW_LFMT_I16 : NGW_LFMT_PACKED);
+    if (p.l_fmt == NGW_LFMT_I32) { p.l_invoff = 4 * nb; p.l_rb = 4 * (nb + ni); }
+    else if (p.l_fmt == NGW_LFMT_I16) { p.l_invoff = 2 * nb; p.l_rb = 2 * (nb + ni); }
+    else { p.l_invoff = (nb + 1) & ~1; p.l_rb = p.l_invoff + 2 * ni; }
+    p.l_world = h->lidar_world;
+    p.lcfg = h->lidar_cfg; p.lout = h->lidar_out; p.lidar_len = h->lidar_len;
+    p.l_beams = h->lidar_beams; p.l_range = h->lidar_range; p.l_chan = h->lidar_chan; p.l_inv = h->lidar_ninv;
+}
+
+// LDS carve-up of the kernels that keep a wave's 64 maps in LDS (dword offsets).  With the lidar epilogue fused the maps sit
+// behind a guard (ray offsets read beyond a hit may leave the lane's own map) and the item tables, the per-lane ray table (only
+// when the rays are not world-frame) and the observation tile follow the rest.
 int layout_lds(ngw_handle* h) {
     NgwLaunch& p = h->proto;
     const int S = p.S, S2 = p.S2;
@@ -243,7 +257,7 @@ int layout_lds(ngw_handle* h) {
     off = (off + 3u) & ~3u;
     p.off_inv = off; off += (uint32_t)(p.KP * NGW_EPB);
     p.off_cand = off; off += (uint32_t)(p.CW * NGW_EPB);
-    p.off_act = off; off += (uint32_t)(NGW_MAX_ACTIONS * NGW_ACT_DW + NGW_MAX_PLACE / 4);
+    p.off_act = off; off += (uint32_t)(NGW_MAX_PLACE / 4);              // the placement sequence of the reset paths
     p.perm_lds = 0; p.off_perm = off;
     if (h->spec.n_passes) {
         // Shuffle array in LDS only while the wave's LDS stays small (<= 32 KiB, 5 waves/CU).  Measured at S = 32: the
@@ -251,27 +265,28 @@ int layout_lds(ngw_handle* h) {
         const uint32_t perm_dw = (uint32_t)(S2 * 32 * 2 / 4);
         if ((size_t)(off + perm_dw) * 4 <= 32 * 1024) { p.perm_lds = 1; off += perm_dw; }
     }
-    p.lcfg = nullptr; p.lout = nullptr; p.lidar_len = 0; p.off_ltab = p.off_ltile = 0;
+    p.lcfg = nullptr; p.lout = nullptr; p.lidar_len = 0; p.off_litem = p.off_ltab = p.off_ltile = 0;
+    uint32_t tile_dw = 0;
     if (h->lidar_fused) {
+        lidar_format(h, p);
         off = (off + 3u) & ~3u;
-        p.off_ltab = off; off += 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE * 2 / 4 + 2 * NGW_MAX_ITEMS / 4;
+        p.off_litem = off; off += 2 * NGW_MAX_ITEMS / 4;
         off = (off + 3u) & ~3u;
-        p.off_ltile = off; off += (uint32_t)(NGW_EPB * h->lidar_len);
-        p.lcfg = h->lidar_cfg; p.lout = h->lidar_out; p.lidar_len = h->lidar_len;
-        p.l_beams = h->lidar_beams; p.l_range = h->lidar_range; p.l_chan = h->lidar_chan; p.l_inv = h->lidar_ninv;
-        p.l_i16 = h->lidar_bits == 16;
+        p.off_ltab = off; if (!h->lidar_world) off += 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE * 2 / 4;
+        tile_dw = (uint32_t)(NGW_EPB * p.l_rb / 4);                     // (l_rb is even: 64 rows are a whole number of 16-byte pieces)
+        p.off_ltile = off; off += tile_dw + NGW_EPB / 4;                // + one dump byte per lane (rays that report nothing store there)
     }
     // Philox word ring of the reset path (ngw_kernels.hip PHILOX_RING, 8 KB).  With the fused lidar epilogue it shares the
-    // observation tile's region (the tile is rebuilt after any reset, the ring is dead by then): 8 KB more would take the
-    // wave past 40 KB and a CU from four resident waves to three - measured as 13.6 -> 21.7 us per batched step.
-    // The ring is used when the reset has no shuffled-subset pass (those draw hundreds of words per lane: register blocks,
-    // PhiloxRegs) and when its LDS does not cost a resident wave per CU (C5: 76 KB + 8 KB would halve the occupancy).
+    // observation tile's region when that is big enough (the tile is rebuilt after any reset, the ring is dead by then): 8 KB
+    // more would take an int32-row wave past 40 KB and a CU from four resident waves to three - measured as 13.6 -> 21.7 us per
+    // batched step.  The ring is used when the reset has no shuffled-subset pass (those draw hundreds of words per lane:
+    // register blocks, PhiloxRegs) and when its LDS does not cost a resident wave per CU (C5: 76 KB + 8 KB would halve the occupancy).
     {
         const bool passes = h->spec.n_passes != 0;
         auto waves_per_cu = [](uint32_t dwords) { return (160u * 1024u) / (((dwords * 4u + 511u) / 512u) * 512u); };
         h->off_rng = 0xFFFFFFFFu;                                  // = PhiloxRegs
         if (!passes) {
-            if (h->lidar_fused && h->lidar_len >= 32) h->off_rng = p.off_ltile;
+            if (h->lidar_fused && tile_dw >= NGW_EPB * 32) h->off_rng = p.off_ltile;
             else if (waves_per_cu(off + NGW_EPB * 32) == waves_per_cu(off) || waves_per_cu(off + NGW_EPB * 32) >= 4) {
                 h->off_rng = off; off += (uint32_t)(NGW_EPB * 32);
             }
@@ -309,7 +324,7 @@ int upload_reset_u(ngw_handle* h) {
         q = h->proto;
         q.b = h->b;
         q.off_map = 0; q.off_inv = 0; q.off_cand = (uint32_t)(q.KP * NGW_EPB); q.off_act = q.off_cand + (uint32_t)(q.CW * NGW_EPB);
-        q.perm_lds = 0; q.off_perm = 0; q.lcfg = nullptr; q.lout = nullptr;
+        q.perm_lds = 0; q.off_perm = 0; q.lcfg = nullptr; q.lout = nullptr; q.off_litem = q.off_ltab = q.off_ltile = 0;
         h->ns_lds = (size_t)(q.off_act + NGW_MAX_PLACE / 4) * 4;
         HIP_TRY(hipMemcpyAsync(&h->dspec->lp_ns, &q, sizeof(q), hipMemcpyDefault, h->stream));
     }
@@ -390,45 +405,59 @@ int launch_reset_fast(ngw_handle* h, int mode, const uint8_t* mask_dev, bool* ta
     return NGW_OK;
 }
 
-void layout_reset_fast_nx(ngw_handle* h);
-
-// (Re)allocates the shadow buffers `depth` deep and publishes them to the kernels; every tag starts at 0 = nothing prepared.
-// Synchronises the stream: called when prepared episodes are switched on and - rarely - when the depth grows.
-int alloc_nx(ngw_handle* h, int depth) {
+int publish_nx(ngw_handle* h, bool on) {
+    const NgwNx on_device = on ? h->nx : NgwNx{};                                  // null pointers switch the consume path off
+    HIP_TRY(hipMemcpyAsync(&h->dspec->nx, &on_device, sizeof(NgwNx), hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    void* const old[6] = {h->nx.map, h->nx.loc, h->nx.facing, h->nx.inv, h->nx.episode, h->nx.slow};
-    uint32_t* const slow_host = h->nx.slow_host;
-    h->nx = NgwNx{};
-    for (void* q : old) if (q) dev_free(h, q);
+    h->rf.nx = h->nx;                                                              // (the dedicated new-episode kernel's copy: launch_reset_fast masks it when prepared episodes are off)
+    return NGW_OK;
+}
+
+// (Re)allocates the shadow buffers `depth` deep and publishes them to the kernels (`on`: the consume path uses them); every tag
+// starts at 0 = nothing prepared.  Order: the NEW set is allocated, then published, and only then is the old one freed.  On a
+// failed allocation (growing the depth multiplies the shadow memory - the expected way to run out) or a failed publish the handle
+// keeps the set it had: NgwDevSpec::nx on the device, the dedicated kernel's rf.nx and h->nx never name freed memory, and the
+// error goes back to the caller.  Synchronises the stream: called when prepared episodes are switched on and - rarely - when the
+// depth grows.
+int alloc_nx(ngw_handle* h, int depth, bool on) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const NgwNx old = h->nx;
+    const int old_depth = h->depth;
+    NgwNx nw = NgwNx{};
     const size_t np = (size_t)h->n_pad * (size_t)depth, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
-    int rc = dev_alloc(h, &h->nx.map, np * S2);
-    if (!rc) rc = dev_alloc(h, &h->nx.loc, np * 2);
-    if (!rc) rc = dev_alloc(h, &h->nx.facing, np);
-    if (!rc) rc = dev_alloc(h, &h->nx.inv, np * K);
-    if (!rc) rc = dev_alloc(h, &h->nx.episode, np);
-    if (!rc) rc = dev_alloc(h, &h->nx.slow, 16);
-    if (rc) { h->nx = NgwNx{}; return rc; }
-    h->nx.slow_host = slow_host;
-    if (!h->nx.slow_host) {
+    int rc = dev_alloc(h, &nw.map, np * S2);
+    if (!rc) rc = dev_alloc(h, &nw.loc, np * 2);
+    if (!rc) rc = dev_alloc(h, &nw.facing, np);
+    if (!rc) rc = dev_alloc(h, &nw.inv, np * K);
+    if (!rc) rc = dev_alloc(h, &nw.episode, np);
+    if (!rc) rc = dev_alloc(h, &nw.slow, 16);
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(NGW_E_HIP, "zero-fill of the prepared-episode buffers failed");
+    auto drop = [&](const NgwNx& x) {
+        void* const part[6] = {x.map, x.loc, x.facing, x.inv, x.episode, x.slow};
+        for (void* q : part) if (q) dev_free(h, q);
+    };
+    if (rc) { drop(nw); (void)hipGetLastError(); return rc; }      // the old set stays in force everywhere
+    nw.slow_host = old.slow_host;
+    if (!nw.slow_host) {
         void* q = nullptr;
         if (hipHostMalloc(&q, 64, hipHostMallocMapped) == hipSuccess) {           // (without it the cadence simply stays fixed)
             memset(q, 0, 64);
             h->host_allocs.push_back(q);
             void* d = nullptr;
-            if (hipHostGetDevicePointer(&d, q, 0) == hipSuccess && d == q) h->nx.slow_host = static_cast<uint32_t*>(q);
+            if (hipHostGetDevicePointer(&d, q, 0) == hipSuccess && d == q) nw.slow_host = static_cast<uint32_t*>(q);
         }
     }
-    if (h->nx.slow_host) { h->nx.slow_host[0] = 0; h->nx.slow_host[1] = 0; }
+    nw.stride = h->n_pad; nw.dmask = depth - 1;
+    h->nx = nw; h->depth = depth;
+    if (int prc = publish_nx(h, on)) {                             // the device may hold either copy of the pointers: both sets are still alive
+        h->nx = old; h->depth = old_depth;
+        (void)publish_nx(h, on && old.episode != nullptr);
+        drop(nw);
+        return prc;
+    }
+    if (nw.slow_host) { nw.slow_host[0] = 0; nw.slow_host[1] = 0; }
     h->slow_seen = 0; h->refill_seen = 0;
-    h->nx.stride = h->n_pad; h->nx.dmask = depth - 1;
-    h->depth = depth;
-    return NGW_OK;
-}
-
-int publish_nx(ngw_handle* h, bool on) {
-    const NgwNx on_device = on ? h->nx : NgwNx{};                                  // null pointers switch the consume path off
-    HIP_TRY(hipMemcpyAsync(&h->dspec->nx, &on_device, sizeof(NgwNx), hipMemcpyDefault, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    drop(old);
     return NGW_OK;
 }
 
@@ -458,9 +487,13 @@ void adapt_cadence(ngw_handle* h) {
             h->noisy = 0;
             if (h->depth < 4 && !h->depth_user) {                    // deeper first
                 const int every = h->prefetch_every;
-                if (alloc_nx(h, h->depth * 2) == NGW_OK && publish_nx(h, true) == NGW_OK) {
-                    layout_reset_fast_nx(h);
+                // (a failed allocation keeps the set the handle had - alloc_nx frees the old one only after the new one stands - and
+                //  the depth simply stops growing: the cadence is halved instead from the next noisy window on)
+                if (alloc_nx(h, h->depth * 2, true) == NGW_OK) {
                     h->since_refill = every;                        // (every row is stale now: refill at once)
+                } else {
+                    h->depth_user = 1;                              // (no further attempts: the memory is not there)
+                    h->adapt_error = true;                          // noted by the next refill (launch_refill)
                 }
             } else {
                 h->cadence = h->cadence / 2 < 2 ? 2 : h->cadence / 2;
@@ -481,11 +514,13 @@ void adapt_cadence(ngw_handle* h) {
     }
 }
 
-void layout_reset_fast_nx(ngw_handle* h) { h->rf.nx = h->nx; }
-
 int launch_refill(ngw_handle* h) {
     h->since_refill = 0;
     adapt_cadence(h);
+    if (h->adapt_error) {                                           // (not fatal: the handle keeps working at the depth it has)
+        h->adapt_error = false;
+        fail(NGW_E_HIP, "prepared episodes: not enough device memory for %d rows per env, staying at %d (the call itself succeeded)", h->depth * 2, h->depth);
+    }
     h->refill_count++;
     bool taken = false;
     if (int rc = launch_reset_fast(h, NGW_MODE_REFILL, nullptr, &taken)) return rc;
@@ -524,18 +559,18 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     const unsigned grid = (unsigned)(h->n_pad / NGW_EPB);
     bool taken = false;
     if (mode == NGW_MODE_RESET) { if (int rc = launch_reset_fast(h, NGW_MODE_RESET, mask_dev, &taken)) return rc; }
-    if (!taken && mode == NGW_MODE_STEP && h->lean && h->nostage && !h->lidar_fused) {   // big maps: no-stage lean kernel
+    if (!taken && mode == NGW_MODE_STEP && h->nostage && !h->lidar_fused) {   // maps read in place: no-stage step kernel
         NgwLaunch q = h->ns_proto;
         q.b = h->b; q.mode = mode; q.n_steps = 1; q.actions = actions_dev; q.autoreset = h->autoreset; q.horizon = h->horizon; q.stamps = h->proto.stamps;
         q.seq = h->launch_seq; q.action0 = h->launch_action0; q.use_action0 = h->launch_use_action0 ? 1 : 0;
-        HIP_TRY(ngw_launch(h->dspec, &q, h->map_mode, 4 | 8 | (h->ext ? 2 : 0), grid, h->ns_lds, h->stream));
+        HIP_TRY(ngw_launch(h->dspec, &q, h->map_mode, 8 | (h->ext ? 2 : 0), grid, h->ns_lds, h->stream));
         taken = true;
     }
     if (!taken) {
         if (!h->general_ok)
-            return fail(NGW_E_INVALID_ARG, "map_size %d: this call keeps a wavefront's 64 maps in LDS (fused rollouts, the fused lidar epilogue, "
-                                           "NGW_LEAN=0) and they need more than 160 KiB; per-launch steps and resets are available", h->proto.S);
-        HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, (h->lidar_fused ? 1 : 0) | (h->ext ? 2 : 0) | (h->lean ? 4 : 0), grid, h->lds_bytes, h->stream));
+            return fail(NGW_E_INVALID_ARG, "map_size %d: this call keeps a wavefront's 64 maps in LDS (fused rollouts, the fused lidar epilogue) "
+                                           "and they need more than 160 KiB; per-launch steps and resets are available", h->proto.S);
+        HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, (h->lidar_fused ? 1 : 0) | (h->ext ? 2 : 0), grid, h->lds_bytes, h->stream));
     }
     if (h->prefetch_every > 0 && (mode == NGW_MODE_STEP || mode == NGW_MODE_RESET || mode == NGW_MODE_ROLLOUT || mode == NGW_MODE_ROLLOUT_ACT)) {
         // Prepared next episodes: every `prefetch_every` batched steps (and right after an explicit reset) one more launch
@@ -645,7 +680,6 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     auto bail = [&](int rc) { ngw_destroy(h); return rc; };
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(NGW_E_HIP, "hipStreamCreate failed"));
     h->own_stream = true;
-    if (const char* v = getenv("NGW_LEAN")) h->lean = atoi(v) != 0;
     if (const char* v = getenv("NGW_FAST_RESET")) h->fast_reset = atoi(v);
     if (const char* v = getenv("NGW_ADAPT_PREFETCH")) h->adapt = atoi(v) != 0;
     if (const char* v = getenv("NGW_HOST_DELTA")) h->host_delta = atoi(v) != 0;
@@ -742,7 +776,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
         for (int j = 0; j < spec->n_start; j++)
             for (int q = 0; q < spec->start_qty[j]; q++) hs.place_seq[hs.n_place++] = spec->start_item[j];
         for (int a = 0; a < spec->n_actions; a++) {
-            uint32_t* d = hs.act_desc + a * NGW_ACT_DW;
+            uint32_t d[5] = {0, 0, 0, 0, 0};                       // recipe fields of a Craft action, packed (kind | arg<<8 | n_inputs<<16 | needs_table<<24; input ids; input quantities)
             const uint32_t kind = spec->act_kind[a], arg = spec->act_arg[a];
             d[0] = kind | (arg << 8);
             if (kind == NGW_ACT_CRAFT) {
@@ -833,7 +867,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     if (int rc = layout_lds(h)) {
         // Maps beyond ~46 x 46 do not fit the kernels that keep a wave's 64 maps in LDS.  The no-stage step kernel and the
         // dedicated new-episode kernel do not need them there: such a handle steps and resets, and refuses what it cannot run.
-        if (!(h->lean && h->nostage)) return bail(rc);
+        if (!h->nostage) return bail(rc);
         h->general_ok = false;
         h->lds_bytes = 0; p.perm_lds = 0; h->off_rng = 0xFFFFFFFFu;
     }
@@ -901,9 +935,8 @@ int ngw_set_reset_prefetch(ngw_handle* h, int32_t every_n_steps) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     drop_graph(h);                                   // captured launches bake the cadence in
-    if (every_n_steps > 0 && !h->nx.episode) { if (int rc = alloc_nx(h, h->depth)) return rc; }
-    if (int rc = publish_nx(h, every_n_steps > 0)) return rc;
-    layout_reset_fast_nx(h);
+    if (every_n_steps > 0 && !h->nx.episode) { if (int rc = alloc_nx(h, h->depth, true)) return rc; }
+    else if (int rc = publish_nx(h, every_n_steps > 0)) return rc;
     h->prefetch_every = every_n_steps;
     h->cadence = every_n_steps; h->quiet = 0; h->noisy = 0; h->quiet_need = 4; h->probing = false;
     h->prefetch_user = 1;
@@ -922,12 +955,16 @@ int ngw_set_reset_prefetch_depth(ngw_handle* h, int32_t depth) {
     const int want = depth ? depth : 1;
     if (want != h->depth) {
         if (h->nx.episode) {
-            if (int rc = alloc_nx(h, want)) return rc;
-            if (int rc = publish_nx(h, h->prefetch_every > 0)) return rc;
-            layout_reset_fast_nx(h);
+            if (int rc = alloc_nx(h, want, h->prefetch_every > 0)) return rc;   // (on failure the old set - and the old depth - stay in force)
             h->since_refill = h->prefetch_every;     // every row is stale: the next launch is followed by a refill
         } else h->depth = want;
     }
+    return NGW_OK;
+}
+
+int ngw_step_kernel_info(ngw_handle* h, int32_t* map_in_place) {
+    if (!h || !map_in_place) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    *map_in_place = (h->nostage && !h->lidar_fused) ? 1 : 0;     // (the rule launch() applies to NGW_MODE_STEP)
     return NGW_OK;
 }
 
@@ -1561,6 +1598,31 @@ int ngw_error_flags(ngw_handle* h, uint32_t* flags) {
     return NGW_OK;
 }
 
+namespace {
+// LDS of the stand-alone lidar launch: item tables | per-lane ray table (only when the rays are not world-frame) | observation
+// tile | guard | maps | guard | inventory rows.  After its hit a ray's remaining cells may fall outside the lane's own map: the
+// guards keep those (ignored) reads inside the allocation.
+int layout_lidar(ngw_handle* h) {
+    NgwLaunch& q = h->lidar_proto;
+    q = h->proto;
+    q.b = h->b;
+    lidar_format(h, q);
+    const uint32_t guard = (uint32_t)((h->lidar_range * (q.S + 1) + 15) / 16 * 4);        // dwords
+    uint32_t off = 0;
+    q.off_litem = off; off += 2 * NGW_MAX_ITEMS / 4;
+    off = (off + 3u) & ~3u;
+    q.off_ltab = off; if (!h->lidar_world) off += 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE * 2 / 4;
+    q.off_ltile = off; off += (uint32_t)(NGW_EPB * q.l_rb / 4) + NGW_EPB / 4;             // + one dump byte per lane
+    off = ((off + 3u) & ~3u) + guard;
+    q.off_map = off; off += (uint32_t)(NGW_EPB * q.MS / 4) + guard;
+    off = (off + 3u) & ~3u;
+    q.off_inv = off; off += (uint32_t)(q.KP * NGW_EPB);
+    if ((size_t)off * 4 > 160 * 1024) return fail(NGW_E_INVALID_ARG, "lidar observation of %d values needs %zu B of LDS (> 160 KiB)", h->lidar_len, (size_t)off * 4);
+    h->lidar_lds = (size_t)off * 4;
+    return NGW_OK;
+}
+}  // namespace
+
 int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg) {
     if (!h || !cfg) return fail(NGW_E_INVALID_ARG, "NULL argument");
     const int K = h->proto.K;
@@ -1578,57 +1640,82 @@ int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg) {
                     return fail(NGW_E_INVALID_ARG, "lidar ray offset (%d, %d) beyond max_range %d", cfg->dr[f][b][k], cfg->dc[f][b][k], cfg->max_range);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    drop_graph(h);
     const int L = cfg->num_beams * cfg->n_chan + cfg->n_inv;
-    // LDS: ray offset table (8 KiB) + item tables | observation tile [64][L] | guard | maps | guard.  After its hit a ray's
-    // remaining prefetched cells may fall outside the lane's own map: the guards keep those (ignored) reads inside the allocation.
-    const uint32_t guard = (uint32_t)((cfg->max_range * (h->proto.S + 1) + 15) / 16 * 4);        // dwords
-    uint32_t off = 0;
-    const uint32_t off_tab = off; off += 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE * 2 / 4 + 2 * NGW_MAX_ITEMS / 4;
-    off = (off + 3u) & ~3u;
-    const uint32_t off_tile = off; off += (uint32_t)(NGW_EPB * L);
-    off = ((off + 3u) & ~3u) + guard;
-    const uint32_t off_map = off; off += (uint32_t)(NGW_EPB * h->proto.MS / 4) + guard;
-    if ((size_t)off * 4 > 160 * 1024) return fail(NGW_E_INVALID_ARG, "lidar observation of %d values needs %zu B of LDS (> 160 KiB)", L, (size_t)off * 4);
     if (!h->lidar_cfg) { if (int rc = dev_alloc(h, &h->lidar_cfg, 1)) return rc; }
-    if (L > h->lidar_cap) {                              /* grow only: a smaller observation reuses the buffer */
+    if (L > h->lidar_cap) {                              /* grow only: a smaller observation reuses the buffer (int32 rows are the widest format) */
         if (h->lidar_out) dev_free(h, h->lidar_out);
         h->lidar_out = nullptr; h->lidar_cap = 0;
         if (int rc = dev_alloc(h, &h->lidar_out, (size_t)h->n_pad * L)) return rc;
         h->lidar_cap = L;
     }
+    int world = 0;
     {
         static thread_local NgwLidarDev hd;
         memset(&hd, 0, sizeof(hd));
-        const int S = h->proto.S;
+        const int S = h->proto.S, B = cfg->num_beams, R = cfg->max_range;
         for (int f = 0; f < 4; f++)
-            for (int b = 0; b < cfg->num_beams; b++)
+            for (int b = 0; b < B; b++)
                 for (int k = 0; k < NGW_LIDAR_MAX_RANGE; k++) {
-                    const int kk = k < cfg->max_range ? k : cfg->max_range - 1;      // pad: repeats the last in-range cell
+                    const int kk = k < R ? k : R - 1;                                 // pad: repeats the last in-range cell
                     hd.off[f][b][k] = (int16_t)(cfg->dr[f][b][kk] * S + cfg->dc[f][b][kk]);
                 }
+        // World-frame form (NgwLidarDev::woff): with B a multiple of 4, ray b of facing f should be world ray (u_f + b - B / 2) mod B,
+        // u_f = B / 2, 0, 3 B / 4, B / 4 for NORTH, SOUTH, WEST, EAST.  The world table is read off facing SOUTH (u = 0) and every
+        // entry of the other facings is compared with it: only an exact match switches the uniform-offset march on.
+        if (B % 4 == 0) {
+            const int uf[4] = {B / 2, 0, 3 * B / 4, B / 4};
+            world = 1;
+            for (int w = 0; w < B; w++)
+                for (int k = 0; k < NGW_LIDAR_MAX_RANGE; k++) hd.woff[w][k] = hd.off[1][(w + B / 2) % B][k];
+            for (int f = 0; f < 4 && world; f++)
+                for (int b = 0; b < B && world; b++) {
+                    const int w = ((uf[f] + b - B / 2) % B + B) % B;
+                    for (int k = 0; k < R; k++)
+                        if (cfg->dr[f][b][k] != cfg->dr[1][(w + B / 2) % B][k] || cfg->dc[f][b][k] != cfg->dc[1][(w + B / 2) % B][k]) { world = 0; break; }
+                }
+            if (const char* v = getenv("NGW_LIDAR_WORLD")) if (atoi(v) == 0) world = 0;     // A/B: the per-lane table march
+        }
+        hd.world = world;
         memcpy(hd.chan_of_item, cfg->chan_of_item, NGW_MAX_ITEMS);
         memcpy(hd.inv_item, cfg->inv_item, NGW_MAX_ITEMS);
-        hd.num_beams = cfg->num_beams; hd.max_range = cfg->max_range; hd.n_chan = cfg->n_chan; hd.n_inv = cfg->n_inv;
+        hd.num_beams = B; hd.max_range = R; hd.n_chan = cfg->n_chan; hd.n_inv = cfg->n_inv;
         HIP_TRY(hipMemcpyAsync(h->lidar_cfg, &hd, sizeof(hd), hipMemcpyDefault, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
-    h->lidar_len = L;
+    h->lidar_len = L; h->lidar_world = world;
     h->lidar_range = cfg->max_range; h->lidar_beams = cfg->num_beams; h->lidar_chan = cfg->n_chan; h->lidar_ninv = cfg->n_inv;
-    if (h->lidar_fused) { drop_graph(h); if (int rc = layout_lds(h)) { h->lidar_fused = 0; layout_lds(h); upload_reset_u(h); return rc; } }
+    if (h->lidar_fused) { if (int rc = layout_lds(h)) { h->lidar_fused = 0; layout_lds(h); upload_reset_u(h); return rc; } }
     if (int rc = upload_reset_u(h)) return rc;
-    h->lidar_magic = (uint32_t)((0x100000000ull + (uint32_t)L - 1) / (uint32_t)L);
-    h->lidar_off_tab = off_tab; h->lidar_off_tile = off_tile; h->lidar_off_map = off_map; h->lidar_lds = (size_t)off * 4;
+    h->lidar_lds = 0;
+    if (h->general_ok) { if (int rc = layout_lidar(h)) return rc; }
     return NGW_OK;
 }
 
 int ngw_lidar_set_output(ngw_handle* h, int bits) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
-    if (bits != 16 && bits != 32) return fail(NGW_E_INVALID_ARG, "lidar output width must be 16 or 32 bits");
+    if (bits != 8 && bits != 16 && bits != 32) return fail(NGW_E_INVALID_ARG, "lidar output format must be 32 (int32), 16 (int16) or 8 (packed: uint8 beams + int16 inventory)");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    drop_graph(h);                                   // captured launches bake the width in
+    drop_graph(h);                                   // captured launches bake the format in
     h->lidar_bits = bits;
-    h->proto.l_i16 = bits == 16;
+    if (h->lidar_len) {
+        if (h->lidar_fused) { if (int rc = layout_lds(h)) return rc; }
+        if (int rc = upload_reset_u(h)) return rc;
+        if (h->general_ok) { if (int rc = layout_lidar(h)) return rc; }
+    }
+    return NGW_OK;
+}
+
+int ngw_lidar_row_layout(ngw_handle* h, int32_t* row_bytes, int32_t* beam_bytes, int32_t* inv_offset, int32_t* inv_bytes) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (!h->lidar_len) return fail(NGW_E_INVALID_ARG, "ngw_lidar_row_layout before ngw_lidar_configure");
+    NgwLaunch q{};
+    lidar_format(h, q);
+    if (row_bytes) *row_bytes = q.l_rb;
+    if (beam_bytes) *beam_bytes = q.l_fmt == NGW_LFMT_I32 ? 4 : (q.l_fmt == NGW_LFMT_I16 ? 2 : 1);
+    if (inv_offset) *inv_offset = q.l_invoff;
+    if (inv_bytes) *inv_bytes = q.l_fmt == NGW_LFMT_I32 ? 4 : 2;
     return NGW_OK;
 }
 
@@ -1638,6 +1725,7 @@ int ngw_lidar_fuse(ngw_handle* h, int enable) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     drop_graph(h);                                   // captured launches bake the LDS layout in
+    if (enable && !h->general_ok) return fail(NGW_E_INVALID_ARG, "map_size %d: the fused lidar epilogue keeps a wavefront's 64 maps in LDS (> 160 KiB)", h->proto.S);
     const int before = h->lidar_fused;
     h->lidar_fused = enable ? 1 : 0;
     if (int rc = layout_lds(h)) { h->lidar_fused = before; layout_lds(h); upload_reset_u(h); return rc; }
@@ -1648,12 +1736,11 @@ int ngw_lidar_fuse(ngw_handle* h, int enable) {
 int ngw_lidar(ngw_handle* h) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     if (!h->lidar_len) return fail(NGW_E_INVALID_ARG, "ngw_lidar before ngw_lidar_configure");
+    if (!h->lidar_lds) return fail(NGW_E_INVALID_ARG, "map_size %d: the lidar observation keeps a wavefront's 64 maps in LDS (> 160 KiB)", h->proto.S);
     HIP_TRY(hipSetDevice(h->device));
-    NgwLaunch a = h->proto;
+    NgwLaunch a = h->lidar_proto;
     a.b = h->b;
-    a.l_i16 = h->lidar_bits == 16;
-    HIP_TRY(ngw_lidar_launch(h->lidar_cfg, &a, h->map_mode, h->lidar_out, h->lidar_len, h->lidar_off_map, h->lidar_off_tab,
-                             h->lidar_off_tile, (unsigned)(h->n_pad / NGW_EPB), h->lidar_lds, h->stream));
+    HIP_TRY(ngw_lidar_launch(&a, h->map_mode, (unsigned)(h->n_pad / NGW_EPB), h->lidar_lds, h->stream));
     return NGW_OK;
 }
 
@@ -1661,7 +1748,9 @@ int ngw_get_lidar(ngw_handle* h, void* out_host) {
     if (!h || !out_host) return fail(NGW_E_INVALID_ARG, "NULL argument");
     if (!h->lidar_len) return fail(NGW_E_INVALID_ARG, "ngw_get_lidar before ngw_lidar_configure");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpyAsync(out_host, h->lidar_out, (size_t)h->n * h->lidar_len * (h->lidar_bits / 8), hipMemcpyDefault, h->stream));
+    NgwLaunch q{};
+    lidar_format(h, q);
+    HIP_TRY(hipMemcpyAsync(out_host, h->lidar_out, (size_t)h->n * (size_t)q.l_rb, hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return NGW_OK;
 }

@@ -47,8 +47,11 @@ struct NgwLaunch {
     const struct NgwLidarDev* lcfg;
     int32_t* lout;               /* [n_pad][lidar_len] */
     int32_t lidar_len, l_beams, l_range, l_chan, l_inv;
-    int32_t l_i16;               /* 1: the observation is stored as int16 (values saturate at 32767), 0: int32 */
-    uint32_t off_ltab, off_ltile;
+    int32_t l_fmt;               /* row format NGW_LFMT_*: int32 / int16 (values saturate at 32767) / packed (uint8 beam entries + int16 inventory tail) */
+    int32_t l_world;             /* 1: the ray table is one world-frame table rotated by the facing (NgwLidarDev::woff): wave-uniform ray offsets */
+    int32_t l_rb, l_invoff;      /* bytes per observation row in this format; byte offset of its inventory tail */
+    uint32_t off_litem;          /* LDS dword offset of the two item tables (chan_of_item | inv_item: 12 dwords) */
+    uint32_t off_ltab, off_ltile; /* ... of the per-lane ray table (8 KiB; only when !l_world) and of the observation tile (64 rows, l_rb bytes each) */
     int32_t perm_lds;            /* AddItem shuffle array: 1 = LDS at off_perm ([S2][32] u16, two half-wave batches), 0 = HBM scratch */
     uint32_t off_perm;
     uint32_t magic;              /* ceil(2^32 / (S2/4)) (or / S2 for odd S): exact division of chunk offsets */
@@ -148,12 +151,6 @@ struct NgwExtU {
     uint32_t nest;                          /* ngw_spec.ext_flags | fire_skip_recipe << 8 (wrapper nesting of a stack) */
 };
 
-/* Per-action descriptor, NGW_ACT_DW dwords, copied to LDS (the only lane-varying LUT of the step):
- *   d0 = kind | arg<<8 | n_inputs<<16 | needs_table<<24      d1 = input item ids (4 bytes, dict order)
- *   d2 = input quantities (4 bytes)                          d3 = out_item | out_qty<<8 | cost_missing<<16 | cost_no_table<<24
- *   d4 = cost_ok | recipe_reward<<8                          (d1..d4 are zero for non-craft actions) */
-#define NGW_ACT_DW 5
-
 /* Blob kept in HBM (one per handle). */
 #define NGW_MAX_PLACE 64            /* items placed by one reset (sum of items_quantity); reference: 6-7 */
 /* Host mirror of a single-wavefront handle (the gym.Env adapter: n = 1): the same rows in page-locked host memory the GPU
@@ -167,10 +164,7 @@ struct NgwMirror {
 
 struct NgwDevSpec {
     NgwStepU u;
-    /* --- the two tables below are contiguous: 256 dwords copied to LDS by every wavefront */
-    uint32_t act_desc[NGW_MAX_ACTIONS * NGW_ACT_DW];
-    uint8_t place_seq[NGW_MAX_PLACE];   /* item id of the n-th placement of a reset (items_quantity flattened in order) */
-    /* --- */
+    uint8_t place_seq[NGW_MAX_PLACE];   /* item id of the n-th placement of a reset (items_quantity flattened in order): the reset paths copy it to LDS */
     int32_t n_place;
     uint32_t act_lean[NGW_MAX_ACTIONS * NGW_LEAN_DW];   /* lean step kernel: micro-op table, see NGW_LEAN_DW */
     NgwLaunch lp;                /* launch prototype (layout + buffer pointers): the lean kernel's cold reset path reads it from here */
@@ -186,7 +180,7 @@ struct NgwDevSpec {
 #ifdef __cplusplus
 extern "C"
 #endif
-hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int feat /* 1 = fused lidar, 2 = EXT */, unsigned grid, size_t lds_bytes,
+hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int feat /* 1 = fused lidar, 2 = EXT, 8 = no-stage step */, unsigned grid, size_t lds_bytes,
                       hipStream_t stream);
 /* Arguments of the dedicated new-episode kernel (ngw_reset.inc: explicit resets and prepared next episodes of the plain
  * configurations and of those with ONE subset pass over the air of the interior (AddItem / Crate) or the wall ring (ReplaceItem /
@@ -222,12 +216,25 @@ extern "C"
 hipError_t ngw_reset_fast_launch(const NgwDevSpec* dspec, const struct NgwResetFast* a, int nw, int subset, unsigned grid, size_t lds_bytes,
                                  hipStream_t stream);
 
+/* Row formats of the LidarInFront observation (ngw_lidar_set_output): what one env's row looks like in the device buffer. */
+enum { NGW_LFMT_I32 = 0,      /* int32 [B * NC + NI] */
+       NGW_LFMT_I16 = 1,      /* int16 [B * NC + NI], values saturate at 32767 */
+       NGW_LFMT_PACKED = 2 }; /* uint8 [B * NC] beam entries (a range is <= 64), padded to an even count, then int16 [NI] inventory (saturating) */
+
 /* Device-side lidar tables, built by ngw_lidar_configure from ngw_lidar_cfg: flat cell offsets dr * S + dc. */
 struct NgwLidarDev {
     int16_t off[4][NGW_LIDAR_MAX_BEAMS][NGW_LIDAR_MAX_RANGE];   /* [facing][beam][range-1], 8 KiB */
     uint8_t chan_of_item[NGW_MAX_ITEMS];
     uint8_t inv_item[NGW_MAX_ITEMS];
     int32_t num_beams, max_range, n_chan, n_inv;
+    /* World-frame form of the same table, valid when `world` is set: with num_beams a multiple of 4 the four facings shoot the
+     * SAME num_beams directions, only numbered from a different start (observation_wrappers.py:38-43: the angles are
+     * direction_radian[facing] - pi + b * 2 pi / B and the four direction_radian values are multiples of 2 pi / 4), so ray b of
+     * facing f is world ray (u_f + b - B / 2) mod B with u_f = B / 2, 0, 3 B / 4, B / 4 for NORTH, SOUTH, WEST, EAST.  ngw_lidar_configure
+     * checks that property on the host's table entry by entry; the offsets of a ray are then the same for every lane of a wave
+     * (scalar loads, no table in LDS).  Ranges beyond max_range repeat the last in-range cell (rows padded to a multiple of 4). */
+    int32_t woff[NGW_LIDAR_MAX_BEAMS][NGW_LIDAR_MAX_RANGE];
+    int32_t world;
 };
 
 #ifdef __cplusplus
@@ -271,7 +278,7 @@ hipError_t ngw_agent_view_launch(const int8_t* map, const int32_t* loc, uint32_t
 #ifdef __cplusplus
 extern "C"
 #endif
-hipError_t ngw_lidar_launch(const NgwLidarDev* cfg, const NgwLaunch* a, int map_mode, int32_t* out, int L, uint32_t off_map,
-                            uint32_t off_tab, uint32_t off_tile, unsigned grid, size_t lds_bytes, hipStream_t stream);
+hipError_t ngw_lidar_launch(const NgwLaunch* a /* with the stand-alone launch's own LDS offsets */, int map_mode, unsigned grid, size_t lds_bytes,
+                            hipStream_t stream);
 
 #endif

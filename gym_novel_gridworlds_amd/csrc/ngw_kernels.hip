@@ -47,11 +47,14 @@ constexpr int EPB = NGW_EPB;   // envs per block = wavefront width
 #ifdef NGW_STAMPS
 #define STAMP_DECL uint64_t st_rt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_cy[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); st_rt[i] = __builtin_amdgcn_s_memrealtime(); st_cy[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define STAMP_FLUSH(a) do { if ((a).stamps && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; i_++) { (a).stamps[(size_t)blockIdx.x * 16 + i_] = st_rt[i_]; (a).stamps[(size_t)blockIdx.x * 16 + 8 + i_] = st_cy[i_]; } } } while (0)
+#define STAMP_STRIDE 32        /* u64 per workgroup: [0, 8) chip clock, [8, 16) shader cycles of the kernel's stamps, [16, 32) shader cycles inside helpers (STAMP_SUB) */
+#define STAMP_FLUSH(a) do { if ((a).stamps && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; i_++) { (a).stamps[(size_t)blockIdx.x * STAMP_STRIDE + i_] = st_rt[i_]; (a).stamps[(size_t)blockIdx.x * STAMP_STRIDE + 8 + i_] = st_cy[i_]; } } } while (0)
+#define STAMP_SUB(a, i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F) /* lgkmcnt(0): LDS work up to here is done */; const uint64_t c_ = __builtin_amdgcn_s_memtime(); if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)blockIdx.x * STAMP_STRIDE + 16 + (i)] = c_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_FLUSH(a)
+#define STAMP_SUB(a, i)
 #endif
 
 // ---------------------------------------------------------------- Philox4x32-10 (counter-based, per env & episode)
@@ -220,6 +223,29 @@ __device__ __forceinline__ void signal_host_seq(uint32_t* flags_host, uint32_t s
         __builtin_amdgcn_s_waitcnt(0);                                             // the wave's stores have been accepted ...
         __threadfence_system();                                                    // ... and are ordered before the word below
         if (threadIdx.x == 0) *(volatile uint32_t*)(flags_host + NGW_SEQ_WORD) = seq;
+    }
+}
+
+// End of a step launch, the parts that almost never run, with every argument read from the HBM blob's copy of the launch block
+// INSIDE the uniform branches (the hot path keeps none of these pointers in registers): sticky error flags (an invalid action id, a
+// placement that cannot succeed), and - single-wavefront handles stepped by ngw_step_host only (seq != 0) - the host mirror and the
+// sequence word the host polls.
+__device__ __forceinline__ void step_signals(const NgwDevSpec* dspec, uint32_t flags, uint32_t seq) {
+    if (__any(flags != 0)) {
+        const GLOBAL_AS NgwLaunch* lp = (const GLOBAL_AS NgwLaunch*)&dspec->lp;
+        uint32_t* const fl = lp->b.flags; uint32_t* const fh = lp->b.flags_host;
+        if (flags) atomicOr(fl, flags);
+        raise_host_flags(fh, flags);
+    }
+    if (seq) {                                                                     // (uniform)
+        const GLOBAL_AS NgwLaunch* lp = (const GLOBAL_AS NgwLaunch*)&dspec->lp;
+        NgwBufs b;
+        b.map = lp->b.map; b.loc = lp->b.loc; b.facing = lp->b.facing; b.inv = lp->b.inv; b.selected = lp->b.selected; b.step_count = lp->b.step_count;
+        b.reward = lp->b.reward; b.done = lp->b.done; b.info = lp->b.info; b.flags_host = lp->b.flags_host;
+        const int S2 = lp->S2, K = lp->K;
+        const int64_t n = lp->n;
+        mirror_wave(dspec, b, S2, K, n);
+        signal_host_seq(b.flags_host, seq);
     }
 }
 
@@ -511,6 +537,33 @@ __device__ __noinline__ uint32_t new_episode(const NgwDevSpec* dspec, LDS_AS int
     return reset_lane<PhiloxRegs>(a, mp, inv, cand, place_seq, perm_lds, nullptr, env_global, env_local, episode);
 }
 
+// The same choice INLINED into its one call site in a step or rollout kernel, Philox words from register blocks (one
+// instantiation of the placement loop).  A real call costs those kernels a stack frame (scratch memory enabled for every dispatch),
+// the callee's 242 VGPRs in their own allocation and, around the call site, the ABI's save / restore of the live scalars -
+// v_writelane / v_readlane traffic in kernels whose hot path is bound by instruction issue.  The general new-episode kernel
+// (explicit resets, refills), where the placement loop IS the work, keeps the out-of-line form with the LDS word ring.
+__device__ __forceinline__ uint32_t new_episode_inline(const NgwDevSpec* dspec, LDS_AS int8_t* mp, LDS_AS int32_t* inv, LDS_AS uint32_t* cand,
+                                                       const LDS_AS uint8_t* place_seq, LDS_AS uint16_t* perm_lds, uint64_t env_global,
+                                                       int64_t env_local, uint32_t episode, bool may_consume) {
+    const GLOBAL_AS NgwResetU* rp = (const GLOBAL_AS NgwResetU*)&dspec->ru;        // both blobs requested together
+    const GLOBAL_AS NgwNx* np = (const GLOBAL_AS NgwNx*)&dspec->nx;
+    NgwResetU ru; NgwNx nx;
+    ru.perm = rp->perm; ru.map = rp->map; ru.inv = rp->inv; ru.n_pad = rp->n_pad; ru.seed = rp->seed; ru.S = rp->S;
+    ru.S2 = rp->S2; ru.K = rp->K; ru.CW = rp->CW; ru.perm_lds = rp->perm_lds; ru.magicS = rp->magicS;
+    const GLOBAL_AS uint32_t* rsw = (const GLOBAL_AS uint32_t*)&rp->wall_item;
+    const uint32_t rs0 = rsw[0], rs1 = rsw[1], rs2 = rsw[2], rs3 = rsw[3], pw0 = rsw[4], pw1 = rsw[5], pw2 = rsw[6], pw3 = rsw[7];
+    nx.map = np->map; nx.loc = np->loc; nx.facing = np->facing; nx.inv = np->inv; nx.episode = np->episode; nx.slow = np->slow;
+    if (may_consume && nx.episode) {
+        const int64_t row = (int64_t)(episode & (uint32_t)np->dmask) * np->stride + env_local;   // the slot of this episode
+        if (((const GLOBAL_AS uint32_t*)nx.episode)[row] == episode)
+            return consume_lane(nx, mp, inv, (GLOBAL_AS int8_t*)ru.map + env_local * ru.S2, (GLOBAL_AS int32_t*)ru.inv + env_local * ru.K,
+                                row, ru.S2, ru.K) | NGW_F_ROWS_STORED;
+        atomicAdd(nx.slow, 1u);                                                    // a stale row inside a step: the host shortens the refill cadence
+    }
+    const ResetArgs a = {dspec, ru.perm, ru.n_pad, ru.seed, ru.S, ru.S2, ru.K, ru.CW, ru.perm_lds, ru.magicS, rs0, rs1, rs2, rs3, pw0, pw1, pw2, pw3};
+    return reset_lane<PhiloxRegs>(a, mp, inv, cand, place_seq, perm_lds, nullptr, env_global, env_local, episode);
+}
+
 // ---------------------------------------------------------------- map staging HBM <-> LDS (coalesced 16-B pieces)
 // The wave's 64 maps are one contiguous 64*S2-byte chunk in HBM = 4*S2 pieces of 16 B; lane l owns pieces
 // l, l+64, ...  A round moves PB pieces per lane: ALL its global loads are issued before the first LDS write (and
@@ -633,90 +686,236 @@ __device__ __forceinline__ void inv_lds(u32x4 (&q)[IQ], const NgwLaunch& a, int3
     }
 }
 
-// ---------------------------------------------------------------- LidarInFront rays (shared by both kernels)
-// observation_wrappers.py:32-65 on the LDS map.  `agent` = this lane's agent cell; `toff` = flat int16 cell offsets
-// [facing][beam][range-1]; 4 beams x 4 ranges per round: 4 table reads (4 offsets each), then 16 independent cell reads
-// in flight - the march is an LDS latency chain and the beams are independent, so they share each latency period.
-// A ray cannot leave the map before it hits the wall ring, so cells prefetched beyond the hit are simply ignored
-// (the LDS layout keeps a guard on both sides of the maps for them).
-__device__ __forceinline__ void lidar_march(const int8_t* agent, int f, int B, int R, int NC, const int16_t* toff,
-                                            const uint8_t* chan_of_item, int32_t* row) {
-    // 4 beams x 12 ranges per chunk: 12 table reads (4 int16 offsets each) and then 48 independent cell reads are in flight
-    // together, so a chunk costs two LDS latencies, not 2 x 12.  The ids of 4 consecutive ranges are packed into one
-    // dword; the first non-air block (:59-64) is its lowest non-zero byte (ffs).  No per-cell range test: beyond max_range
-    // the table repeats the last in-range cell, so a padded entry can never be the FIRST non-zero one.
-    const uint8_t* ag = reinterpret_cast<const uint8_t*>(agent);
-    for (int b0 = 0; b0 < B; b0 += 4) {
-        int hit_k[4] = {0, 0, 0, 0}, hit_id[4] = {0, 0, 0, 0};
-        for (int k0 = 0; k0 < R; k0 += 12) {
-            bool open = false;
+// ---------------------------------------------------------------- LidarInFront observation (shared by every kernel that produces it)
+// observation_wrappers.py:32-78 on the LDS map.  The wave's 64 rows are built in an LDS tile that is the exact HBM image of
+// those rows in the chosen format (NGW_LFMT_*: int32, int16, or uint8 beam entries + an int16 inventory tail) and leave as one
+// contiguous run of 16-byte pieces.  Two marches:
+//   * WORLD FRAME (num_beams a multiple of 4 - the reference's default 8, and 12, 16; ngw_lidar_configure verifies it entry by
+//     entry): the four facings shoot the same rays, numbered from a different start, so the cell offsets of a ray are the same
+//     for EVERY lane of the wave - they arrive through scalar loads (no per-lane table reads, no unpacking) and a cell costs
+//     one address add and one byte read; all eight rays advance four ranges per round (32 reads in flight) and the wave stops
+//     when no lane has an open ray left;
+//   * per-lane table (any other beam count): flat int16 offsets [facing][beam][range-1] staged into LDS by the epilogue itself.
+// A ray cannot leave the map before it hits the wall ring; cells read beyond the hit are ignored (the LDS layout keeps a
+// guard on both sides of the maps for them), and beyond max_range a table repeats the last in-range cell, so a padded entry
+// can never be the FIRST non-zero one.
+#define CONST_AS __attribute__((address_space(4)))
+
+// A wave alone on its SIMD issues one instruction every ~6 cycles whatever the instruction is (stamped: 1 150 instructions of march in
+// 7 100 cycles, with either march), so what the march costs is its INSTRUCTION COUNT.  Per cell: an address add, a byte read and
+// three quarters of a pack; per ray and round, three instructions that remember the first non-zero word; the hit itself is resolved
+// once per ray, after the rounds.
+//
+// Four cells of one ray as one dword, bytes in range order: four byte reads and three shift-ors.  (The d16 forms of the byte read -
+// two reads filling the halves of one register, one shift-or per four cells - are no use on this part: with SRAM ECC on, a d16 load
+// ZEROES the other half of its destination instead of preserving it, which is why the compiler never emits them here; tried through
+// inline asm, every observation came out wrong.)
+__device__ __forceinline__ uint32_t lidar_cells4(const LDS_AS uint8_t* ag, int o0, int o1, int o2, int o3) {
+    const uint32_t c0 = ag[o0], c1 = ag[o1], c2 = ag[o2], c3 = ag[o3];
+    return (c0 | (c1 << 8)) | ((c2 | (c3 << 8)) << 16);
+}
+
+// Eight rays, one round of four ranges each (k0 + 1 .. k0 + 4): `first` keeps a ray's first non-zero word, `kc` the round it came
+// from.  Returns whether any of the eight is still open in this lane.
+__device__ __forceinline__ bool lidar_round(const uint32_t (&word)[8], int k0, uint32_t (&first)[8], int (&kc)[8]) {
 #pragma unroll
-            for (int bb = 0; bb < 4; bb++) open |= (b0 + bb < B) && !hit_k[bb];
-            if (!open) break;
-            uint2 o[4][3];
+    for (int i = 0; i < 8; i++) {
+        const bool take = first[i] == 0;
+        first[i] = take ? word[i] : first[i];
+        kc[i] = take ? k0 : kc[i];
+    }
+    const uint32_t m = min(min(min(first[0], first[1]), min(first[2], first[3])), min(min(first[4], first[5]), min(first[6], first[7])));
+    return m == 0;
+}
+
+// The hits of up to eight rays (observation_wrappers.py:59-64: the first non-air block = the lowest non-zero byte of the ray's first
+// non-zero word) go into the row: the channel look-ups go out together (a ray without a hit looks up item 0 = air = no channel), a
+// beam entry is a range <= 64, so ONE byte store at the entry's place serves every row format (the tile was zeroed, rows are
+// little-endian; `sh` = log2 of the entry size), and a ray that reports nothing stores into the lane's dump byte behind the tile -
+// no branch per ray.
+__device__ __forceinline__ void lidar_hits(const uint32_t (&first)[8], const int (&kc)[8], const int (&beam)[8], int nb, int R, int NC, int sh,
+                                           const LDS_AS uint8_t* chan_of_item, LDS_AS uint8_t* rowp, int dump) {
+    int hk[8], ch[8];
 #pragma unroll
-            for (int bb = 0; bb < 4; bb++) {
-                const int16_t* t = toff + (f * NGW_LIDAR_MAX_BEAMS + min(b0 + bb, B - 1)) * NGW_LIDAR_MAX_RANGE + k0;
+    for (int i = 0; i < 8; i++) {
+        const int q = (__ffs((int)(first[i] | 0x80000000u)) - 1) >> 3;
+        hk[i] = kc[i] + q + 1;
+        ch[i] = chan_of_item[(first[i] >> (8 * q)) & 255u];                        // (first == 0: item 0)
+    }
 #pragma unroll
-                for (int g = 0; g < 3; g++) o[bb][g] = *reinterpret_cast<const uint2*>(t + 4 * min(g, (NGW_LIDAR_MAX_RANGE - 1 - k0) / 4));
-            }
-            uint32_t w[4][3];
-#pragma unroll
-            for (int bb = 0; bb < 4; bb++)
-#pragma unroll
-                for (int g = 0; g < 3; g++) {
-                    const uint32_t i0 = ag[(int16_t)(o[bb][g].x & 0xFFFFu)], i1 = ag[(int16_t)(o[bb][g].x >> 16)];
-                    const uint32_t i2 = ag[(int16_t)(o[bb][g].y & 0xFFFFu)], i3 = ag[(int16_t)(o[bb][g].y >> 16)];
-                    w[bb][g] = i0 | (i1 << 8) | (i2 << 16) | (i3 << 24);
-                }
-#pragma unroll
-            for (int bb = 0; bb < 4; bb++)
-                if (!hit_k[bb]) {
-#pragma unroll
-                    for (int g = 2; g >= 0; g--)
-                        if (w[bb][g]) {
-                            const int q = (__ffs((int)w[bb][g]) - 1) >> 3;                   // lowest non-zero byte
-                            hit_k[bb] = k0 + 4 * g + q + 1;
-                            hit_id[bb] = (int)((w[bb][g] >> (8 * q)) & 255u);
-                        }
-                }
-        }
-#pragma unroll
-        for (int bb = 0; bb < 4; bb++)
-            if (b0 + bb < B && hit_k[bb] && hit_k[bb] <= R) {
-                const int ch = chan_of_item[hit_id[bb]];
-                if (ch) row[(b0 + bb) * NC + ch - 1] = hit_k[bb];
-            }
+    for (int i = 0; i < 8; i++) {
+        const bool hit = i < nb && ch[i] != 0 && hk[i] <= R;
+        rowp[hit ? (beam[i] * NC + ch[i] - 1) << sh : dump] = (uint8_t)hk[i];
     }
 }
 
-// The wave's 64 observation rows leave the LDS tile as one contiguous block: 16 * L pieces of int32, or - with the int16
-// output - 8 * L pieces, each packing eight consecutive values (they are >= 0; anything above 32767 saturates).
-// (pointers carry their address space: a pinned generic pointer would turn every access into a flat_* instruction)
-__device__ __forceinline__ void lidar_store(const LDS_AS uint32_t* tile, GLOBAL_AS uint32_t* out_chunk, int L, bool i16, int tid) {
-    const LDS_AS u32x4* t4 = (const LDS_AS u32x4*)tile;
-    GLOBAL_AS u32x4* g4 = (GLOBAL_AS u32x4*)out_chunk;
-    if (!i16) {
-        for (int p = tid; p < 16 * L; p += EPB) g4[p] = t4[p];
-    } else {
-        for (int p = tid; p < 8 * L; p += EPB) {
-            const u32x4 a = t4[2 * p], b = t4[2 * p + 1];
-            g4[p] = u32x4{min(a.x, 32767u) | (min(a.y, 32767u) << 16), min(a.z, 32767u) | (min(a.w, 32767u) << 16),
-                          min(b.x, 32767u) | (min(b.y, 32767u) << 16), min(b.z, 32767u) | (min(b.w, 32767u) << 16)};
+// One workgroup IS one wavefront here (NGW_EPB == 64), and a wave's LDS operations execute in program order: a lane reading what
+// another lane of the same wave wrote earlier needs no hardware wait, only the compiler must not reorder the accesses.
+// __syncthreads() would also drain every outstanding GLOBAL store of the wave (s_waitcnt vmcnt(0)): ~500 cycles after the step's
+// output stores, three times per lidar epilogue.
+__device__ __forceinline__ void wave_lds_sync() {
+    static_assert(NGW_EPB == 64, "one wavefront per workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void lidar_march_world(const LDS_AS uint8_t* ag, int f, int B, int R, int NC, int sh, const NgwLidarDev* cfg,
+                                                  const LDS_AS uint8_t* chan_of_item, LDS_AS uint8_t* rowp, int dump) {
+    const CONST_AS int32_t* woff = (const CONST_AS int32_t*)(const void*)&cfg->woff[0][0];   // uniform addresses: scalar loads
+    const int half = B >> 1, quarter = B >> 2;
+    const int uf = f == 0 ? half : (f == 1 ? 0 : (f == 2 ? half + quarter : quarter));     // NORTH pi, SOUTH 0, WEST 3 pi / 2, EAST pi / 2 (:38)
+    int rot = half - uf;                                                                  // beam b = (world ray + rot) mod B
+    rot += rot < 0 ? B : 0;
+    for (int w0 = 0; w0 < B; w0 += 8) {
+        uint32_t first[8];
+        int kc[8], beam[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { first[i] = 0; kc[i] = 0; }
+        // Scalar loads and LDS reads share one counter (lgkmcnt) and scalar loads return out of order, so a wait for offsets drains
+        // the cell reads too.  Hence the order below: the cell reads of this round go out, THEN the offsets of the next round are
+        // requested, and one wait covers both (left alone, the scheduler interleaved them: four full drains per round).
+        int o[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {                                                       // (a ray slot beyond B repeats ray B - 1)
+            const CONST_AS int32_t* t = woff + min(w0 + i, B - 1) * NGW_LIDAR_MAX_RANGE;
+            o[i][0] = t[0]; o[i][1] = t[1]; o[i][2] = t[2]; o[i][3] = t[3];
         }
+        for (int k0 = 0; k0 < R; k0 += 4) {
+            uint32_t c[8][4];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) c[i][j] = ag[o[i][j]];
+            __builtin_amdgcn_sched_barrier(0);
+            const int kn = min(k0 + 4, NGW_LIDAR_MAX_RANGE - 4);                            // (the last round re-requests in-table entries nobody uses)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const CONST_AS int32_t* t = woff + min(w0 + i, B - 1) * NGW_LIDAR_MAX_RANGE + kn;
+                o[i][0] = t[0]; o[i][1] = t[1]; o[i][2] = t[2]; o[i][3] = t[3];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t word[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) word[i] = (c[i][0] | (c[i][1] << 8)) | ((c[i][2] | (c[i][3] << 8)) << 16);
+            if (!__any(lidar_round(word, k0, first, kc))) break;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const int b = w0 + i + rot; beam[i] = b - (b >= B ? B : 0); }
+        lidar_hits(first, kc, beam, B - w0, R, NC, sh, chan_of_item, rowp, dump);
     }
 }
 
-constexpr int LIDAR_TAB16 = 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE * 2 / 16;     // ray table = 512 pieces of 16 B
+// Per-lane table form: flat int16 offsets [facing][beam][range-1] in LDS; eight rays advance four ranges per round (8 table
+// reads of 4 offsets each, then 32 cell reads in flight).
+__device__ __forceinline__ void lidar_march_table(const LDS_AS uint8_t* ag, int f, int B, int R, int NC, int sh, const LDS_AS int16_t* toff,
+                                                  const LDS_AS uint8_t* chan_of_item, LDS_AS uint8_t* rowp, int dump) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        uint32_t first[8];
+        int kc[8], beam[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { first[i] = 0; kc[i] = 0; beam[i] = b0 + i; }
+        for (int k0 = 0; k0 < R; k0 += 4) {
+            u32x2 o[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                o[i] = *reinterpret_cast<const LDS_AS u32x2*>(toff + (f * NGW_LIDAR_MAX_BEAMS + min(b0 + i, B - 1)) * NGW_LIDAR_MAX_RANGE + k0);
+            uint32_t word[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                word[i] = lidar_cells4(ag, (int16_t)(o[i].x & 0xFFFFu), (int16_t)(o[i].x >> 16), (int16_t)(o[i].y & 0xFFFFu), (int16_t)(o[i].y >> 16));
+            if (!__any(lidar_round(word, k0, first, kc))) break;
+        }
+        lidar_hits(first, kc, beam, B - b0, R, NC, sh, chan_of_item, rowp, dump);
+    }
+}
+
+constexpr int LIDAR_TAB16 = 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE * 2 / 16;     // per-lane ray table = 512 pieces of 16 B
+constexpr int LIDAR_ITEM_DW = 2 * NGW_MAX_ITEMS / 4;                                    // chan_of_item | inv_item
 static_assert(LIDAR_TAB16 == 8 * NGW_EPB, "ray table is 8 pieces per lane");
 static_assert(offsetof(NgwLidarDev, chan_of_item) == 16 * LIDAR_TAB16 && offsetof(NgwLidarDev, inv_item) == 16 * LIDAR_TAB16 + NGW_MAX_ITEMS,
               "lidar tables are contiguous");
 
-// ---------------------------------------------------------------- the kernel
-// LDS reads of the step are issued in TWO parallel levels (L0: action descriptor, block in front and its four
-// neighbours, the inventory slots whose item id is uniform; L1: the slots whose id comes out of L0) and the per-kind
-// bodies then work on registers only - the dependency chain of a step is two LDS latencies plus ALU, whatever the kind.
-template <int MAPMODE, int MODE, bool LIDAR, bool EXT>
+// The observation of the wave's 64 envs: `agent` = the lane's agent cell in its LDS map, `inv` = its inventory row in LDS; the two
+// item tables are in LDS at a.off_litem (the caller's prologue put them there).  Whole-wave call (barriers inside).
+__device__ __forceinline__ void lidar_epilogue(const NgwLaunch& a, uint32_t* lds, int tid, bool live, const int8_t* agent, int f, const int32_t* inv) {
+    const int B = a.l_beams, R = a.l_range, NC = a.l_chan, NI = a.l_inv, rb = a.l_rb, npc = 4 * rb;   // 64 rows = 4 * rb pieces of 16 B
+    const int sh = a.l_fmt == NGW_LFMT_I32 ? 2 : (a.l_fmt == NGW_LFMT_I16 ? 1 : 0);                   // beam entry = 1 << sh bytes
+    LDS_AS u32x4* t4 = (LDS_AS u32x4*)(lds + a.off_ltile);
+    wave_lds_sync();
+    STAMP_SUB(a, 0);
+    for (int base = 0; base < npc; base += EPB * 4) {                              // (a piece index beyond the tile zeroes the last piece again)
+#pragma unroll
+        for (int j = 0; j < 4; j++) t4[min(base + tid + EPB * j, npc - 1)] = u32x4{0u, 0u, 0u, 0u};
+    }
+    if (!a.l_world) {                                                              // (uniform) the per-lane ray table, staged now: 8 KiB
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.lcfg->off);
+        LDS_AS u32x4* dst = (LDS_AS u32x4*)(lds + a.off_ltab);
+        u32x4 tb[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) tb[j] = src[tid + EPB * j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) dst[tid + EPB * j] = tb[j];
+    }
+    wave_lds_sync();
+    STAMP_SUB(a, 1);
+    const LDS_AS uint8_t* chan_of_item = (const LDS_AS uint8_t*)(lds + a.off_litem);
+    LDS_AS uint8_t* rowp = (LDS_AS uint8_t*)(lds + a.off_ltile) + tid * rb;
+    if (live) {
+        const LDS_AS uint8_t* ag = (const LDS_AS uint8_t*)agent;
+        const int dump = EPB * rb - tid * rb + tid;                                // the 64 bytes behind the tile: one per lane
+        if (a.l_world) lidar_march_world(ag, f, B, R, NC, sh, a.lcfg, chan_of_item, rowp, dump);
+        else lidar_march_table(ag, f, B, R, NC, sh, (const LDS_AS int16_t*)(lds + a.off_ltab), chan_of_item, rowp, dump);
+    }
+    STAMP_SUB(a, 3);
+    if (live) {
+        // the inventory tail (:74-75): the item ids sit in LDS behind the channel table (every lane reads the same six dwords: broadcast
+        // reads), an entry is then one read of the lane's inventory row and one store; eight entries in flight
+        const LDS_AS uint32_t* idw = (const LDS_AS uint32_t*)(chan_of_item + NGW_MAX_ITEMS);
+        uint32_t iw[NGW_MAX_ITEMS / 4];
+#pragma unroll
+        for (int i = 0; i < NGW_MAX_ITEMS / 4; i++) iw[i] = idw[i];
+        const LDS_AS int32_t* iv = (const LDS_AS int32_t*)inv;
+        LDS_AS uint8_t* tail = rowp + a.l_invoff;
+        const bool wide = a.l_fmt == NGW_LFMT_I32;
+#pragma unroll
+        for (int j0 = 0; j0 < NGW_MAX_ITEMS; j0 += 8) {
+            if (j0 < NI) {                                                         // (uniform)
+                int cnt[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) cnt[i] = iv[(iw[(j0 + i) >> 2] >> (8 * ((j0 + i) & 3))) & 255u];   // (entries beyond NI name item 0)
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (j0 + i < NI) {
+                        if (wide) *(LDS_AS int32_t*)(tail + 4 * (j0 + i)) = cnt[i];
+                        else *(LDS_AS uint16_t*)(tail + 2 * (j0 + i)) = (uint16_t)min(cnt[i], 32767);
+                    }
+            }
+        }
+    }
+    wave_lds_sync();
+    STAMP_SUB(a, 4);
+    GLOBAL_AS u32x4* g4 = (GLOBAL_AS u32x4*)(reinterpret_cast<char*>(a.lout) + (uint64_t)blockIdx.x * (uint32_t)(EPB * rb));
+    for (int base = 0; base < npc; base += EPB * 4) {                              // four pieces per lane in flight
+        u32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = t4[min(base + tid + EPB * j, npc - 1)];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (base + tid + EPB * j < npc) g4[base + tid + EPB * j] = v[j];
+    }
+    STAMP_SUB(a, 5);
+}
+
+// ---------------------------------------------------------------- the general new-episode kernel
+// Explicit resets (NGW_MODE_RESET) and refills of the prepared next episodes (NGW_MODE_REFILL) of every configuration the dedicated
+// new-episode kernel (ngw_reset.inc) does not take: reset passes that read the map (Fence, ReplaceItem of an interior item), stacks
+// of passes, the v0 tree tap, 10 x 10 plain maps, and resets that refresh the fused LidarInFront observation.  The wave stages its
+// 64 maps and inventory rows into LDS, the lanes that reset run new_episode there (a prepared row if there is one, else the
+// placement loop), and the chunk goes back with coalesced 16-byte pieces.  Steps and fused rollouts live in ngw_lean.inc - up to
+// round 3 this kernel also carried a switch-dispatched step; there is ONE step implementation now (lean_body).
+template <int MAPMODE, int MODE, bool LIDAR>
 __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restrict__ dspec, const NgwLaunch a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if (MODE == NGW_MODE_DBG_NOP) return;
@@ -729,31 +928,17 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     const int S = a.S, K = a.K;
     const int npieces = 4 * a.S2;                                                  // EPB * S2 / 16
 
-    // LDS carve-up (dword offsets): maps | inventory [64][KP] | candidate masks [CW][64] | action descriptors
+    // LDS carve-up (dword offsets): maps | inventory [64][KP] | candidate masks [CW][64] | placement sequence
     uint32_t* lds_map = lds + a.off_map;
     int32_t* lds_inv = reinterpret_cast<int32_t*>(lds + a.off_inv);
-    uint32_t* lds_cand = lds + a.off_cand;
-    const uint32_t* lds_act = lds + a.off_act;
-    const NgwStepU U = dspec->u;                                                   // uniform: ONE scalar load, kept in SGPRs
     int8_t* mp = reinterpret_cast<int8_t*>(lds_map) + tid * a.MS;                 // this lane's map
     int32_t* inv = lds_inv + tid * a.KP;                                           // this lane's inventory row
-    uint32_t* cand = lds_cand + tid;
+    uint32_t* cand = lds + a.off_cand + tid;
 
-    // ---- issue EVERY global load of the prologue before touching LDS: action table, first map round, scalars, inventory
-    constexpr int NACT = NGW_MAX_ACTIONS * NGW_ACT_DW + NGW_MAX_PLACE / 4;       // action descriptors + placement sequence
-    static_assert(NACT <= 4 * EPB, "the LUT block is loaded with 4 dwords per lane");
-    static_assert(offsetof(NgwDevSpec, place_seq) == offsetof(NgwDevSpec, act_desc) + NGW_MAX_ACTIONS * NGW_ACT_DW * 4, "LUT block is contiguous");
-    uint32_t sv[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) sv[j] = dspec->act_desc[min(tid + EPB * j, NACT - 1)];
-    u32x4 ltb[LIDAR ? 8 : 1];                                                       // fused lidar: ray table + item tables
+    // ---- issue EVERY global load of the prologue before touching LDS: placement sequence, first map round, scalars, inventory
+    const uint32_t psv = reinterpret_cast<const uint32_t*>(dspec->place_seq)[min(tid, NGW_MAX_PLACE / 4 - 1)];
     uint32_t lit = 0;
-    if (LIDAR) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(a.lcfg->off);
-#pragma unroll
-        for (int j = 0; j < 8; j++) ltb[j] = src[tid + EPB * j];
-        if (tid < 2 * NGW_MAX_ITEMS / 4) lit = reinterpret_cast<const uint32_t*>(a.lcfg->chan_of_item)[tid];
-    }
+    if (LIDAR && tid < LIDAR_ITEM_DW) lit = reinterpret_cast<const uint32_t*>(a.lcfg->chan_of_item)[tid];
     int r = 1, c = 1, f = 0, sel = 0, steps = 0, action = 0;
     uint32_t episode = 0, nx_old = 0;
     if (MODE == NGW_MODE_REFILL) {
@@ -780,9 +965,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
             steps = a.b.step_count[e];
             episode = a.b.episode[e];
         }
-        if (MODE == NGW_MODE_STEP || MODE == NGW_MODE_ROLLOUT_ACT) action = a.actions[e];
-        if (MODE == NGW_MODE_STEP && a.use_action0) action = a.action0;            // (one-env handles: the action came with the arguments)
-        else if (MODE == NGW_MODE_RESET) action = a.reset_mask ? (int)a.reset_mask[e] : 1;
+        if (MODE == NGW_MODE_RESET) action = a.reset_mask ? (int)a.reset_mask[e] : 1;
     }
     u32x4 iq[IQ];
     {
@@ -792,379 +975,68 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     }
     STAMP(1);
     // ---- land them in LDS
-    {
-        uint32_t* dst = lds + a.off_act;
-#pragma unroll
-        for (int j = 0; j < 4; j++) { const int i = tid + EPB * j; if (i < NACT) dst[i] = sv[j]; }
-    }
+    if (tid < NGW_MAX_PLACE / 4) lds[a.off_act + tid] = psv;
     pieces_lds<true, MAPMODE>(buf, a, lds_map, 0, npieces, tid);
     for (int base = EPB * PB; base < npieces; base += EPB * PB) {                  // big maps: further rounds
         pieces_load(buf, gin, base, npieces, tid);
         pieces_lds<true, MAPMODE>(buf, a, lds_map, base, npieces, tid);
     }
     inv_lds<true>(iq, a, lds_inv, tid);
-    if (LIDAR) {
-        u32x4* dst = reinterpret_cast<u32x4*>(lds + a.off_ltab);
-#pragma unroll
-        for (int j = 0; j < 8; j++) dst[tid + EPB * j] = ltb[j];
-        if (tid < 2 * NGW_MAX_ITEMS / 4) lds[a.off_ltab + 4 * LIDAR_TAB16 + tid] = lit;
-    }
+    if (LIDAR && tid < LIDAR_ITEM_DW) lds[a.off_litem + tid] = lit;
     __syncthreads();
     STAMP(2);
 
     uint32_t flags = 0;
-    int reward = 0, ended = 0;
-    uint32_t info = 0;
-    uint32_t aw0 = 0, aw1 = 0, aw2 = 0, aw3 = 0;                                   // rollout: 4 actions per Philox block
-    int act_next = action;                                                         // rollout with the caller's actions: one step ahead
-
-    // ---- everything the step loop needs, fetched once and pinned in registers
-    // per-lane output addresses (VGPR pairs; 1 wave per SIMD leaves plenty)
-    g_u32x4* gmap = (g_u32x4*)(reinterpret_cast<u32x4*>(a.b.map + env0 * a.S2) + tid);     // coalesced chunk (reset only)
+    g_u32x4* gmap = (g_u32x4*)(reinterpret_cast<u32x4*>(a.b.map + env0 * a.S2) + tid);     // the wave's coalesced chunk
     g_u32x4* ginv = (g_u32x4*)(reinterpret_cast<u32x4*>(a.b.inv + env0 * K) + tid);
-    GLOBAL_AS int8_t* gm = (GLOBAL_AS int8_t*)(a.b.map + e * a.S2);                      // this env's map / inventory row
-    g_i32* gi = (g_i32*)(a.b.inv + e * K);
-    g_int2* gloc = (g_int2*)(reinterpret_cast<int2*>(a.b.loc) + e);
-    g_i32* gfac = (g_i32*)(a.b.facing + e);
-    g_i32* grew = (g_i32*)(a.b.reward + e);
-    g_u8* gdone = (g_u8*)(a.b.done + e);
-    g_u32* ginfo = (g_u32*)(a.b.info + e);
-    PIN_V(gmap); PIN_V(ginv); PIN_V(gm); PIN_V(gi); PIN_V(gloc); PIN_V(gfac); PIN_V(grew); PIN_V(gdone); PIN_V(ginfo);
-    // int16 output: the same buffer holds half as many bytes per row (chunk start = env0 * L * 2 bytes)
-    GLOBAL_AS uint32_t* glid = LIDAR ? (GLOBAL_AS uint32_t*)(reinterpret_cast<uint32_t*>(a.lout) + ((env0 * a.lidar_len) >> (a.l_i16 ? 1 : 0))) : nullptr;
-    int lB = 0, lR = 0, lNC = 0, lNI = 0;
-    if (LIDAR) {
-        lB = a.l_beams; lR = a.l_range; lNC = a.l_chan; lNI = a.l_inv;
-        PIN_V(glid); PIN_S(lB); PIN_S(lR); PIN_S(lNC); PIN_S(lNI);
-    }
-    constexpr int mode = MODE;
-    int n_steps = (MODE == NGW_MODE_ROLLOUT || MODE == NGW_MODE_ROLLOUT_ACT) ? a.n_steps : 1, autoreset = a.autoreset, horizon = a.horizon;
-    PIN_S(n_steps); PIN_S(autoreset); PIN_S(horizon);
     const uint64_t env_global = (uint64_t)(a.env_base + e);
-    uint32_t key0 = (uint32_t)a.action_seed, key1 = (uint32_t)(a.action_seed >> 32) ^ 0xA511E9B3u;
-    uint64_t tt = (uint64_t)a.t0;
-    PIN_S(key0); PIN_S(key1);
-    // uniform step parameters, unpacked into scalars
-    uint32_t brk_mask = U.brk_mask, ent_mask = U.ent_mask, rew_mask = U.rew_mask, brk2_mask = U.brk2_mask;
-    int axe_required = U.axe_required, cost_chop = U.cost_chop, cost_jump = U.cost_jump, chop_reward = U.chop_reward;
-    int n_actions = U.n_actions, reward_step = U.reward_step, reward_done = U.reward_done;
-    int break_reward = U.break_reward;
-    int cost_forward = U.cost_forward, cost_turn = U.cost_turn, cost_break = U.cost_break, cost_place = U.cost_place;
-    int cost_extract = U.cost_extract, cost_select = U.cost_select, table_item = U.table_item, goal_item = U.goal_item;
-    int place_item = U.place_item, place_near = U.place_near, n_entities = U.n_entities, ext_src = U.ext_src;
-    int ext_near = U.ext_near, ext_out = U.ext_out, ext_qty = U.ext_qty, ext_consume = U.ext_consume;
-    int ext_cost_ok = U.ext_cost_ok, axe_item = U.axe_item, axe_cost = U.axe_cost, axe_qty = U.axe_qty;
-    int place_reward = U.place_reward, ext_reward = U.ext_reward, axe_reward = U.axe_reward;
-    PIN_S(brk_mask); PIN_S(ent_mask); PIN_S(rew_mask); PIN_S(brk2_mask); PIN_S(axe_required); PIN_S(cost_chop); PIN_S(cost_jump); PIN_S(chop_reward); PIN_S(n_actions); PIN_S(reward_step); PIN_S(reward_done);
-    PIN_S(break_reward); PIN_S(cost_forward); PIN_S(cost_turn); PIN_S(cost_break); PIN_S(cost_place);
-    PIN_S(cost_extract); PIN_S(cost_select); PIN_S(table_item); PIN_S(goal_item); PIN_S(place_item); PIN_S(place_near);
-    PIN_S(n_entities); PIN_S(ext_src); PIN_S(ext_near); PIN_S(ext_out); PIN_S(ext_qty); PIN_S(ext_consume);
-    PIN_S(ext_cost_ok); PIN_S(axe_item); PIN_S(axe_cost); PIN_S(axe_qty); PIN_S(place_reward); PIN_S(ext_reward); PIN_S(axe_reward);
-    // step-time novelty predicates (FireWall / FenceRestriction / Crate): only the EXT instantiation carries them
-    int fire_item = 0, fire_reward = 0, fence_item = 0, fence_mode = 0, crate_item = 0;
-    uint32_t crate_a0 = 0, crate_a1 = 0, crate_a2 = 0, nest = 0;
-    if (EXT) {
-        const NgwExtU& X = dspec->x;
-        fire_item = X.fire_item; fire_reward = X.fire_reward; fence_item = X.fence_item; fence_mode = X.fence_mode;
-        crate_item = X.crate_item; crate_a0 = X.crate_add[0]; crate_a1 = X.crate_add[1]; crate_a2 = X.crate_add[2]; nest = X.nest;
-        PIN_S(nest); PIN_S(fire_item); PIN_S(fire_reward); PIN_S(fence_item); PIN_S(fence_mode); PIN_S(crate_item);
-        PIN_S(crate_a0); PIN_S(crate_a1); PIN_S(crate_a2);
-    }
-
-    // fused rollouts: per-step rows and episode accumulators for whoever consumes the rollout (a learner, an evaluator)
-    const bool rolling = MODE == NGW_MODE_ROLLOUT || MODE == NGW_MODE_ROLLOUT_ACT;
-    int acc_ret = 0, acc_len = 0, acc_sum = 0, acc_eps = 0;
-    if (rolling && a.acc && live) { acc_ret = a.acc[e]; acc_len = a.acc[a.n_pad + e]; acc_sum = a.acc[2 * a.n_pad + e]; acc_eps = a.acc[3 * a.n_pad + e]; }
     if (MODE == NGW_MODE_REFILL && blockIdx.x == 0 && tid == 0) {                  // what the host reads (without a sync) before the next refill
         uint32_t* const sh = dspec->nx.slow_host;                                 // (one report per refill: the launch of slot 0 makes it)
         if (sh && a.autoreset == 0) { sh[0] = dspec->nx.slow[0]; sh[1] = atomicAdd(dspec->nx.slow + 1, 1u) + 1u; }
     }
     STAMP(3);
-    for (int t = 0; t < n_steps; t++, tt++) {
-        bool do_reset = false;
-        if (live && mode != NGW_MODE_DBG_COPY) {
-            if (mode == NGW_MODE_RESET || mode == NGW_MODE_REFILL) {
-                do_reset = action != 0;
-            } else {
-                if (mode == NGW_MODE_ROLLOUT) {
-                    // action(t, env) = (w * A) >> 32 with w = word (t & 3) of philox(key = action_seed ^ tag; ctr = (t >> 2, env))
-                    if (t == 0 || (tt & 3) == 0) {
-                        const uint64_t tb = tt >> 2;
-                        philox_block((uint32_t)tb, (uint32_t)(tb >> 32), (uint32_t)env_global, (uint32_t)(env_global >> 32),
-                                     key0, key1, aw0, aw1, aw2, aw3);
-                    }
-                    const uint32_t q = (uint32_t)tt & 3u;
-                    const uint32_t w = q == 0 ? aw0 : (q == 1 ? aw1 : (q == 2 ? aw2 : aw3));
-                    action = (int)__umulhi(w, (uint32_t)n_actions);
-                }
-                if (mode == NGW_MODE_ROLLOUT_ACT) {
-                    // the caller's action rows: this step's action was requested one step ago (or in the prologue), the next
-                    // step's load is issued now and lands while this step runs
-                    action = act_next;
-                    if (t + 1 < n_steps) act_next = a.actions[(int64_t)(t + 1) * a.t0 + e];
-                }
-                if (action < 0 || action >= n_actions) {                         // reference: ValueError before any change (:236)
-                    flags |= NGW_F_INVALID_ACTION;
-                    reward = 0; ended = 0; info = 0;
-                } else {
-                    // ---------------- L0: independent LDS reads
-                    const uint32_t* ad = lds_act + action * NGW_ACT_DW;
-                    const uint32_t d0 = ad[0], d1 = ad[1], d2 = ad[2], d3 = ad[3], d4 = ad[4];
-                    const int dr = (f == 0) ? -1 : (f == 1 ? 1 : 0), dc = (f == 2) ? -1 : (f == 3 ? 1 : 0);
-                    const int fr = r + dr, fc = c + dc, fcell = fr * S + fc;
-                    const int front = mp[fcell];                                   // block in front (:369-389)
-                    // 4-neighbourhood of the front cell, only in-bounds cells count (is_block_in_front_next_to :391-411)
-                    const bool okN = fr > 0, okS = fr < S - 1, okW = fc > 0, okE = fc < S - 1;
-                    int nbN = mp[okN ? fcell - S : fcell], nbS = mp[okS ? fcell + S : fcell];
-                    int nbW = mp[okW ? fcell - 1 : fcell], nbE = mp[okE ? fcell + 1 : fcell];
-                                        const int fr2 = fr + dr, fc2 = fc + dc;                        // two cells ahead (Jump)
-                    const bool ok2 = fr2 >= 0 && fr2 <= S - 1 && fc2 >= 0 && fc2 <= S - 1;
-                    int front2 = mp[ok2 ? fr2 * S + fc2 : fcell];
-                    int inv_place = inv[place_item], inv_ext = inv[ext_out], inv_axe = inv[axe_item];
-                    // (LLVM sinks a load into the only branch that uses it, which would put one LDS latency back into
-                    //  every divergent case; the empty asm makes each value "used" here, so the reads stay together)
-                    { int p0 = (int)d0, p1 = (int)d1, p2 = (int)d2, p3 = (int)d3, p4 = (int)d4;
-                      PIN_V(p0); PIN_V(p1); PIN_V(p2); PIN_V(p3); PIN_V(p4); }
-                    // ---------------- L1: reads whose address came out of L0
-                    const int kind = d0 & 255, aarg = (d0 >> 8) & 255, nin = (d0 >> 16) & 255;
-                    const int in0 = d1 & 255, in1 = (d1 >> 8) & 255, in2 = (d1 >> 16) & 255, in3 = d1 >> 24;
-                    const int out_item = d3 & 255;
-                    int inv_front = inv[front];
-                    int inv_arg = inv[min(aarg, K - 1)];
-                    int iv0 = inv[in0], iv1 = inv[in1], iv2 = inv[in2], iv3 = inv[in3], inv_out = inv[out_item];
-                    PIN_V(inv_front); PIN_V(inv_arg); PIN_V(iv0); PIN_V(iv1); PIN_V(iv2);
-                    PIN_V(iv3); PIN_V(inv_out); PIN_V(front2); PIN_V(nbN); PIN_V(nbS);
-                    PIN_V(nbW); PIN_V(nbE); PIN_V(inv_place); PIN_V(inv_ext); PIN_V(inv_axe);
-                    // ---------------- register-only bodies
-                    int rew = reward_step, result = 1, cost = 0, msg = NGW_MSG_NONE, arg = 0;   // :239-242
-                    bool fence_twice = false;
-                    switch (kind) {
-                    case NGW_ACT_FORWARD:                                          // :244-257
-                        if (front == 0) { r = fr; c = fc; } else { result = 0; msg = NGW_MSG_BLOCK_IN_PATH; }
-                        cost = cost_forward;
-                        break;
-                    case NGW_ACT_LEFT:                                             // :258-268  N->W S->E W->S E->N
-                        f = (0x0132 >> (f * 4)) & 3; cost = cost_turn;
-                        break;
-                    case NGW_ACT_RIGHT:                                            // :269-279  N->E S->W W->N E->S
-                        f = (0x1023 >> (f * 4)) & 3; cost = cost_turn;
-                        break;
-                    case NGW_ACT_BREAK: {                                          // :280-294, axe: novelty_wrappers.py:144-183
-                        cost = cost_break;
-                        // Crate.step :1086-1089: the ingredients come first - unless the Crate wrapper sits BELOW FenceRestriction
-                        // (NGW_XF_CRATE_IN_FENCE): then a restricted Break never reaches it
-                        bool crate_now = EXT && crate_item && front == crate_item;
-                        if (EXT && fence_mode && ((brk_mask >> front) & 1u)) {     // FenceRestriction.step :924-946
-                            bool restricted = false;
-                            if (front != fence_item) {
-                                if (fence_mode == 1) {                             // medium: fence beside the AGENT, across its facing
-                                    const int side = f <= 1 ? 1 : S;
-                                    restricted = mp[r * S + c - side] == fence_item || mp[r * S + c + side] == fence_item;
-                                } else {                                           // hard: any fence in the 3x3 around the block in front
-                                    for (int dq = -S; dq <= S; dq += S)
-                                        for (int dc2 = -1; dc2 <= 1; dc2++) restricted |= mp[fcell + dq + dc2] == fence_item;
-                                }
-                            }
-                            if (restricted) {
-                                result = 0; msg = NGW_MSG_FENCE_RESTRICTION;
-                                if (nest & NGW_XF_CRATE_IN_FENCE) crate_now = false;
-                            } else fence_twice = true;                             // the wrapper runs env.step() AND its own epilogue
-                        }
-                        if (crate_now)
-                            for (int i = 1; i < K; i++) {
-                                const uint32_t w = i < 8 ? crate_a0 : (i < 16 ? crate_a1 : crate_a2);
-                                const int q = (int)((w >> (4 * (i & 7))) & 15u);
-                                if (q) { const int nv = inv[i] + q; inv[i] = nv; gi[i] = nv; }
-                            }
-                        if (msg == NGW_MSG_FENCE_RESTRICTION) break;
-                        if ((brk_mask >> front) & 1u) {
-                            const bool axe_ok = axe_item && inv_axe >= 1 && sel == axe_item;
-                            if (!axe_ok && axe_required) {                         // AxetoBreak*: novelty_wrappers.py:589-591
-                                result = 0; msg = NGW_MSG_NEED_AXE; arg = axe_item;
-                            } else {
-                                mp[fcell] = 0; gm[fcell] = 0;
-                                int nv = inv_front + 1 + (int)((brk2_mask >> front) & 1u);    // 2 under BreakIncrease
-                                if (axe_ok) {
-                                    nv = inv_front + axe_qty; rew = axe_reward; cost = axe_cost;
-                                } else if (!axe_item && ((rew_mask >> front) & 1u)) rew = break_reward;
-                                inv[front] = nv; gi[front] = nv;
-                            }
-                        } else { result = 0; msg = NGW_MSG_CANNOT_BREAK; arg = front; }
-                        break;
-                    }
-                    case NGW_ACT_CHOP:                                             // AddChopAction.step, novelty_wrappers.py:1288-1308
-                        cost = cost_chop;
-                        if ((brk_mask >> front) & 1u) {
-                            mp[fcell] = 0; gm[fcell] = 0;
-                            inv[front] = inv_front + 2; gi[front] = inv_front + 2;
-                            rew = chop_reward;
-                        } else { result = 0; msg = NGW_MSG_CANNOT_CHOP; arg = front; }
-                        break;
-                    case NGW_ACT_JUMP:                                             // AddJumpAction.step :1362-1381 (cell between ignored)
-                        if (ok2 && front2 == 0) { r = fr2; c = fc2; } else { result = 0; msg = NGW_MSG_BLOCK_IN_PATH; }
-                        cost = cost_jump;
-                        break;
-                    case NGW_ACT_PLACE:                                            // :295-314
-                        if (inv_place >= 1) {
-                            if (front == 0) {
-                                mp[fcell] = (int8_t)place_item; gm[fcell] = (int8_t)place_item;
-                                inv[place_item] = inv_place - 1; gi[place_item] = inv_place - 1;
-                                msg = NGW_MSG_PLACED; arg = place_item;
-                                const int nr = place_near;
-                                if ((okN && nbN == nr) || (okS && nbS == nr) || (okW && nbW == nr) || (okE && nbE == nr))
-                                    rew = place_reward;
-                            } else { result = 0; msg = NGW_MSG_ALREADY_EXISTS; arg = front; }
-                        } else { result = 0; msg = NGW_MSG_NOT_IN_INVENTORY; }
-                        cost = cost_place;
-                        break;
-                    case NGW_ACT_EXTRACT:                                          // :315-331 / bow_v1_env.py:293-304
-                        cost = cost_extract;
-                        if (front == ext_src) {
-                            const int nr = ext_near;
-                            if (!nr || (okN && nbN == nr) || (okS && nbS == nr) || (okW && nbW == nr) || (okE && nbE == nr)) {
-                                inv[ext_out] = inv_ext + ext_qty; gi[ext_out] = inv_ext + ext_qty;
-                                if (ext_consume) { mp[fcell] = 0; gm[fcell] = 0; }
-                                rew = ext_reward; cost = ext_cost_ok;
-                            } else { result = 0; msg = NGW_MSG_EXTRACT_NOT_NEAR; }
-                        } else { result = 0; msg = NGW_MSG_EXTRACT_NO_SRC; }
-                        break;
-                    case NGW_ACT_CRAFT: {                                          // craft :413-474
-                        const int nd0 = d2 & 255, nd1 = (d2 >> 8) & 255, nd2 = (d2 >> 16) & 255, nd3 = d2 >> 24;
-                        const int missing = ((nin > 0 && iv0 < nd0) ? 1 : 0) | ((nin > 1 && iv1 < nd1) ? 2 : 0) |
-                                            ((nin > 2 && iv2 < nd2) ? 4 : 0) | ((nin > 3 && iv3 < nd3) ? 8 : 0);   // :422-427
-                        if (missing) {                                             // :430-440
-                            result = 0; msg = NGW_MSG_MISSING_ITEMS; arg = (aarg << 8) | missing; cost = (d3 >> 16) & 255;
-                        } else if (((d0 >> 24) & 1u) && front != table_item) {   // :444-453
-                            result = 0; msg = NGW_MSG_NEED_TABLE; cost = d3 >> 24;
-                        } else {                                                   // :455-474 (ids of a recipe are distinct)
-                            rew = (int)(int8_t)(d4 >> 8);
-                            if (nin > 0) { inv[in0] = iv0 - nd0; gi[in0] = iv0 - nd0; }
-                            if (nin > 1) { inv[in1] = iv1 - nd1; gi[in1] = iv1 - nd1; }
-                            if (nin > 2) { inv[in2] = iv2 - nd2; gi[in2] = iv2 - nd2; }
-                            if (nin > 3) { inv[in3] = iv3 - nd3; gi[in3] = iv3 - nd3; }
-                            const int nout = inv_out + (int)((d3 >> 8) & 255);
-                            inv[out_item] = nout; gi[out_item] = nout;
-                            cost = (int)(d4 & 255u); msg = NGW_MSG_CRAFTED; arg = out_item;
-                        }
-                        break;
-                    }
-                    case NGW_ACT_SELECT:                                           // :338-347
-                        cost = cost_select;
-                        if (inv_arg >= 1) sel = aarg; else { result = 0; msg = NGW_MSG_NOT_IN_INVENTORY; }
-                        break;
-                    default: break;
-                    }
-                    if (n_entities) {                                            // grab_entities :538-554 (3x3 incl. own cell)
-                        for (int rr = r - 1; rr <= r + 1; rr++)
-                            for (int cc = c - 1; cc <= c + 1; cc++) {
-                                const int id = mp[rr * S + cc];
-                                if (id != 0 && ((ent_mask >> id) & 1u)) {
-                                    mp[rr * S + cc] = 0; gm[rr * S + cc] = 0;
-                                    const int nv = inv[id] + 1;
-                                    inv[id] = nv; gi[id] = nv;
-                                }
-                            }
-                    }
-                    int done = 0;                                                  // :354-357 (LDS ops of a wave are in order)
-                    if (inv[goal_item] >= 1) { rew = reward_done; done = 1; }
-                    if (EXT) {
-                        if (fence_twice) {                                         // FenceRestriction.step :949-972: its own info + a
-                            result = 1; cost = cost_break; msg = NGW_MSG_NONE; arg = 0;   // second step_count += 1 (:966)
-                            steps += 1;
-                        }
-                        if (fire_item && !((nest & NGW_XF_FIRE_SKIP_BREAK) && kind == NGW_ACT_BREAK) &&
-                            !((nest >> 8) && kind == NGW_ACT_CRAFT && (uint32_t)aarg + 1u == (nest >> 8))) {   // FireWall.step :1168-1189, after the wrapped step
-                            const int ac = r * S + c;
-                            if (mp[ac - S] == fire_item || mp[ac + S] == fire_item || mp[ac - 1] == fire_item || mp[ac + 1] == fire_item) {
-                                rew = fire_reward; done = 1; msg = NGW_MSG_FIRE_WALL; arg = 0;
-                            }
-                        }
-                    }
-                    steps += 1;                                                    // :362
-                    reward = rew; ended = done;
-                    info = (uint32_t)result | ((uint32_t)done << 1) | ((uint32_t)cost << 2) | ((uint32_t)msg << 8) |
-                           ((uint32_t)arg << 16);
-                    if (autoreset && (done || (horizon > 0 && steps >= horizon))) {   // same-step autoreset
-                        do_reset = true; ended = 1;
-                    }
-                }
-            }
-            if (do_reset) {                                                        // cold path, out of line
-                episode++;
-                uint32_t rr = new_episode(dspec, (LDS_AS int8_t*)mp, (LDS_AS int32_t*)inv, (LDS_AS uint32_t*)cand,
-                                          (const LDS_AS uint8_t*)(lds_act + NGW_MAX_ACTIONS * NGW_ACT_DW),
-                                          (LDS_AS uint16_t*)(lds + a.off_perm), env_global, e, episode, mode != NGW_MODE_REFILL,
-                                          mode != NGW_MODE_RESET);   // (an explicit reset that finds nothing prepared is not a miss)
-                do_reset = !(rr & NGW_F_ROWS_STORED);                              // from here on: "the wave must store its chunk"
-                rr &= ~(uint32_t)NGW_F_ROWS_STORED;
-                if (mode == NGW_MODE_REFILL && (rr & 0xFFu)) { rr &= ~0xFFu; episode = nx_old; }   // failed placement: leave the row
+    bool do_reset = live && (MODE == NGW_MODE_RESET || MODE == NGW_MODE_REFILL) && action != 0;
+    if (do_reset) {                                                                // out of line: new_episode
+        episode++;
+        uint32_t rr = new_episode(dspec, (LDS_AS int8_t*)mp, (LDS_AS int32_t*)inv, (LDS_AS uint32_t*)cand, (const LDS_AS uint8_t*)(lds + a.off_act),
+                                  (LDS_AS uint16_t*)(lds + a.off_perm), env_global, e, episode, MODE != NGW_MODE_REFILL,
+                                  MODE != NGW_MODE_RESET);   // (an explicit reset that finds nothing prepared is not a miss)
+        do_reset = !(rr & NGW_F_ROWS_STORED);                                      // from here on: "the wave must store its chunk"
+        rr &= ~(uint32_t)NGW_F_ROWS_STORED;
+        if (MODE == NGW_MODE_REFILL && (rr & 0xFFu)) { rr &= ~0xFFu; episode = nx_old; }   // failed placement: leave the row
                                                                                    // stale, the real reset raises the flag
-                flags |= rr & 0xFFu;
-                r = (int)((rr >> 8) & 0xFFu); c = (int)((rr >> 16) & 0xFFu); f = (int)(rr >> 24);
-                sel = 0; steps = 0;
-            }
-        }
-        if (t == 0) STAMP(4);
-        // ---- a reset rewrote whole maps / inventory rows in LDS: store the wave's chunk back with coalesced 16-B pieces
-        //      (wave-uniform decision; lanes that only stepped have already written their few changed bytes through)
-        if (mode == NGW_MODE_DBG_COPY || __any(do_reset)) {
-            __syncthreads();
-            for (int base = 0; base < npieces; base += EPB * PB) {
-                pieces_lds<false, MAPMODE>(buf, a, lds_map, base, npieces, tid);
+        flags |= rr & 0xFFu;
+        r = (int)((rr >> 8) & 0xFFu); c = (int)((rr >> 16) & 0xFFu); f = (int)(rr >> 24);
+        sel = 0; steps = 0;
+    }
+    STAMP(4);
+    // ---- a reset rewrote whole maps / inventory rows in LDS: store the wave's chunk back with coalesced 16-B pieces
+    if (MODE == NGW_MODE_DBG_COPY || __any(do_reset)) {
+        __syncthreads();
+        for (int base = 0; base < npieces; base += EPB * PB) {
+            pieces_lds<false, MAPMODE>(buf, a, lds_map, base, npieces, tid);
 #pragma unroll
-                for (int j = 0; j < PB; j++)
-                    if (base + tid + EPB * j < npieces) gmap[base + EPB * j] = buf[j];
-            }
-            inv_lds<false>(iq, a, lds_inv, tid);
+            for (int j = 0; j < PB; j++)
+                if (base + tid + EPB * j < npieces) gmap[base + EPB * j] = buf[j];
+        }
+        inv_lds<false>(iq, a, lds_inv, tid);
 #pragma unroll
-            for (int j = 0; j < IQ; j++) { if (j * EPB < 16 * K && tid + EPB * j < 16 * K) ginv[EPB * j] = iq[j]; }
-            __syncthreads();
-        }
-        if (live) {
-            gloc->x = r; gloc->y = c;
-            *gfac = f;
-            if (mode != NGW_MODE_RESET && mode != NGW_MODE_REFILL) {
-                *grew = reward;
-                *gdone = (uint8_t)ended;
-                *ginfo = info;
-            }
-            if (rolling) {
-                if (a.row_reward) a.row_reward[(int64_t)t * a.row_stride + e] = reward;
-                if (a.row_done) a.row_done[(int64_t)t * a.row_stride + e] = (uint8_t)ended;
-                acc_ret += reward; acc_len += 1;
-                if (ended) { acc_sum += acc_ret; acc_eps += 1; acc_ret = 0; acc_len = 0; }
-            }
-        }
-        if (LIDAR) {
-            // ---- fused LidarInFront observation of the state this step produced (observation_wrappers.py:67-78)
-            const int L = a.lidar_len, LB = lB, LR = lR, LNC = lNC, LNI = lNI;
-            u32x4* t4 = reinterpret_cast<u32x4*>(lds + a.off_ltile);
-            __syncthreads();
-            for (int p = tid; p < 16 * L; p += EPB) t4[p] = u32x4{0u, 0u, 0u, 0u};
-            __syncthreads();
-            if (live) {
-                const int16_t* toff = reinterpret_cast<const int16_t*>(lds + a.off_ltab);
-                const uint8_t* chan_of_item = reinterpret_cast<const uint8_t*>(lds + a.off_ltab + 4 * LIDAR_TAB16);
-                const uint8_t* inv_item = chan_of_item + NGW_MAX_ITEMS;
-                int32_t* row = reinterpret_cast<int32_t*>(lds + a.off_ltile) + tid * L;
-                lidar_march(mp + r * S + c, f, LB, LR, LNC, toff, chan_of_item, row);
-                for (int j = 0; j < LNI; j++) row[LB * LNC + j] = inv[inv_item[j]];           // :74-75, inventory is in LDS
-            }
-            __syncthreads();
-            lidar_store((const LDS_AS uint32_t*)(lds + a.off_ltile), glid, L, a.l_i16 != 0, tid);
-        }
+        for (int j = 0; j < IQ; j++) { if (j * EPB < 16 * K && tid + EPB * j < 16 * K) ginv[EPB * j] = iq[j]; }
+        __syncthreads();
     }
     if (live) {
+        reinterpret_cast<int2*>(a.b.loc)[e] = int2{r, c};
+        a.b.facing[e] = f;
         if (MODE != NGW_MODE_REFILL) {
             a.b.selected[e] = (uint8_t)sel;
             a.b.step_count[e] = steps;
         }
         a.b.episode[e] = episode;
-        if (rolling && a.acc) { a.acc[e] = acc_ret; a.acc[a.n_pad + e] = acc_len; a.acc[2 * a.n_pad + e] = acc_sum; a.acc[3 * a.n_pad + e] = acc_eps; }
     }
+    if (LIDAR) lidar_epilogue(a, lds, tid, live, mp + r * S + c, f, inv);          // the observation of the state this reset produced
     if (flags) atomicOr(a.b.flags, flags);
     raise_host_flags(a.b.flags_host, flags);
-    if (MODE == NGW_MODE_STEP || MODE == NGW_MODE_RESET) {
+    if (MODE == NGW_MODE_RESET) {
         if (a.seq) mirror_wave(dspec, a.b, a.S2, a.K, a.n);
         signal_host_seq(a.b.flags_host, a.seq);
     }
@@ -1179,32 +1051,22 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
 #include "ngw_lean.inc"
 #include "ngw_reset.inc"
 
-// ---------------------------------------------------------------- LidarInFront observation kernel
-// observation_wrappers.py:32-80.  Same wave = 64 envs decomposition and the same coalesced map staging as the step
-// kernel; every lane marches its env's beams on the LDS map along the host-computed integer offsets (4 ranges per
-// round: one 8-byte table read + 4 independent cell reads), builds its observation row in an LDS tile with an odd
-// stride, and the wave then writes the tile out as one contiguous block of dwords.
+// ---------------------------------------------------------------- LidarInFront observation kernel (stand-alone launch)
+// observation_wrappers.py:32-80 of the CURRENT state.  Same wave = 64 envs decomposition and the same coalesced staging of the
+// maps and inventory rows as the other kernels, then the shared row builder (lidar_epilogue).  `a` carries the launch's own LDS
+// layout (ngw_lidar_configure: off_litem, off_ltab, off_ltile, off_map, off_inv).
 template <int MAPMODE>
-__global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const NgwLidarDev* __restrict__ cfg, const NgwLaunch a,
-                                                             int32_t* __restrict__ out, int L, uint32_t off_map, uint32_t off_tab,
-                                                             uint32_t off_tile) {
+__global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const NgwLaunch a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
     const int64_t env0 = (int64_t)blockIdx.x * EPB;
     const int64_t e = env0 + tid;
     const bool live = e < a.n;
     const int S = a.S, K = a.K, npieces = 4 * a.S2;
-    uint32_t* lds_map = lds + off_map;
-    // ray offset table (8 KiB = 512 pieces of 16 B, 8 per lane) + the two item tables right behind it
-    constexpr int TAB16 = LIDAR_TAB16;
-    u32x4 tb[8];
-    {
-        const u32x4* src = reinterpret_cast<const u32x4*>(cfg->off);
-#pragma unroll
-        for (int j = 0; j < 8; j++) tb[j] = src[tid + EPB * j];
-    }
+    uint32_t* lds_map = lds + a.off_map;
+    int32_t* lds_inv = reinterpret_cast<int32_t*>(lds + a.off_inv);
     uint32_t it = 0;
-    if (tid < 2 * NGW_MAX_ITEMS / 4) it = reinterpret_cast<const uint32_t*>(cfg->chan_of_item)[tid];
+    if (tid < LIDAR_ITEM_DW) it = reinterpret_cast<const uint32_t*>(a.lcfg->chan_of_item)[tid];
     u32x4 buf[PB];
     const u32x4* gin = reinterpret_cast<const u32x4*>(a.b.map + env0 * a.S2);
     pieces_load(buf, gin, 0, npieces, tid);
@@ -1214,44 +1076,21 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const NgwLidarDev* _
         r = rc.x; c = rc.y;
         f = a.b.facing[e];
     }
-    const int B = cfg->num_beams, R = cfg->max_range, NC = cfg->n_chan, NI = cfg->n_inv;
+    u32x4 iq[IQ];
     {
-        u32x4* dst = reinterpret_cast<u32x4*>(lds + off_tab);
+        const u32x4* gi = reinterpret_cast<const u32x4*>(a.b.inv + env0 * K);
 #pragma unroll
-        for (int j = 0; j < 8; j++) dst[tid + EPB * j] = tb[j];
-        if (tid < 2 * NGW_MAX_ITEMS / 4) lds[off_tab + 4 * TAB16 + tid] = it;
-        u32x4* t4 = reinterpret_cast<u32x4*>(lds + off_tile);                        // zero the observation tile
-        for (int p = tid; p < 16 * L; p += EPB) t4[p] = u32x4{0u, 0u, 0u, 0u};
+        for (int j = 0; j < IQ; j++) iq[j] = (j * EPB < 16 * K) ? gi[min(tid + EPB * j, 16 * K - 1)] : u32x4{0u, 0u, 0u, 0u};
     }
+    if (tid < LIDAR_ITEM_DW) lds[a.off_litem + tid] = it;
     pieces_lds<true, MAPMODE>(buf, a, lds_map, 0, npieces, tid);
     for (int base = EPB * PB; base < npieces; base += EPB * PB) {
         pieces_load(buf, gin, base, npieces, tid);
         pieces_lds<true, MAPMODE>(buf, a, lds_map, base, npieces, tid);
     }
-    __syncthreads();
+    inv_lds<true>(iq, a, lds_inv, tid);
     const int8_t* mp = reinterpret_cast<const int8_t*>(lds_map) + tid * a.MS;
-    const int16_t* toff = reinterpret_cast<const int16_t*>(lds + off_tab);
-    const uint8_t* chan_of_item = reinterpret_cast<const uint8_t*>(lds + off_tab + 4 * TAB16);
-    const uint8_t* inv_item = chan_of_item + NGW_MAX_ITEMS;
-    int32_t* row = reinterpret_cast<int32_t*>(lds + off_tile) + tid * L;
-    // inventory tail (:74-75): issue every (scattered, per-lane) global load NOW, all at once - their latency hides under
-    // the march; the values go into the tile afterwards.  A rolled loop here serialises NI dependent HBM round trips.
-    int32_t ivals[NGW_MAX_ITEMS];
-    if (live) {
-        const int32_t* gi = a.b.inv + e * K;
-#pragma unroll
-        for (int j = 0; j < NGW_MAX_ITEMS; j++) ivals[j] = (j < NI) ? gi[inv_item[j]] : 0;
-    }
-    if (live) {
-        lidar_march(mp + r * S + c, f, B, R, NC, toff, chan_of_item, row);
-#pragma unroll
-        for (int j = 0; j < NGW_MAX_ITEMS; j++)
-            if (j < NI) row[B * NC + j] = ivals[j];
-    }
-    __syncthreads();
-    // the wave's 64 rows are one contiguous block of 64 * L dwords in HBM = 16 * L pieces of 16 B
-    lidar_store((const LDS_AS uint32_t*)(lds + off_tile), (GLOBAL_AS uint32_t*)(reinterpret_cast<uint32_t*>(out) + ((env0 * L) >> (a.l_i16 ? 1 : 0))), L,
-                a.l_i16 != 0, tid);   // out is padded to n_pad rows
+    lidar_epilogue(a, lds, tid, live, mp + r * S + c, f, lds_inv + tid * a.KP);     // (its first barrier makes the staging visible)
 }
 
 // Delta refresh of a host mirror (NgwDiff, ngw_step_host): region blockIdx.y is compared, 16 bytes at a time, with the shadow
@@ -1352,9 +1191,7 @@ extern "C" hipError_t ngw_agent_view_launch(const int8_t* map, const int32_t* lo
     return hipGetLastError();
 }
 
-extern "C" hipError_t ngw_lidar_launch(const NgwLidarDev* cfg, const NgwLaunch* a, int map_mode, int32_t* out, int L,
-                                       uint32_t off_map, uint32_t off_tab, uint32_t off_tile, unsigned grid, size_t lds_bytes,
-                                       hipStream_t stream) {
+extern "C" hipError_t ngw_lidar_launch(const NgwLaunch* a, int map_mode, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     const void* fn = map_mode == NGW_MAP_STRAIGHT ? reinterpret_cast<const void*>(ngw_lidar_kernel<NGW_MAP_STRAIGHT>)
                      : map_mode == NGW_MAP_DWORD  ? reinterpret_cast<const void*>(ngw_lidar_kernel<NGW_MAP_DWORD>)
                                                   : reinterpret_cast<const void*>(ngw_lidar_kernel<NGW_MAP_BYTE>);
@@ -1363,21 +1200,16 @@ extern "C" hipError_t ngw_lidar_launch(const NgwLidarDev* cfg, const NgwLaunch* 
         if (e != hipSuccess) return e;
     }
     switch (map_mode) {
-    case NGW_MAP_STRAIGHT:
-        hipLaunchKernelGGL(ngw_lidar_kernel<NGW_MAP_STRAIGHT>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, cfg, *a, out, L, off_map, off_tab, off_tile);
-        break;
-    case NGW_MAP_DWORD:
-        hipLaunchKernelGGL(ngw_lidar_kernel<NGW_MAP_DWORD>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, cfg, *a, out, L, off_map, off_tab, off_tile);
-        break;
-    default:
-        hipLaunchKernelGGL(ngw_lidar_kernel<NGW_MAP_BYTE>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, cfg, *a, out, L, off_map, off_tab, off_tile);
+    case NGW_MAP_STRAIGHT: hipLaunchKernelGGL(ngw_lidar_kernel<NGW_MAP_STRAIGHT>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, *a); break;
+    case NGW_MAP_DWORD: hipLaunchKernelGGL(ngw_lidar_kernel<NGW_MAP_DWORD>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, *a); break;
+    default: hipLaunchKernelGGL(ngw_lidar_kernel<NGW_MAP_BYTE>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, *a);
     }
     return hipGetLastError();
 }
 
 namespace {
 
-template <int MAPMODE, int MODE, bool LIDAR, bool EXT>
+template <int MAPMODE, int MODE, bool LIDAR>
 hipError_t launch_one(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     // CDNA4 has 160 KiB of LDS per CU; anything above the 64 KiB default needs an explicit opt-in per device.
     static size_t lds_opt_in[64] = {0};
@@ -1385,37 +1217,26 @@ hipError_t launch_one(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (lds_bytes > 64 * 1024 && dev < 64 && lds_bytes > lds_opt_in[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ngw_kernel<MAPMODE, MODE, LIDAR, EXT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ngw_kernel<MAPMODE, MODE, LIDAR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes);
         if (e != hipSuccess) return e;
         lds_opt_in[dev] = lds_bytes;
     }
-    hipLaunchKernelGGL((ngw_kernel<MAPMODE, MODE, LIDAR, EXT>), dim3(grid), dim3(NGW_EPB), lds_bytes, stream, dspec, *a);
+    hipLaunchKernelGGL((ngw_kernel<MAPMODE, MODE, LIDAR>), dim3(grid), dim3(NGW_EPB), lds_bytes, stream, dspec, *a);
     return hipGetLastError();
 }
 
-template <int MAPMODE, bool LIDAR, bool EXT>
-static hipError_t launch_mode(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
-    switch (a->mode) {
-    case NGW_MODE_STEP: return launch_one<MAPMODE, NGW_MODE_STEP, LIDAR, EXT>(dspec, a, grid, lds_bytes, stream);
-    case NGW_MODE_RESET: return launch_one<MAPMODE, NGW_MODE_RESET, LIDAR, EXT>(dspec, a, grid, lds_bytes, stream);
-    case NGW_MODE_ROLLOUT: return launch_one<MAPMODE, NGW_MODE_ROLLOUT, LIDAR, EXT>(dspec, a, grid, lds_bytes, stream);
-    case NGW_MODE_ROLLOUT_ACT: return launch_one<MAPMODE, NGW_MODE_ROLLOUT_ACT, LIDAR, EXT>(dspec, a, grid, lds_bytes, stream);
-    default: break;
-    }
-    if (a->mode == NGW_MODE_REFILL) return launch_one<MAPMODE, NGW_MODE_REFILL, false, false>(dspec, a, grid, lds_bytes, stream);
-    if (LIDAR || EXT) return hipErrorInvalidValue;
-    if (a->mode == NGW_MODE_DBG_COPY) return launch_one<MAPMODE, NGW_MODE_DBG_COPY, false, false>(dspec, a, grid, lds_bytes, stream);
-    return launch_one<MAPMODE, NGW_MODE_DBG_NOP, false, false>(dspec, a, grid, lds_bytes, stream);
-}
-
+// the general new-episode kernel: explicit resets (with or without the fused lidar observation), refills, diagnostics
 template <int MAPMODE>
-static hipError_t launch_feat(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream) {
-    switch (feat & 3) {
-    case 0: return launch_mode<MAPMODE, false, false>(dspec, a, grid, lds_bytes, stream);
-    case 1: return launch_mode<MAPMODE, true, false>(dspec, a, grid, lds_bytes, stream);
-    case 2: return launch_mode<MAPMODE, false, true>(dspec, a, grid, lds_bytes, stream);
-    default: return launch_mode<MAPMODE, true, true>(dspec, a, grid, lds_bytes, stream);
+static hipError_t launch_general(const NgwDevSpec* dspec, const NgwLaunch* a, bool lidar, unsigned grid, size_t lds_bytes, hipStream_t stream) {
+    switch (a->mode) {
+    case NGW_MODE_RESET:
+        return lidar ? launch_one<MAPMODE, NGW_MODE_RESET, true>(dspec, a, grid, lds_bytes, stream)
+                     : launch_one<MAPMODE, NGW_MODE_RESET, false>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MODE_REFILL: return launch_one<MAPMODE, NGW_MODE_REFILL, false>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MODE_DBG_COPY: return launch_one<MAPMODE, NGW_MODE_DBG_COPY, false>(dspec, a, grid, lds_bytes, stream);
+    case NGW_MODE_DBG_NOP: return launch_one<MAPMODE, NGW_MODE_DBG_NOP, false>(dspec, a, grid, lds_bytes, stream);
+    default: return hipErrorInvalidValue;
     }
 }
 
@@ -1438,6 +1259,7 @@ extern "C" hipError_t ngw_reset_fast_launch(const NgwDevSpec* dspec, const NgwRe
     return hipLaunchKernel(fn, dim3(grid), dim3(NGW_EPB), args, lds_bytes, stream);
 }
 
+// feat: 1 = fused LidarInFront epilogue, 2 = wrapper predicates (EXT), 8 = no-stage step (maps read in place)
 extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int feat, unsigned grid,
                                  size_t lds_bytes, hipStream_t stream) {
     if (a->mode >= 10 && a->mode <= 12) {       // diagnostics: empty kernels with other workgroup shapes over the same lanes
@@ -1445,17 +1267,17 @@ extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, in
         hipLaunchKernelGGL(ngw_nop_kernel, dim3(grid * NGW_EPB / tpb), dim3(tpb), a->mode == 12 ? lds_bytes * 2 : 0, stream, dspec, *a);
         return hipGetLastError();
     }
-    // Everything but the fused LidarInFront epilogue steps through the lean kernels; the wrapper predicates (feat & 2) are a
-    // template flag of the same body.
-#define NGW_LEAN_EXT(CALL_F, CALL_T) ((feat & 2) ? CALL_T : CALL_F)
-    if ((feat & 4) && a->mode == NGW_MODE_STEP && (!(feat & 1) || !(feat & 8))) {   // one step (the lidar epilogue needs the staged form)
-        if (feat & 8)                                               // no-stage (big maps)
-            return NGW_LEAN_EXT((launch_lean<NGW_MAP_STRAIGHT, false, false, false>(dspec, a, grid, lds_bytes, stream)),
-                                (launch_lean<NGW_MAP_STRAIGHT, false, true, false>(dspec, a, grid, lds_bytes, stream)));
-#define NGW_LEAN_STEP(MM) ((feat & 1) ? NGW_LEAN_EXT((launch_lean<MM, true, false, true>(dspec, a, grid, lds_bytes, stream)),   \
-                                                     (launch_lean<MM, true, true, true>(dspec, a, grid, lds_bytes, stream)))    \
-                                      : NGW_LEAN_EXT((launch_lean<MM, true, false, false>(dspec, a, grid, lds_bytes, stream)),  \
-                                                     (launch_lean<MM, true, true, false>(dspec, a, grid, lds_bytes, stream))))
+    const bool lidar = (feat & 1) != 0, ext = (feat & 2) != 0;
+    if (a->mode == NGW_MODE_STEP) {                                     // ONE batched step(): ngw_step_lean
+        if (feat & 8) {                                                 // no-stage (the lidar epilogue needs the staged form)
+            if (lidar) return hipErrorInvalidValue;
+            return ext ? launch_lean<NGW_MAP_STRAIGHT, false, true, false>(dspec, a, grid, lds_bytes, stream)
+                       : launch_lean<NGW_MAP_STRAIGHT, false, false, false>(dspec, a, grid, lds_bytes, stream);
+        }
+#define NGW_LEAN_STEP(MM) (lidar ? (ext ? launch_lean<MM, true, true, true>(dspec, a, grid, lds_bytes, stream)      \
+                                        : launch_lean<MM, true, false, true>(dspec, a, grid, lds_bytes, stream))    \
+                                 : (ext ? launch_lean<MM, true, true, false>(dspec, a, grid, lds_bytes, stream)     \
+                                        : launch_lean<MM, true, false, false>(dspec, a, grid, lds_bytes, stream)))
         switch (map_mode) {
         case NGW_MAP_STRAIGHT: return NGW_LEAN_STEP(NGW_MAP_STRAIGHT);
         case NGW_MAP_DWORD: return NGW_LEAN_STEP(NGW_MAP_DWORD);
@@ -1463,23 +1285,24 @@ extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, in
         }
 #undef NGW_LEAN_STEP
     }
-    if ((feat & 4) && !(feat & 1) && (a->mode == NGW_MODE_ROLLOUT || a->mode == NGW_MODE_ROLLOUT_ACT)) {   // fused rollout
+    if (a->mode == NGW_MODE_ROLLOUT || a->mode == NGW_MODE_ROLLOUT_ACT) {   // fused rollout: ngw_rollout_lean
         const bool sup = a->mode == NGW_MODE_ROLLOUT_ACT;
-#define NGW_LEAN_RO(MM) (sup ? NGW_LEAN_EXT((launch_rollout_lean<MM, true, false>(dspec, a, grid, lds_bytes, stream)),   \
-                                            (launch_rollout_lean<MM, true, true>(dspec, a, grid, lds_bytes, stream)))    \
-                             : NGW_LEAN_EXT((launch_rollout_lean<MM, false, false>(dspec, a, grid, lds_bytes, stream)),  \
-                                            (launch_rollout_lean<MM, false, true>(dspec, a, grid, lds_bytes, stream))))
+#define NGW_LEAN_RO2(MM, SUP) (lidar ? (ext ? launch_rollout_lean<MM, SUP, true, true>(dspec, a, grid, lds_bytes, stream)      \
+                                            : launch_rollout_lean<MM, SUP, false, true>(dspec, a, grid, lds_bytes, stream))    \
+                                     : (ext ? launch_rollout_lean<MM, SUP, true, false>(dspec, a, grid, lds_bytes, stream)     \
+                                            : launch_rollout_lean<MM, SUP, false, false>(dspec, a, grid, lds_bytes, stream)))
+#define NGW_LEAN_RO(MM) (sup ? NGW_LEAN_RO2(MM, true) : NGW_LEAN_RO2(MM, false))
         switch (map_mode) {
         case NGW_MAP_STRAIGHT: return NGW_LEAN_RO(NGW_MAP_STRAIGHT);
         case NGW_MAP_DWORD: return NGW_LEAN_RO(NGW_MAP_DWORD);
         default: return NGW_LEAN_RO(NGW_MAP_BYTE);
         }
 #undef NGW_LEAN_RO
+#undef NGW_LEAN_RO2
     }
-#undef NGW_LEAN_EXT
     switch (map_mode) {
-    case NGW_MAP_STRAIGHT: return launch_feat<NGW_MAP_STRAIGHT>(dspec, a, feat, grid, lds_bytes, stream);
-    case NGW_MAP_DWORD: return launch_feat<NGW_MAP_DWORD>(dspec, a, feat, grid, lds_bytes, stream);
-    default: return launch_feat<NGW_MAP_BYTE>(dspec, a, feat, grid, lds_bytes, stream);
+    case NGW_MAP_STRAIGHT: return launch_general<NGW_MAP_STRAIGHT>(dspec, a, lidar, grid, lds_bytes, stream);
+    case NGW_MAP_DWORD: return launch_general<NGW_MAP_DWORD>(dspec, a, lidar, grid, lds_bytes, stream);
+    default: return launch_general<NGW_MAP_BYTE>(dspec, a, lidar, grid, lds_bytes, stream);
     }
 }

@@ -1,8 +1,8 @@
 """Observation wrappers with the reference's call shape (gym_novel_gridworlds/observation_wrappers.py).
 
 `LidarInFront(env, num_beams=8)` (reference :10-80) works on the single-env adapter (returns the reference's 1-D
-np.array of ints from reset()/step()) and on `VecNovelGridworld` (returns int32 [N, L] batches computed by the
-`ngw_lidar_kernel`).  As in the reference, the set of lidar items and the beam range are fixed when the wrapper is
+np.array of ints from reset()/step()) and on `VecNovelGridworld` (returns int16 [N, L] batches - int32 or a packed pair on request - computed in the
+step launch's own epilogue).  As in the reference, the set of lidar items and the beam range are fixed when the wrapper is
 constructed, while the appended inventory follows the env's current items - so a novelty injected AFTER wrapping adds
 an inventory entry but no lidar channel (tests/random_action.py:24-42 order).
 
@@ -17,10 +17,10 @@ from .vec_env import VecNovelGridworld
 
 
 class LidarInFront(NoveltyWrapper):
-    def __init__(self, env, num_beams=8, fused=True, dtype=np.int32):
+    def __init__(self, env, num_beams=8, fused=True, dtype=np.int16):
         super().__init__(env)
         self.num_beams = num_beams
-        self._dtype = np.dtype(dtype)                           # batched envs: int32 (default) or int16 observation rows
+        self._dtype = dtype if isinstance(dtype, str) else np.dtype(dtype)   # batched envs: int16 (default), int32 or 'packed' rows (vec_env.lidar_configure)
         self._fused = fused                                     # batched envs: compute the observation inside the step launch
         self._vec = env if isinstance(env, VecNovelGridworld) else None
         spec = env.spec if self._vec is not None else self._base()._sync_spec()

@@ -92,7 +92,7 @@ class VecNovelGridworld:
         self.autoreset, self.horizon = bool(autoreset), int(horizon)
         # what the caller chose for the prepared next episodes ('auto' / 0 = the library's own defaults); rebuild() re-applies it
         self._prefetch_arg, self._depth_arg = reset_prefetch, int(reset_prefetch_depth)
-        self.lidar, self.lidar_fused, self.lidar_len, self.lidar_dtype = None, False, 0, np.dtype(np.int32)   # set by lidar_configure()
+        self.lidar, self.lidar_fused, self.lidar_len, self.lidar_dtype, self.lidar_packed = None, False, 0, np.dtype(np.int16), False   # set by lidar_configure()
         self._h = C.c_void_p()
         self._open(spec)
 
@@ -125,7 +125,7 @@ class VecNovelGridworld:
         self._flags_word = C.c_uint32(0)
         self._host = None                                     # host mirrors of the host API: allocated on first use
         if self.lidar is not None:                            # the observation setup travels with the env (rebuild)
-            self.lidar_configure(self.lidar, fused=self.lidar_fused, dtype=self.lidar_dtype)
+            self.lidar_configure(self.lidar, fused=self.lidar_fused, dtype='packed' if self.lidar_packed else self.lidar_dtype)
 
     def rebuild(self, spec):
         """The same batched env - same object, same shard of the global env index space (`env_index_base`), same autoreset /
@@ -384,6 +384,14 @@ class VecNovelGridworld:
         return int(f(self._h))
 
     @property
+    def step_reads_map_in_place(self):
+        """True if step launches run the kernel that reads the few map cells a step needs straight from HBM, False if they stage the
+        wave's maps through LDS (include/ngw.h ngw_step_kernel_info)."""
+        v = C.c_int32()
+        _cabi.check(_cabi.lib().ngw_step_kernel_info(self._h, C.byref(v)))
+        return bool(v.value)
+
+    @property
     def reset_prefetch_depth(self):
         v = C.c_int32()
         _cabi.check(_cabi.lib().ngw_get_reset_prefetch_depth(self._h, C.byref(v)))
@@ -464,26 +472,47 @@ class VecNovelGridworld:
                                                *[C.c_void_p(int(x)) if x else None for x in dst_ptrs]))
 
     # ------------------------------------------------------------------ LidarInFront observation
-    def lidar_configure(self, lidar_config=None, num_beams=8, fused=False, dtype=np.int32):
+    def lidar_configure(self, lidar_config=None, num_beams=8, fused=False, dtype=np.int16):
         """Enable the LidarInFront observation (reference observation_wrappers.py:10-80).  `lidar_config` fixes the lidar
         item set at wrap time like the reference wrapper does; by default it is built from the current spec.
-        fused=True: every reset / step / rollout launch refreshes the observation in its own epilogue (no extra launch)."""
+        fused=True: every reset / step / rollout launch refreshes the observation in its own epilogue (no extra launch).
+        dtype: the row format on the device and of what lidar_observation() returns - np.int16 (default: a beam entry is a
+        range <= 64, inventory counts saturate at 32767), np.int32, or 'packed' (uint8 beam entries + int16 inventory tail,
+        70 B per env for the reference's 8 beams; lidar_observation() then returns the pair (beams uint8 [N, B * NC],
+        inventory int16 [N, NI]) as views of one buffer)."""
         from .lidar import LidarConfig
         self.lidar = lidar_config if lidar_config is not None else LidarConfig(self.spec, num_beams)
         self._lidar_c = self.lidar.compile(self.spec)
-        _cabi.check(_cabi.lib().ngw_lidar_configure(self._h, C.byref(self._lidar_c)))
+        L = _cabi.lib()
+        _cabi.check(L.ngw_lidar_configure(self._h, C.byref(self._lidar_c)))
         self.lidar_len = self.lidar.obs_len(self.spec)
-        self.lidar_dtype = np.dtype(dtype)
-        assert self.lidar_dtype in (np.dtype(np.int32), np.dtype(np.int16)), "lidar dtype must be int32 or int16"
-        if hasattr(_cabi.lib(), 'ngw_lidar_set_output') or self.lidar_dtype.itemsize != 4:   # (older builds through NGW_LIB: int32 only)
-            _cabi.check(_cabi.lib().ngw_lidar_set_output(self._h, self.lidar_dtype.itemsize * 8))
-        self._lidar_host = _cabi.pinned_array((self.num_envs, self.lidar_len), self.lidar_dtype)
+        self.lidar_packed = isinstance(dtype, str) and dtype == 'packed'
+        self.lidar_dtype = np.dtype(np.uint8) if self.lidar_packed else np.dtype(dtype)
+        assert self.lidar_packed or self.lidar_dtype in (np.dtype(np.int32), np.dtype(np.int16)), "lidar dtype must be int32, int16 or 'packed'"
+        _cabi.check(L.ngw_lidar_set_output(self._h, 8 if self.lidar_packed else self.lidar_dtype.itemsize * 8))
+        lay = [C.c_int32() for _ in range(4)]
+        _cabi.check(L.ngw_lidar_row_layout(self._h, *[C.byref(x) for x in lay]))
+        self.lidar_row_bytes, self._lidar_beam_bytes, self._lidar_inv_off, self._lidar_inv_bytes = [int(x.value) for x in lay]
+        if self.lidar_packed:
+            self._lidar_host = _cabi.pinned_array((self.num_envs, self.lidar_row_bytes), np.uint8)
+        else:
+            self._lidar_host = _cabi.pinned_array((self.num_envs, self.lidar_len), self.lidar_dtype)
         self.lidar_fused = bool(fused)
-        _cabi.check(_cabi.lib().ngw_lidar_fuse(self._h, int(self.lidar_fused)))
+        _cabi.check(L.ngw_lidar_fuse(self._h, int(self.lidar_fused)))
+
+    def _lidar_split(self, rows):
+        """(beams uint8 [N, B * NC], inventory int16 [N, NI]) views of packed rows (numpy array or torch tensor [N, row_bytes])."""
+        nb = self.lidar.num_beams * len(self.lidar.lidar_items_id)
+        beams, tail = rows[:, :nb], rows[:, self._lidar_inv_off:]
+        if isinstance(rows, np.ndarray):
+            return beams, tail.view(np.int16)
+        import torch
+        return beams, tail.view(torch.int16)
 
     def lidar_observation(self, device=False, copy=False):
-        """[N, num_beams * n_lidar_items + n_inventory] int32 observation of the current state (one kernel launch, or
-        none in fused mode - then it is the observation the last reset / step launch produced)."""
+        """[N, num_beams * n_lidar_items + n_inventory] observation of the current state in the configured dtype (one kernel
+        launch, or none in fused mode - then it is the observation the last reset / step / rollout launch produced); with the
+        packed format the pair (beams, inventory), see lidar_configure."""
         if not self.lidar_fused:
             _cabi.check(_cabi.lib().ngw_lidar(self._h))
         if device:
@@ -491,9 +520,21 @@ class VecNovelGridworld:
             p = C.c_void_p()
             _cabi.check(_cabi.lib().ngw_lidar_device_ptr(self._h, C.byref(p)))
             self.sync()
+            if self.lidar_packed:
+                raw = torch.as_tensor(_DevArray(p.value, (self.num_envs, self.lidar_row_bytes), '|u1'), device='cuda:%d' % self.device)
+                return self._lidar_split(raw)
             return torch.as_tensor(_DevArray(p.value, (self.num_envs, self.lidar_len), self.lidar_dtype.str), device='cuda:%d' % self.device)
         _cabi.check(_cabi.lib().ngw_get_lidar(self._h, _cabi._ptr(self._lidar_host, self.lidar_dtype)))
-        return self._lidar_host.copy() if copy else self._lidar_host
+        out = self._lidar_host.copy() if copy else self._lidar_host
+        return self._lidar_split(out) if self.lidar_packed else out
+
+    def lidar_widen(self, packed_pair, dtype=np.int32):
+        """The [N, L] array of `dtype` from a packed (beams, inventory) pair (host side)."""
+        beams, tail = packed_pair
+        out = np.empty((beams.shape[0], beams.shape[1] + tail.shape[1]), dtype)
+        out[:, :beams.shape[1]] = beams
+        out[:, beams.shape[1]:] = tail
+        return out
 
     # ------------------------------------------------------------------ state (checkpoint / oracle injection)
     def get_state(self, first=0, count=None):

@@ -356,18 +356,31 @@ int ngw_pack_obs(ngw_handle* h, void* payload_dev);
 int ngw_unpack_obs(ngw_handle* h, const void* payloads_dev, int32_t world, int8_t* map, int32_t* loc, int32_t* facing,
                    int32_t* inv, int32_t* reward, uint8_t* done, uint32_t* info);
 
-/* LidarInFront: configure once, then ngw_lidar() computes the observation of the CURRENT state of every env into an
- * int32 [N][num_beams * n_chan + n_inv] device buffer (enqueued on the handle's stream, after the steps before it). */
+/* Which per-launch step kernel this handle's ngw_step* calls run right now: *map_in_place = 1 - the one that reads the <= 14 map
+ * cells a step needs straight from HBM (every map size but 10 x 10 and 6 x 6), 0 - the one that stages the wave's 64 maps through
+ * LDS (10 x 10, 6 x 6, and any size while the fused lidar epilogue is on).  What bench.py prices its byte models on. */
+int ngw_step_kernel_info(ngw_handle* h, int32_t* map_in_place);
+
+/* LidarInFront: configure once, then ngw_lidar() computes the observation of the CURRENT state of every env into a device
+ * buffer of [N] rows of num_beams * n_chan beam entries + n_inv inventory entries (enqueued on the handle's stream, after the
+ * steps before it). */
 int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg);
 int ngw_lidar(ngw_handle* h);
-/* enable = 1: every following reset / step / rollout launch also refreshes the lidar observation in its epilogue (the
- * maps are already in LDS there), so ngw_lidar() is not needed; 0 restores the plain kernels. */
+/* enable = 1: every following reset / step / rollout launch also refreshes the lidar observation in its epilogue (the maps are
+ * already in LDS there), so ngw_lidar() is not needed; 0 restores the plain kernels.  A fused rollout refreshes it ONCE, for
+ * the state the launch ends in (the buffer holds one row per env). */
 int ngw_lidar_fuse(ngw_handle* h, int enable);
-/* Element width of the observation: 32 (default, int32) or 16 (int16, values saturate at 32767 - beam ranges are < 128,
- * the inventory tail is the only part that could ever exceed it).  Halves the largest transfer of a LidarInFront loop;
- * ngw_get_lidar / ngw_lidar_device_ptr then deal in int16 rows of the same length. */
+/* Row format of the observation in the device buffer (and of what ngw_get_lidar copies out):
+ *   16 (default)  int16 [len]: half the bytes of the reference's integers; values saturate at 32767 - a beam entry is a range
+ *                 <= 64, the inventory tail is the only part that could ever exceed it;
+ *   32            int32 [len];
+ *    8            packed: uint8 [num_beams * n_chan] beam entries, padded to an even count, then int16 [n_inv] inventory
+ *                 (saturating) - 70 B per env for the reference's 8 beams on Pogostick-v1 against 252 B as int32.
+ * ngw_lidar_row_layout reports bytes per row, bytes per beam entry, the byte offset of the inventory tail and bytes per
+ * inventory entry of the current format (any pointer may be NULL). */
 int ngw_lidar_set_output(ngw_handle* h, int bits);
-int ngw_get_lidar(ngw_handle* h, void* out_host /* int32 or int16 [n_envs][len] */);
+int ngw_lidar_row_layout(ngw_handle* h, int32_t* row_bytes, int32_t* beam_bytes, int32_t* inv_offset, int32_t* inv_bytes);
+int ngw_get_lidar(ngw_handle* h, void* out_host /* [n_envs] rows of the current format */);
 int ngw_lidar_device_ptr(ngw_handle* h, void** out);
 
 /* AgentMap (observation_wrappers.py:83-129): ngw_agent_view() gathers, for every env, the (2*view_size+1)^2 window of the

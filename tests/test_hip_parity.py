@@ -561,7 +561,7 @@ def test_maps_beyond_the_lds_budget_step_and_reset_but_refuse_fused_rollouts():
     """Beyond ~46 x 46 a wave's 64 maps no longer fit in LDS.  The no-stage step kernel and the dedicated new-episode kernel do
     not keep them there: such a handle resets and steps (equal to the oracle, autoreset and prepared episodes included) and
     refuses the calls that would need the maps in LDS; configurations whose resets need the general kernel are refused at creation."""
-    if os.environ.get('NGW_LEAN') == '0' or os.environ.get('NGW_FAST_RESET') == '0' or os.environ.get('NGW_NOSTAGE') == '0':
+    if os.environ.get('NGW_FAST_RESET') == '0' or os.environ.get('NGW_NOSTAGE') == '0':
         pytest.skip('the A/B switches that route everything through kernels with the maps in LDS keep the 160 KiB limit')
     from gym_novel_gridworlds_amd import apply_novelty
     for S, nov in ((60, None), (52, ('additem', 'easy', 'arrow', '')), (64, ('firewall', 'medium', '', ''))):

@@ -187,6 +187,59 @@ def test_fused_lidar_epilogue_matches_oracle(cfg, n, steps, prefetch):
     v.step(an[0]); o.step(an[0]); check('unfused')
 
 
+def _widen(v, got):
+    """lidar_observation() of any row format as one integer [N, L] array."""
+    return v.lidar_widen(got) if isinstance(got, tuple) else got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cfg,beams', [('pogo10', 8), ('bowaxe16', 12), ('pogo13', 5), ('pogo13', 16), ('add32', 4), ('bow20', 6)])
+@pytest.mark.parametrize('dtype', [np.int32, np.int16, 'packed'])
+def test_lidar_row_formats_and_marches(cfg, beams, dtype, monkeypatch):
+    """Every row format (int32, int16, packed uint8 beams + int16 inventory) x both marches - the world-frame one (beam counts
+    that are a multiple of 4: wave-uniform ray offsets) and the per-lane table (any other count, or NGW_LIDAR_WORLD=0) - stand-alone
+    launch and fused epilogue (step, reset, rollout), against the oracle's lidar of the oracle's state."""
+    import gym_novel_gridworlds_amd as G
+    from gym_novel_gridworlds_amd.lidar import LidarConfig
+    from oracle.ngw_oracle import Oracle, lidar
+    spec = T.build_spec(cfg)
+    A, S, K = len(spec.actions_id), spec.map_size, len(spec.items_id)
+    lc = LidarConfig(spec, beams)
+    cc = lc.compile(spec)
+    n = 700
+    for world in (('1', '0') if beams % 4 == 0 else ('1',)):
+        monkeypatch.setenv('NGW_LIDAR_WORLD', world)
+        for fused in (False, True):
+            v = G.VecNovelGridworld(spec=spec, num_envs=n, seed=21, autoreset=True, horizon=13)
+            v.lidar_configure(lc, fused=fused, dtype=dtype)
+            o = Oracle(spec.compile(), n, seed=21, autoreset=True, horizon=13)
+
+            def check(where):
+                got = v.lidar_observation()
+                if dtype == 'packed':
+                    assert got[0].dtype == np.uint8 and got[1].dtype == np.int16 and got[0].shape == (n, beams * len(lc.lidar_items_id))
+                else:
+                    assert got.dtype == np.dtype(dtype)
+                exp = lidar(cc, S, K, o.st.map, o.st.loc, o.st.facing, o.st.inv)
+                bad = np.nonzero((_widen(v, got) != exp).any(1))[0]
+                assert bad.size == 0, (where, world, fused, bad[:4])
+                dev = v.lidar_observation(device=True)
+                dev = tuple(x.cpu().numpy() for x in dev) if isinstance(dev, tuple) else dev.cpu().numpy()
+                assert (_widen(v, dev) == exp).all(), (where, 'device view')
+
+            v.reset(); o.reset(); check('reset')
+            rs = np.random.RandomState(4)
+            for t in range(30):
+                a = rs.randint(0, A, size=n).astype(np.int32)
+                v.step(a); o.step(a)
+                if t % 3 == 0 or t > 24:
+                    check('step %d' % t)
+            v.rollout(17, action_seed=5, t0=2); o.rollout(17, 5, 2); check('rollout')
+            mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+            v.reset(mask); o.reset(mask); check('masked reset')
+            v.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('fused', [False, True])
 def test_int16_lidar_output(fused):
@@ -216,5 +269,7 @@ def test_int16_lidar_output(fused):
     big = v.lidar_observation()
     col = lc.num_beams * len(lc.lidar_items_id) + lc.inventory_order(spec).index('plank')
     assert (big[:, col] == 32767).all()
-    w = G.LidarInFront(G.VecNovelGridworld(spec=spec, num_envs=64, seed=1), num_beams=8, dtype=np.int16)
-    assert w.reset().dtype == np.int16
+    w = G.LidarInFront(G.VecNovelGridworld(spec=spec, num_envs=64, seed=1), num_beams=8)
+    assert w.reset().dtype == np.int16                                  # the batched wrapper's default row format
+    w = G.LidarInFront(G.VecNovelGridworld(spec=spec, num_envs=64, seed=1), num_beams=8, dtype=np.int32)
+    assert w.reset().dtype == np.int32

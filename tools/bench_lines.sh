@@ -1,6 +1,6 @@
 #!/bin/bash
 # bench lines of the named workloads (no CPU baseline, sides on): tools/bench_lines.sh C5 X1 ...
-OUT=gpurun_out/${ROUND:-r03}; mkdir -p $OUT
+OUT=gpurun_out/${ROUND:-r04}; mkdir -p $OUT
 for W in "$@"; do
   timeout -k 10 400 python bench.py --workload $W --no-cpu-baseline --steps 1000 > $OUT/bench_$W.log 2>&1
   python - <<PY

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The driver's own command, five times (box-to-box and run-to-run spread of a 20-step region is ~3 %), + the default 1000-step line
-OUT=gpurun_out/${ROUND:-r03}; mkdir -p $OUT
+OUT=gpurun_out/${ROUND:-r04}; mkdir -p $OUT
 for i in 1 2 3 4 5; do
   timeout -k 10 200 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-side > $OUT/driver_$i.log 2>&1
   python - <<PY

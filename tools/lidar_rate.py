@@ -1,57 +1,80 @@
-"""Time the LidarInFront observation kernel (device-resident, one launch per batched step) beside the step kernel."""
+"""Time the LidarInFront observation at C2 (65 536 envs, 10 x 10, 8 beams), device-resident: the plain step, the stand-alone lidar
+launch, and the step with the FUSED epilogue in every row format (int32 / int16 / packed) and with both marches (world-frame
+rays, per-lane table: NGW_LIDAR_WORLD=0), each as a 64-step hipGraph replayed 16 times (default prepared-episode cadence).
+    python tools/lidar_rate.py [n_envs] [workload: C2 | C3]"""
 import os
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from gym_novel_gridworlds_amd import VecNovelGridworld, _cabi  # noqa: E402
+from gym_novel_gridworlds_amd import VecNovelGridworld, _cabi, make_spec  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-v = VecNovelGridworld(num_envs=n, autoreset=True, horizon=100, reset_prefetch=0)
-v.reset()
-v.lidar_configure(num_beams=8)
-acts = torch.randint(0, 17, (64, n), dtype=torch.int32, device='cuda')
-torch.cuda.synchronize()
+wl = sys.argv[2] if len(sys.argv) > 2 else 'C2'
+spec = make_spec('NovelGridworld-Pogostick-v1', 10) if wl == 'C2' else make_spec('NovelGridworld-Bow-v1', 20)
+A = len(spec.actions_id)
 L = _cabi.lib()
+acts = None
+
+
+def replay(v, label, reps=16, G=64):
+    global acts
+    if acts is None:
+        acts = torch.randint(0, A, (G, n), dtype=torch.int32, device='cuda')
+        torch.cuda.synchronize()
+    v.reset()
+    v.graph_build(acts.data_ptr(), n, G)
+    v.graph_launch(4)
+    v.sync()
+    v.timing_begin()
+    t = time.perf_counter()
+    v.graph_launch(reps)
+    ms = v.timing_end()
+    dt = time.perf_counter() - t
+    assert v.error_flags() == 0
+    print('%-58s %6.2f us per batched step (device %6.2f) -> %5.2f G env-steps/s' % (label, dt / (reps * G) * 1e6, ms / (reps * G) * 1e3, n * reps * G / dt / 1e9), flush=True)
+    return ms / (reps * G) * 1e3
+
+
+def env():
+    return VecNovelGridworld(spec=spec, num_envs=n, autoreset=True, horizon=100)
+
+
+# clock warm-up on a scratch handle
+s = env(); s.reset()
+t_end = time.perf_counter() + 0.25
+while time.perf_counter() < t_end:
+    s.rollout(200, 1, 0); s.sync()
+s.close()
+
+v = env()
+replay(v, 'plain step')
+v.close()
+for world in ('1', '0'):
+    os.environ['NGW_LIDAR_WORLD'] = world
+    for dt_, name in ((np.int32, 'int32'), (np.int16, 'int16'), ('packed', 'packed u8+i16')):
+        v = env()
+        v.lidar_configure(num_beams=8, fused=True, dtype=dt_)
+        replay(v, 'fused lidar, %s rows (%d B/env), %s rays' % (name, v.lidar_row_bytes, 'world-frame' if world == '1' else 'per-lane table'))
+        if world == '1':
+            v.rollout(100, 1, 0); v.sync()
+            v.timing_begin(); v.rollout(1000, 1, 100); ms = v.timing_end()
+            print('    fused rollout, observation of the final state: %.2f us per batched step -> %.1f G env-steps/s' % (ms, n / ms / 1e6), flush=True)
+        v.close()
+os.environ['NGW_LIDAR_WORLD'] = '1'
+v = env()
+v.lidar_configure(num_beams=8, fused=False, dtype=np.int16)
+v.reset()
 for k in range(20):
-    v.step_device(acts[k].data_ptr()); L.ngw_lidar(v._h)
+    L.ngw_lidar(v._h)
 v.sync()
 K = 500
 v.timing_begin(); t = time.perf_counter()
 for k in range(K):
     L.ngw_lidar(v._h)
 ms = v.timing_end(); dt = time.perf_counter() - t
-print('lidar only: %.2f us/launch (device %.2f), %d x %d int32 out = %.0f B/env' % (dt / K * 1e6, ms / K * 1e3, n, v.lidar_len, v.lidar_len * 4))
-v.timing_begin(); t = time.perf_counter()
-for k in range(K):
-    v.step_device(acts[k % 64].data_ptr()); L.ngw_lidar(v._h)
-ms = v.timing_end(); dt = time.perf_counter() - t
-print('step + lidar: %.2f us per batched step (device %.2f) -> %.2f G env-steps/s' % (dt / K * 1e6, ms / K * 1e3, n * K / dt / 1e9))
-v.lidar_configure(num_beams=8, fused=True)
-for k in range(20):
-    v.step_device(acts[k].data_ptr())
-v.sync()
-v.timing_begin(); t = time.perf_counter()
-for k in range(K):
-    v.step_device(acts[k % 64].data_ptr())
-ms = v.timing_end(); dt = time.perf_counter() - t
-print('step with FUSED lidar epilogue: %.2f us per batched step (device %.2f) -> %.2f G env-steps/s' % (dt / K * 1e6, ms / K * 1e3, n * K / dt / 1e9))
-v.graph_build(acts.data_ptr(), n, 64); v.graph_launch(1); v.sync()
-v.timing_begin(); t = time.perf_counter(); v.graph_launch(8); ms = v.timing_end(); dt = time.perf_counter() - t
-print('  same, hipGraph replay: %.2f us per batched step -> %.2f G env-steps/s' % (dt / 512 * 1e6, n * 512 / dt / 1e9))
-v.rollout(50, 1, 0); v.sync()
-v.timing_begin(); t = time.perf_counter(); v.rollout(500, 1, 50); ms = v.timing_end(); dt = time.perf_counter() - t
-print('fused rollout with lidar every step: %.2f us per batched step -> %.2f G env-steps/s' % (dt / 500 * 1e6, n * 500 / dt / 1e9))
-import numpy as np
-v.lidar_configure(num_beams=8, fused=True, dtype=np.int16)
-for k in range(20):
-    v.step_device(acts[k].data_ptr())
-v.sync()
-v.graph_build(acts.data_ptr(), n, 64); v.graph_launch(1); v.sync()
-v.timing_begin(); t = time.perf_counter(); v.graph_launch(8); ms = v.timing_end(); dt = time.perf_counter() - t
-print('int16 observation rows, fused, hipGraph replay: %.2f us per batched step -> %.2f G env-steps/s' % (dt / 512 * 1e6, n * 512 / dt / 1e9))
-v.rollout(50, 1, 0); v.sync()
-v.timing_begin(); t = time.perf_counter(); v.rollout(500, 1, 50); ms = v.timing_end(); dt = time.perf_counter() - t
-print('int16, fused rollout with lidar every step: %.2f us per batched step -> %.2f G env-steps/s' % (dt / 500 * 1e6, n * 500 / dt / 1e9))
+print('stand-alone lidar launch (int16 rows): %.2f us per launch (device %.2f)' % (dt / K * 1e6, ms / K * 1e3))
+v.close()

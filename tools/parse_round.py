@@ -16,7 +16,7 @@ import re
 import statistics as st
 import sys
 
-ROUND = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+ROUND = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'gpurun_out', 'prof_' + ROUND)

@@ -3,7 +3,7 @@
 # measurements), the driver-style short run, the 2-rank rehearsal of the multi-GPU leg on one GPU, reset launch times and the
 # in-kernel timelines (the diagnostics build is REBUILT here first, so it can never be stale).  tools/write_perf_matrix.py <round>
 # turns the output into profiles/<round>_perf_matrix.md.
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 OUT=gpurun_out/matrix_$ROUND; rm -rf $OUT; mkdir -p $OUT
 make -C gym_novel_gridworlds_amd/csrc stamps > $OUT/stamps_build.log 2>&1 || { echo "stamps build failed"; tail -5 $OUT/stamps_build.log; }
 for W in C2 C3 C4 C5; do

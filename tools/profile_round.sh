@@ -8,7 +8,7 @@
 #   3. SQ counters (wave cycles, waiting, issue mix) of the C2 step kernel and of the C2 fused rollout
 #   4. FETCH_SIZE / WRITE_SIZE of the new-episode kernel (explicit resets of every env, prepared episodes off): C3, C5, X1
 # Outputs land in gpurun_out/prof_<round>/ ; tools/parse_round.py <round> turns them into profiles/<round>_*.md + profiles/pmc_traffic.json.
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 OUT=gpurun_out/prof_$ROUND
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

@@ -15,7 +15,7 @@ for wl in (sys.argv[1:] or ['C2', 'C5']):
         apply_novelty(spec, *nov)
     v = VecNovelGridworld(spec=spec, num_envs=n, seed=1, reset_prefetch=0)
     grid = (n + 63) // 64
-    stamps = torch.zeros((grid, 16), dtype=torch.int64, device='cuda')
+    stamps = torch.zeros((grid, 32), dtype=torch.int64, device='cuda')
     _cabi.check(L.ngw_debug_set_stamps(v._h, C.c_void_p(stamps.data_ptr())))
     _cabi.check(L.ngw_reset(v._h, None)); v.sync()
     _cabi.check(L.ngw_reset(v._h, None)); v.sync()

@@ -36,11 +36,11 @@ def main():
         v = VecNovelGridworld(spec=spec, num_envs=n, device=0, seed=0, autoreset=True, horizon=100, reset_prefetch=(1 << 20) if stagger else 0)   # (rows prepared by reset(); no refill launch among the sampled steps)
         v.reset()
         if os.environ.get('NGW_LIDAR') == '1':          # the fused LidarInFront epilogue sits between 'outputs begin' and 'outputs issued'
-            v.lidar_configure(num_beams=8, fused=True)
+            v.lidar_configure(num_beams=8, fused=True, dtype={'int32': np.int32, 'int16': np.int16}.get(os.environ.get('NGW_LIDAR_DTYPE', 'int16'), 'packed'))
         if stagger:
             v.set_state(0, step_count=(np.arange(n) * 7919 % 100).astype(np.int32))
         grid = (n + 63) // 64
-        stamps = torch.zeros((grid, 16), dtype=torch.int64, device='cuda')
+        stamps = torch.zeros((grid, 32), dtype=torch.int64, device='cuda')
         acts = torch.randint(0, A, (40, n), dtype=torch.int32, device='cuda')
         torch.cuda.synchronize()
         _cabi.check(L.ngw_debug_set_stamps(v._h, C.c_void_p(stamps.data_ptr())))
@@ -61,7 +61,7 @@ def main():
             v.graph_launch(1)
             ms = v.timing_end()
         st = stamps.cpu().numpy()
-        rt, cy = st[:, :8].astype(np.float64), st[:, 8:].astype(np.float64)
+        rt, cy, sub = st[:, :8].astype(np.float64), st[:, 8:16].astype(np.float64), st[:, 16:].astype(np.float64)
         t0 = rt[:, 0].min()
         names = LEAN if rt[:, 7].max() > 0 else NAMES           # the lean kernel fills all eight slots
         print('== %s%s: %s; %d waves; event time per launch %.2f us' % (wl, ' (staggered episode ends)' if stagger else '', desc, grid, ms / 40 * 1e3))
@@ -77,6 +77,13 @@ def main():
         if stagger and last >= 6:                        # the cold path sits between 'outputs begin' and 'outputs issued'
             d = cy[:, 6] - cy[:, 5]
             print('  outputs begin -> outputs issued, percentiles 10/25/50/75/90/99: ' + ' '.join('%.0f' % np.percentile(d, q) for q in (10, 25, 50, 75, 90, 99)))
+        if sub.max() > 0:                                # stamps inside the LidarInFront row builder (STAMP_SUB in lidar_rows)
+            sn = ['epilogue entered', 'tile zeroed', 'march done', 'hits written', 'inventory written', 'rows stored (issued)']
+            have = [i for i in range(len(sn)) if sub[:, i].max() > 0]
+            print('  inside the lidar epilogue, shader cycles (median / p90):')
+            for a_, b_ in zip(have[:-1], have[1:]):
+                d = sub[:, b_] - sub[:, a_]
+                print('    %-20s -> %-22s %8.0f %8.0f' % (sn[a_], sn[b_], np.median(d), np.percentile(d, 90)))
         life = cy[:, last] - cy[:, 0]
         print('  wave life %.0f cycles median; clock ~%.2f GHz' % (np.median(life), np.median(life / np.maximum((rt[:, last] - rt[:, 0]) * 10.0, 1.0))))
         _cabi.check(L.ngw_debug_set_stamps(v._h, None))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # In-kernel timelines (diagnostics build, always rebuilt here so it can never be stale): tools/stamps.sh <reset workloads> -- <step workloads>
-OUT=gpurun_out/${ROUND:-r03}; mkdir -p $OUT
+OUT=gpurun_out/${ROUND:-r04}; mkdir -p $OUT
 make -C gym_novel_gridworlds_amd/csrc stamps > $OUT/stamps_build.log 2>&1 || { tail -20 $OUT/stamps_build.log; exit 1; }
 export NGW_LIB=$PWD/gym_novel_gridworlds_amd/libngw_hip_stamps.so
 R=(); T=(); cur=R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Step-kernel tuning call: stamps timeline + C2/C4 bench (1000-step graph and the driver's 20-step eager form), optional env A/B
-OUT=gpurun_out/${ROUND:-r03}; mkdir -p $OUT
+OUT=gpurun_out/${ROUND:-r04}; mkdir -p $OUT
 bash tools/stamps.sh -- C2 2>&1 | tail -22
 run() { # label, env...
   local L=$1; shift

@@ -2,7 +2,7 @@
 """tools/write_perf_matrix.py <round>: gpurun_out/matrix_<round>/ (tools/perf_matrix.sh <round>) -> profiles/<round>_perf_matrix.md.
 A log that holds a Python traceback is an ERROR here (exit 1): a matrix with a crash where a measurement should be is not evidence."""
 import json, os, sys
-ROUND = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+ROUND = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = os.path.join(ROOT, 'gpurun_out', 'matrix_' + ROUND) + '/'
 out = ['# Performance matrix of %s (one MI355X; `tools/perf_matrix.sh %s`)\n' % (ROUND, ROUND),
