@@ -171,6 +171,8 @@ def main():
     ap.add_argument('--clock-warm-ms', type=float, default=250.0,
                     help='keep the GPU busy this long on a SCRATCH handle before anything is measured (a fresh process finds the device in a '
                          'low power state, and 5 warm-up steps are 25 us); 0 = off')
+    ap.add_argument('--lidar', default='', choices=['', 'int32', 'int16', 'packed'],
+                    help='run the MAIN timed region with the fused LidarInFront observation in this row format (profiling runs; the default line reports it in `lidar`)')
     ap.add_argument('--repeats', type=int, default=5, help='run the K-step region this many more times after the contract region (median / spread in `repeats`)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stagger', action='store_true', help='skip the staggered-episode-ends side measurement')
@@ -212,6 +214,8 @@ def main():
     sv = ShardedVecNovelGridworld(spec=spec, global_num_envs=n * world, seed=0, autoreset=True, horizon=HORIZON,
                                   device=local_rank, reset_prefetch=prefetch)
     v = sv.local                                          # this rank's envs [rank * n, (rank + 1) * n)
+    if args.lidar:
+        v.lidar_configure(num_beams=8, fused=True, dtype={'int32': np.int32, 'int16': np.int16}.get(args.lidar, 'packed'))
     steps, warmup = args.steps, args.warmup
 
     def start_episodes():
@@ -591,6 +595,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8/int32', 'data': 'synthetic',
             'config': {'workload': desc, 'name': args.workload, 'envs_per_gpu': n, 'global_envs': n * world,
                        'map_size': S, 'n_items': K, 'n_actions': A, 'horizon': HORIZON, 'autoreset': 'same-step',
+                       'fused_lidar': ({'format': args.lidar, 'row_bytes': v.lidar_row_bytes, 'row_len': v.lidar_len} if args.lidar else None),
                        'reset_prefetch': v.reset_prefetch,
                        'mode': ('one launch per batched step (%s), actions in HBM' % ('hipGraph replay' if use_graph else 'eager')) if args.mode == 'step'
                                else 'fused rollout: all steps in one launch, actions generated in-kernel',

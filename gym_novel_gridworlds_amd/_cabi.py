@@ -24,7 +24,8 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_get_agent_view', 'ngw_agent_view_device_ptr', 'ngw_set_reset_prefetch', 'ngw_step_host', 'ngw_lidar_set_output', 'ngw_rollout_actions',
            'ngw_pack_layout', 'ngw_pack_obs', 'ngw_unpack_obs', 'ngw_rollout_outputs', 'ngw_episode_stats', 'ngw_host_step_layout', 'ngw_step_device_many',
            'ngw_set_reset_prefetch_depth', 'ngw_get_reset_prefetch_depth', 'ngw_stream_order', 'ngw_host_mirror_invalidate', 'ngw_reset_host',
-           'ngw_lidar_row_layout', 'ngw_step_kernel_info']
+           'ngw_lidar_row_layout', 'ngw_step_kernel_info', 'ngw_set_terminal_capture', 'ngw_get_terminal_obs', 'ngw_terminal_device_ptrs',
+           'ngw_host_step_layout_packed', 'ngw_step_host_packed']
 
 _lib = None
 
@@ -119,6 +120,13 @@ def lib():
     L.ngw_lidar_fuse.argtypes = [vp, C.c_int]
     if hasattr(L, 'ngw_lidar_set_output'):
         L.ngw_lidar_set_output.argtypes = [vp, C.c_int]
+    if hasattr(L, 'ngw_step_host_packed'):
+        L.ngw_host_step_layout_packed.argtypes = [vp, C.POINTER(u64)]
+        L.ngw_step_host_packed.argtypes = [vp, vp, vp, C.c_int]
+    if hasattr(L, 'ngw_set_terminal_capture'):
+        L.ngw_set_terminal_capture.argtypes = [vp, C.c_int]
+        L.ngw_get_terminal_obs.argtypes = [vp, vp, vp, vp, vp]
+        L.ngw_terminal_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     if hasattr(L, 'ngw_step_kernel_info'):
         L.ngw_step_kernel_info.argtypes = [vp, C.POINTER(C.c_int32)]
     if hasattr(L, 'ngw_lidar_row_layout'):

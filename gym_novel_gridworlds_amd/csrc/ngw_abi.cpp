@@ -68,6 +68,9 @@ struct ngw_handle {
     uint8_t* mask_pin = nullptr; uint8_t* mask_pin_dev = nullptr;   // ngw_reset's mask: two page-locked halves the kernel reads in place
     hipEvent_t mask_ev[2] = {nullptr, nullptr};
     int mask_next = 0;
+    uint8_t* act_pin_dev = nullptr;            // ... the same buffer as the GPU addresses it (ngw_step_host_packed: the kernel reads the actions in place)
+    bool launch_act_u8 = false;                // the launch being issued reads one byte per env from `actions`
+    uint8_t* wire_stage = nullptr;             // ngw_step_host_packed: device staging of the dense sections
     uint8_t* act_pin = nullptr;                // ngw_step's actions: two page-locked halves feeding the asynchronous copy
     hipEvent_t act_ev[2] = {nullptr, nullptr};
     int act_next = 0;
@@ -100,6 +103,8 @@ struct ngw_handle {
     bool adapt_error = false;             // growing the prepared-episode depth failed (out of memory): the depth stays, the next refill notes it once
     int prefetch_user = 0;                // the caller chose the cadence (ngw_set_reset_prefetch): ngw_set_autoreset leaves it alone
     int depth = 1, depth_user = 0;        // prepared episodes per env (power of two); depth_user: chosen through ngw_set_reset_prefetch_depth
+    NgwTerm term = {};                    // terminal observations (ngw_set_terminal_capture); all null = off
+    bool term_on = false;
     int32_t* row_reward = nullptr;        // fused rollouts: the caller's output rows (ngw_rollout_outputs)
     uint8_t* row_done = nullptr;
     int64_t row_stride = 0;
@@ -555,14 +560,14 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     a.action_seed = action_seed;
     a.t0 = t0;
     a.seq = h->launch_seq;
-    a.action0 = h->launch_action0; a.use_action0 = h->launch_use_action0 ? 1 : 0;
+    a.action0 = h->launch_action0; a.use_action0 = h->launch_use_action0 ? 1 : (h->launch_act_u8 ? 2 : 0);
     const unsigned grid = (unsigned)(h->n_pad / NGW_EPB);
     bool taken = false;
     if (mode == NGW_MODE_RESET) { if (int rc = launch_reset_fast(h, NGW_MODE_RESET, mask_dev, &taken)) return rc; }
     if (!taken && mode == NGW_MODE_STEP && h->nostage && !h->lidar_fused) {   // maps read in place: no-stage step kernel
         NgwLaunch q = h->ns_proto;
         q.b = h->b; q.mode = mode; q.n_steps = 1; q.actions = actions_dev; q.autoreset = h->autoreset; q.horizon = h->horizon; q.stamps = h->proto.stamps;
-        q.seq = h->launch_seq; q.action0 = h->launch_action0; q.use_action0 = h->launch_use_action0 ? 1 : 0;
+        q.seq = h->launch_seq; q.action0 = h->launch_action0; q.use_action0 = h->launch_use_action0 ? 1 : (h->launch_act_u8 ? 2 : 0);
         HIP_TRY(ngw_launch(h->dspec, &q, h->map_mode, 8 | (h->ext ? 2 : 0), grid, h->ns_lds, h->stream));
         taken = true;
     }
@@ -585,6 +590,9 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
 // episodes on, an env's reset inside the launch copies its prepared row - but only the first one, the shadow rows are
 // re-prepared between launches.  Same action stream (keyed by the absolute step), same results as one launch.
 int rollout_chunks(ngw_handle* h, int mode, int32_t n_steps, const int32_t* actions_dev, uint64_t action_seed, int64_t t0, int64_t step_stride) {
+    if (h->term_on)
+        return fail(NGW_E_INVALID_ARG, "fused rollouts keep no terminal observations (the state lives on chip between steps): switch "
+                                       "ngw_set_terminal_capture off, or step with ngw_step / ngw_step_device");
     // a prepared row serves an env's FIRST reset of a launch, and under a horizon H an env resets at most once per H steps
     // (plus the rare early `done`): H-step launches (capped) keep the per-launch staging cost low; no horizon: 4 cadences
     int32_t chunk = n_steps;
@@ -1132,6 +1140,54 @@ int ngw_rollout_actions(ngw_handle* h, const int32_t* actions_dev, int64_t step_
     return rollout_chunks(h, NGW_MODE_ROLLOUT_ACT, n_steps, actions_dev, 0, 0, step_stride);
 }
 
+int ngw_set_terminal_capture(ngw_handle* h, int enable) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (enable && !h->term.map) {
+        const size_t np = (size_t)h->n_pad, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
+        NgwTerm t = {};
+        int rc = dev_alloc(h, &t.map, np * S2);
+        if (!rc) rc = dev_alloc(h, &t.loc, np * 2);
+        if (!rc) rc = dev_alloc(h, &t.facing, np);
+        if (!rc) rc = dev_alloc(h, &t.inv, np * K);
+        if (rc) {
+            void* const part[4] = {t.map, t.loc, t.facing, t.inv};
+            for (void* q : part) if (q) dev_free(h, q);
+            return rc;
+        }
+        h->term = t;
+    }
+    const NgwTerm on_device = enable ? h->term : NgwTerm{};          // null pointers switch the capture off; the buffers stay for the next switch-on
+    HIP_TRY(hipMemcpyAsync(&h->dspec->term, &on_device, sizeof(NgwTerm), hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->term_on = enable != 0;
+    return NGW_OK;
+}
+
+int ngw_get_terminal_obs(ngw_handle* h, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (!h->term.map) return fail(NGW_E_INVALID_ARG, "ngw_get_terminal_obs before ngw_set_terminal_capture(h, 1)");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)h->n, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
+    D2H(map, h->term.map, n * S2);
+    D2H(loc, h->term.loc, n * 2 * sizeof(int32_t));
+    D2H(facing, h->term.facing, n * sizeof(int32_t));
+    D2H(inv, h->term.inv, n * K * sizeof(int32_t));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NGW_OK;
+}
+
+int ngw_terminal_device_ptrs(ngw_handle* h, void** map, void** loc, void** facing, void** inv) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (!h->term.map) return fail(NGW_E_INVALID_ARG, "ngw_terminal_device_ptrs before ngw_set_terminal_capture(h, 1)");
+    if (map) *map = h->term.map;
+    if (loc) *loc = h->term.loc;
+    if (facing) *facing = h->term.facing;
+    if (inv) *inv = h->term.inv;
+    return NGW_OK;
+}
+
 int ngw_rollout_outputs(ngw_handle* h, int32_t* reward_rows_dev, uint8_t* done_rows_dev, int64_t row_stride, int accumulate) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     if ((reward_rows_dev || done_rows_dev) && row_stride < h->n) return fail(NGW_E_INVALID_ARG, "row_stride %lld is smaller than n_envs", (long long)row_stride);
@@ -1430,6 +1486,116 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
     return NGW_OK;
 }
 
+/* ---- the host step in its narrow wire format (big batches)
+ * Block sections (index: 0 map int8 [n][S*S], 1 inventory int32 [n][K], 2 pose uint32 [n] = r | c << 8 | facing << 16 | selected << 24,
+ * 3 reward int16 [n], 4 done uint8 [n], 5 info uint32 [n] (NGW_INFO_*), 6 error flags uint32), each padded to 256 bytes; offsets7[7] =
+ * the block's size.  Sections 0-1 are refreshed by deltas (only the 16-byte pieces a step changed cross PCIe), 2-6 are dense and
+ * come back with ONE copy: 11 B per env against the 26 B of the int32 SoA arrays of ngw_step_host. */
+namespace {
+void host_step_layout_packed(const ngw_handle* h, uint64_t off[8]) {
+    const uint64_t n = (uint64_t)h->n, S2 = (uint64_t)h->proto.S2, K = (uint64_t)h->proto.K;
+    const uint64_t bytes[7] = {n * S2, n * K * 4, n * 4, n * 2, n, n * 4, 4};
+    uint64_t o = 0;
+    for (int i = 0; i < 7; i++) { off[i] = o; o += (bytes[i] + 255) & ~(uint64_t)255; }
+    off[7] = o;
+}
+}  // namespace
+
+int ngw_host_step_layout_packed(ngw_handle* h, uint64_t* offsets8) {
+    if (!h || !offsets8) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    host_step_layout_packed(h, offsets8);
+    return NGW_OK;
+}
+
+int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block, int with_map) {
+    if (!h || !actions_host || !block) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    const ngw_spec& sp = h->spec;
+    {   // rewards travel as int16 here
+        const int rw[5] = {sp.reward_step, sp.reward_done, sp.fire_reward, sp.place_reward, sp.ext_reward};
+        for (int v : rw) if (v < -32768 || v > 32767) return fail(NGW_E_INVALID_ARG, "a reward of %d does not fit the narrow wire format (int16): use ngw_step_host", v);
+        for (int i = 0; i < sp.n_items; i++) if (sp.break_reward[i] < -32768 || sp.break_reward[i] > 32767) return fail(NGW_E_INVALID_ARG, "break_reward does not fit int16: use ngw_step_host");
+    }
+    const size_t n = (size_t)h->n, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
+    if (h->proto.S > 255) return fail(NGW_E_INVALID_ARG, "map_size beyond the pose bytes");
+    HIP_TRY(hipSetDevice(h->device));
+    // ---- actions: validated and narrowed to one byte per env in ONE pass, into a page-locked, GPU-addressable buffer (two halves, an
+    //      event per half as in ngw_step) that the step kernel reads in place: no copy call for 64 KB.  (The buffer is 4 n bytes long:
+    //      the kernel's int32 load of the same lanes must stay in bounds.)
+    const int A = sp.n_actions;
+    const size_t cap = (n * sizeof(int32_t) + 255) & ~(size_t)255;
+    if (!h->act_pin) {
+        h->act_pin = static_cast<uint8_t*>(ngw_host_alloc(2 * cap));
+        if (!h->act_pin) return NGW_E_HIP;
+        HIP_TRY(hipEventCreateWithFlags(&h->act_ev[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->act_ev[1], hipEventDisableTiming));
+    }
+    if (!h->act_pin_dev) {
+        void* d = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&d, h->act_pin, 0));
+        h->act_pin_dev = static_cast<uint8_t*>(d);
+    }
+    const int slot = h->act_next; h->act_next ^= 1;
+    HIP_TRY(hipEventSynchronize(h->act_ev[slot]));
+    uint8_t* const a8 = h->act_pin + (size_t)slot * cap;
+    uint32_t bad = 0;
+    for (size_t i = 0; i < n; i++) {                                  // (branch-free: vectorises)
+        const uint32_t a = (uint32_t)actions_host[i];
+        bad |= a >= (uint32_t)A ? 1u : 0u;
+        a8[i] = (uint8_t)a;
+    }
+    if (bad) {
+        h->act_next ^= 1;
+        for (size_t i = 0; i < n; i++)
+            if (actions_host[i] < 0 || actions_host[i] >= A) return fail(NGW_E_INVALID_ACTION, "%d is not in list", (int)actions_host[i]);   // pogostick_v1_env.py:236
+    }
+    uint64_t off[8];
+    host_step_layout_packed(h, off);
+    if (!h->wire_stage) { if (int rc = dev_alloc(h, &h->wire_stage, (size_t)(off[7] - off[2]))) return rc; }
+    const bool delta = h->host_delta && h->mirror_valid && h->mirror_block == block;
+    h->launch_use_action0 = false; h->launch_act_u8 = true;
+    const int lrc = launch(h, NGW_MODE_STEP, 1, reinterpret_cast<const int32_t*>(h->act_pin_dev + (size_t)slot * cap), nullptr, 0, 0);
+    h->launch_act_u8 = false;
+    if (lrc) return lrc;
+    HIP_TRY(hipEventRecord(h->act_ev[slot], h->stream));
+    uint8_t* const blk = static_cast<uint8_t*>(block);
+    const void* const srcs[2] = {h->b.map, h->b.inv};
+    const uint64_t nb[2] = {n * S2, n * K * 4};
+    if (delta) {
+        NgwDiff d = {};
+        int k = 0;
+        for (int r = with_map ? 0 : 1; r < 2; r++, k++) {
+            d.cur[k] = static_cast<const uint8_t*>(srcs[r]); d.shadow[k] = h->shadow[r]; d.host[k] = h->mirror_dev + off[r]; d.nbytes[k] = nb[r];
+        }
+        d.n_regions = k;
+        HIP_TRY(ngw_diff_launch(&d, h->stream));
+    } else {
+        for (int r = 0; r < 2; r++) HIP_TRY(hipMemcpyAsync(blk + off[r], srcs[r], (size_t)nb[r], hipMemcpyDefault, h->stream));
+        if (h->host_delta) {                                          // (re-)seed the shadows: the block mirrors the state from here on
+            void* dev = nullptr;
+            bool ok = hipHostGetDevicePointer(&dev, block, 0) == hipSuccess && dev;
+            if (!ok) (void)hipGetLastError();                         // (a block that is not mapped into the GPU's address space: full copies)
+            for (int r = 0; r < 2 && ok; r++) {
+                if (!h->shadow[r]) ok = dev_alloc(h, &h->shadow[r], (size_t)((nb[r] + 255) & ~(uint64_t)255)) == NGW_OK;
+                if (ok) HIP_TRY(hipMemcpyAsync(h->shadow[r], srcs[r], (size_t)nb[r], hipMemcpyDeviceToDevice, h->stream));
+            }
+            h->mirror_block = ok ? block : nullptr; h->mirror_dev = static_cast<uint8_t*>(dev);
+        }
+    }
+    NgwWire w = {};
+    w.loc = h->b.loc; w.facing = h->b.facing; w.selected = h->b.selected; w.reward = h->b.reward; w.done = h->b.done; w.info = h->b.info; w.flags = h->b.flags;
+    uint8_t* const st = h->wire_stage - off[2];                       // (staging holds sections 2 .. 6 at their block offsets)
+    w.pose = reinterpret_cast<uint32_t*>(st + off[2]); w.reward16 = reinterpret_cast<int16_t*>(st + off[3]); w.done8 = st + off[4];
+    w.info32 = reinterpret_cast<uint32_t*>(st + off[5]); w.flags_out = reinterpret_cast<uint32_t*>(st + off[6]);
+    w.n = (int64_t)n;
+    HIP_TRY(ngw_wire_launch(&w, h->stream));
+    HIP_TRY(hipMemcpyAsync(blk + off[2], h->wire_stage, (size_t)(off[7] - off[2]), hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    // (a delta step that skipped the map leaves the map's shadow describing what the block holds: the next step that wants the map
+    //  brings every change since across)
+    h->mirror_valid = h->host_delta && h->mirror_block == block;
+    return NGW_OK;
+}
+
 /* Payload of the multi-GPU observation gather: the seven SoA arrays back to back, each section padded to 16 bytes. */
 namespace {
 struct PackSection { const void* dev; uint64_t bytes; };
@@ -1675,6 +1841,14 @@ int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg) {
                         if (cfg->dr[f][b][k] != cfg->dr[1][(w + B / 2) % B][k] || cfg->dc[f][b][k] != cfg->dc[1][(w + B / 2) % B][k]) { world = 0; break; }
                 }
             if (const char* v = getenv("NGW_LIDAR_WORLD")) if (atoi(v) == 0) world = 0;     // A/B: the per-lane table march
+        }
+        if (world && B == 8 && S == NGW_LIDAR_CONST_S) {               // the reference's default rays on its default map: compile-time offsets?
+            bool same = R == 11;                                       // int(sqrt(2 * (S - 2)^2)) for S = 10: what the kernels instantiate
+            for (int w = 0; w < 8 && same; w++)
+                for (int k = 1; k <= R; k++)
+                    if (hd.woff[w][k - 1] != ngw_lidar8_dr(w, k) * S + ngw_lidar8_dc(w, k)) { same = false; break; }
+            if (same) world = 2;
+            if (const char* v = getenv("NGW_LIDAR_WORLD")) if (atoi(v) == 1) world = 1;   // A/B: the table-driven world march
         }
         hd.world = world;
         memcpy(hd.chan_of_item, cfg->chan_of_item, NGW_MAX_ITEMS);

@@ -48,7 +48,8 @@ struct NgwLaunch {
     int32_t* lout;               /* [n_pad][lidar_len] */
     int32_t lidar_len, l_beams, l_range, l_chan, l_inv;
     int32_t l_fmt;               /* row format NGW_LFMT_*: int32 / int16 (values saturate at 32767) / packed (uint8 beam entries + int16 inventory tail) */
-    int32_t l_world;             /* 1: the ray table is one world-frame table rotated by the facing (NgwLidarDev::woff): wave-uniform ray offsets */
+    int32_t l_world;             /* 1: the ray table is one world-frame table rotated by the facing (NgwLidarDev::woff): wave-uniform ray offsets;
+                                  * 2: and it is the reference's default 8-beam table on a NGW_LIDAR_CONST_S map: compile-time offsets */
     int32_t l_rb, l_invoff;      /* bytes per observation row in this format; byte offset of its inventory tail */
     uint32_t off_litem;          /* LDS dword offset of the two item tables (chan_of_item | inv_item: 12 dwords) */
     uint32_t off_ltab, off_ltile; /* ... of the per-lane ray table (8 KiB; only when !l_world) and of the observation tile (64 rows, l_rb bytes each) */
@@ -62,7 +63,7 @@ struct NgwLaunch {
     uint32_t seq;                /* single-wavefront handles: the step refreshes the host mirror (NgwMirror) and then writes this number to
                                   * flags_host[NGW_SEQ_WORD] (0 = neither) */
     int32_t action0;             /* one-env handles: the step's action travels in the argument block ... */
-    int32_t use_action0;         /* ... when this is set (`actions` still points at valid device memory) */
+    int32_t use_action0;         /* ... when this is 1 (`actions` still points at valid device memory); 2: `actions` holds one BYTE per env (ngw_step_host_packed) */
     /* fused rollouts: per-step output rows and per-env episode accumulators (ngw_rollout_outputs), any of them nullptr */
     int32_t* row_reward;         /* [n_steps][row_stride]: reward of step t of env e at [t * row_stride + e] */
     uint8_t* row_done;           /* [n_steps][row_stride]: 1 where the step ended an episode (done, or the horizon under autoreset) */
@@ -162,6 +163,17 @@ struct NgwMirror {
     int32_t* reward; uint8_t* done; uint32_t* info;
 };
 
+/* Terminal observations under same-step autoreset (ngw_set_terminal_capture): before a resetting env's rows are overwritten by its
+ * next episode, the step kernel's cold path copies them here - map row, inventory row, pose of the state the episode ENDED in
+ * (reference loops look at that observation: tests/test.py:30-41, enjoy.py:107-116).  Row e is valid for the envs whose `done` the
+ * same launch set; all null = off (one scalar load and a uniform branch on the cold path, nothing on the hot path). */
+struct NgwTerm {
+    int8_t* map;          /* [n_pad][S*S] */
+    int32_t* loc;         /* [n_pad][2]   */
+    int32_t* facing;      /* [n_pad]      */
+    int32_t* inv;         /* [n_pad][K]   */
+};
+
 struct NgwDevSpec {
     NgwStepU u;
     uint8_t place_seq[NGW_MAX_PLACE];   /* item id of the n-th placement of a reset (items_quantity flattened in order): the reset paths copy it to LDS */
@@ -174,6 +186,7 @@ struct NgwDevSpec {
     NgwNx nx;
     NgwResetU ru;
     NgwMirror mir;
+    NgwTerm term;
     double pctq[NGW_MAX_PASSES][64];   /* per reset pass: pct / 100.0 for pct in [pct_lo, pct_hi) as the host's IEEE double */
 };
 
@@ -220,6 +233,20 @@ hipError_t ngw_reset_fast_launch(const NgwDevSpec* dspec, const struct NgwResetF
 enum { NGW_LFMT_I32 = 0,      /* int32 [B * NC + NI] */
        NGW_LFMT_I16 = 1,      /* int16 [B * NC + NI], values saturate at 32767 */
        NGW_LFMT_PACKED = 2 }; /* uint8 [B * NC] beam entries (a range is <= 64), padded to an even count, then int16 [NI] inventory (saturating) */
+
+/* The reference's DEFAULT LidarInFront rays - 8 beams (observation_wrappers.py:16), i.e. the four axes and the four diagonals, the
+ * diagonals advancing by round(0.71 k) cells (np.round(np.cos(pi / 4), 2) = 0.71, :49-55) - as compile-time constants: world ray w
+ * (0 .. 7 = +r, +r+c, +c, -r+c, -r, -r-c, -c, +r-c), range k >= 1.  With the map size a compile-time constant too, every cell
+ * offset of the march is an instruction immediate.  ngw_lidar_configure compares this table with the host's entry by entry and only
+ * an exact match (NgwLaunch::l_world == 2) selects the kernels' constant-offset march. */
+#define NGW_LIDAR_CONST_S 10                 /* the map size the constant march is instantiated for: the reference's default */
+static constexpr int ngw_lidar8_diag(int k) { return (71 * k + 50) / 100; }        /* round(0.71 k): no tie for k < 50 */
+static constexpr int ngw_lidar8_dr(int w, int k) {
+    return w == 0 ? k : (w == 4 ? -k : ((w == 1 || w == 7) ? ngw_lidar8_diag(k) : ((w == 3 || w == 5) ? -ngw_lidar8_diag(k) : 0)));
+}
+static constexpr int ngw_lidar8_dc(int w, int k) {
+    return w == 2 ? k : (w == 6 ? -k : ((w == 1 || w == 3) ? ngw_lidar8_diag(k) : ((w == 5 || w == 7) ? -ngw_lidar8_diag(k) : 0)));
+}
 
 /* Device-side lidar tables, built by ngw_lidar_configure from ngw_lidar_cfg: flat cell offsets dr * S + dc. */
 struct NgwLidarDev {
@@ -269,6 +296,19 @@ struct NgwDiff {
 extern "C"
 #endif
 hipError_t ngw_diff_launch(const struct NgwDiff* p, hipStream_t stream);
+/* Narrow wire format of the host step (ngw_step_host_packed): per env the pose as four bytes (r, c, facing, selected), the reward as
+ * int16, done as a byte and the packed info word, written as four dense arrays into one staging payload that a single copy brings
+ * across PCIe (11 B per env instead of the 26 B of the int32 SoA arrays). */
+struct NgwWire {
+    const int32_t* loc; const int32_t* facing; const uint8_t* selected; const int32_t* reward; const uint8_t* done; const uint32_t* info;
+    const uint32_t* flags;
+    uint32_t* pose; int16_t* reward16; uint8_t* done8; uint32_t* info32; uint32_t* flags_out;
+    int64_t n;
+};
+#ifdef __cplusplus
+extern "C"
+#endif
+hipError_t ngw_wire_launch(const struct NgwWire* p, hipStream_t stream);
 #ifdef __cplusplus
 extern "C"
 #endif

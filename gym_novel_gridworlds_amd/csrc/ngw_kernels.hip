@@ -733,8 +733,9 @@ __device__ __forceinline__ bool lidar_round(const uint32_t (&word)[8], int k0, u
 // beam entry is a range <= 64, so ONE byte store at the entry's place serves every row format (the tile was zeroed, rows are
 // little-endian; `sh` = log2 of the entry size), and a ray that reports nothing stores into the lane's dump byte behind the tile -
 // no branch per ray.
-__device__ __forceinline__ void lidar_hits(const uint32_t (&first)[8], const int (&kc)[8], const int (&beam)[8], int nb, int R, int NC, int sh,
-                                           const LDS_AS uint8_t* chan_of_item, LDS_AS uint8_t* rowp, int dump) {
+__device__ __forceinline__ void lidar_hits(const uint32_t (&first)[8], const int (&kc)[8], int pos0 /* row entry of ray slot 0's beam: beam * NC */,
+                                           int nb, int R, int NC, int wrap /* num_beams * NC */, int sh, const LDS_AS uint8_t* chan_of_item,
+                                           LDS_AS uint8_t* rowp, int dump) {
     int hk[8], ch[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -744,8 +745,79 @@ __device__ __forceinline__ void lidar_hits(const uint32_t (&first)[8], const int
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
+        int p = pos0 + i * NC;                                                     // consecutive ray slots are consecutive beams (mod num_beams)
+        p -= p >= wrap ? wrap : 0;
         const bool hit = i < nb && ch[i] != 0 && hk[i] <= R;
-        rowp[hit ? (beam[i] * NC + ch[i] - 1) << sh : dump] = (uint8_t)hk[i];
+        rowp[hit ? (p + ch[i] - 1) << sh : dump] = (uint8_t)hk[i];
+    }
+}
+
+// The constant-offset march (NgwLaunch::l_world == 2): the reference's default 8 rays on an S x S map with S a compile-time
+// constant.  What bounds a march is the LDS itself: every ray cell is a byte read at a per-lane address (the agents stand
+// anywhere, so the 64 addresses of a read fall on the banks at random: ~3.5-way conflicts), and the four waves of a CU share one LDS
+// pipe - stamped: ~25 cycles per read instruction, 104 of them in the table-driven marches = 2 600 of their 4 100 cycles, whatever
+// the arithmetic around them looked like.  So this form issues FEWER reads:
+//   * a diagonal ray advances by round(0.71 k) cells: ranges 1..11 visit the 8 diagonal cells d = 1..8, some twice; the first block
+//     is the same either way, so rays are walked in GEOMETRIC steps d = 1..8 (8 cells per ray, not 11) and the range reported is the
+//     first k that reaches d (a 4-bit-per-entry constant: 1 3 4 5 7 8 10 11); an axis ray cannot run further than S - 2 = 8 cells;
+//   * every address is the agent's cell + an instruction immediate: no address arithmetic, no offset table, no loop.
+// 64 byte reads per lane instead of 104.  (Tried: one 8-byte read for each of the two rays along the agent's row and one 4- / 8-byte
+// read per neighbouring row for the three rays that cross it - 38 reads; the LDS takes unaligned wide reads, but at ~65 cycles
+// apiece: 3 000 cycles for the 38.)  The reads are inline asm (the compiler folds the bias of the negative offsets back into adds and
+// packs bytes through v_and / v_perm thickets); ngw_lidar_configure checks the host's ray table against ngw_lidar8_dr / _dc.
+template <int OFF>
+__device__ __forceinline__ uint32_t lds_u8_imm(const LDS_AS uint8_t* base) {
+    static_assert(OFF >= 0 && OFF < 65536, "DS immediates are unsigned 16-bit");
+    uint32_t v;
+    asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(OFF));
+    return v;                                                                      // (zero-extended)
+}
+// byte 0 of a | byte 0 of b << 8 | byte 0 of c << 16 | byte 0 of d << 24 (the values are zero-extended bytes: three shift-ors)
+__device__ __forceinline__ uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return (a | (b << 8)) | ((c | (d << 8)) << 16); }
+
+template <int S, int DR, int DC>
+__device__ __forceinline__ void lidar_ray8(const LDS_AS uint8_t* agb, uint32_t (&c)[8]) {
+    constexpr int BIAS = 8 * (S + 1);
+#define NGW_O(d) (BIAS + (d) * (DR * S + DC))
+    c[0] = lds_u8_imm<NGW_O(1)>(agb); c[1] = lds_u8_imm<NGW_O(2)>(agb); c[2] = lds_u8_imm<NGW_O(3)>(agb); c[3] = lds_u8_imm<NGW_O(4)>(agb);
+    c[4] = lds_u8_imm<NGW_O(5)>(agb); c[5] = lds_u8_imm<NGW_O(6)>(agb); c[6] = lds_u8_imm<NGW_O(7)>(agb); c[7] = lds_u8_imm<NGW_O(8)>(agb);
+#undef NGW_O
+}
+
+template <int S>
+__device__ __forceinline__ void lidar_march_const8(const NgwLaunch& a, const LDS_AS uint8_t* ag, int f, int NC, int sh, const LDS_AS uint8_t* chan_of_item,
+                                                   LDS_AS uint8_t* rowp, int dump) {
+    static_assert(S - 2 == 8, "eight geometric steps per ray: two words");
+    static_assert(8 * (S + 1) <= 11 * (S + 1), "inside the LDS guard (11 * (S + 1) bytes on both sides of the maps)");
+    const LDS_AS uint8_t* agb = ag - 8 * (S + 1);                                  // (immediates are unsigned)
+    // world rays in table order: 0 (+d, 0)  1 (+d, +d)  2 (0, +d)  3 (-d, +d)  4 (-d, 0)  5 (-d, -d)  6 (0, -d)  7 (+d, -d)
+    uint32_t c[8][8];
+    lidar_ray8<S, 1, 0>(agb, c[0]); lidar_ray8<S, 1, 1>(agb, c[1]); lidar_ray8<S, 0, 1>(agb, c[2]); lidar_ray8<S, -1, 1>(agb, c[3]);
+    lidar_ray8<S, -1, 0>(agb, c[4]); lidar_ray8<S, -1, -1>(agb, c[5]); lidar_ray8<S, 0, -1>(agb, c[6]); lidar_ray8<S, 1, -1>(agb, c[7]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                             // one wait for all 64 reads ...
+#pragma unroll
+    for (int w = 0; w < 8; w++)                                                    // ... and every value pinned behind it (no instruction; the compiler does not count asm reads)
+        asm volatile("" : "+v"(c[w][0]), "+v"(c[w][1]), "+v"(c[w][2]), "+v"(c[w][3]), "+v"(c[w][4]), "+v"(c[w][5]), "+v"(c[w][6]), "+v"(c[w][7]));
+    STAMP_SUB(a, 2);
+    const int uf = f == 0 ? 4 : (f == 1 ? 0 : (f == 2 ? 6 : 2));                   // NORTH pi, SOUTH 0, WEST 3 pi / 2, EAST pi / 2 in units of pi / 4 (:38)
+    int pos = ((4 - uf) & 7) * NC;                                                 // beam b = (world ray + rot) mod 8; its row entries start at b * NC
+    const int wrap = 8 * NC;
+    int hk[8], ch[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        const uint32_t lo = pack4(c[w][0], c[w][1], c[w][2], c[w][3]), hi = pack4(c[w][4], c[w][5], c[w][6], c[w][7]);
+        const uint32_t t = lo ? lo : hi;                                           // (the wall ring stops every ray within 8 cells: t != 0)
+        const int q = (__ffs((int)(t | 0x80000000u)) - 1) >> 3;
+        const int d = (lo ? 0 : 4) + q;                                            // geometric distance - 1
+        hk[w] = (w & 1) ? (int)((0xBA875431u >> (4 * d)) & 15u) : d + 1;          // a diagonal reports the first range k with round(0.71 k) = d + 1
+        ch[w] = chan_of_item[(t >> (8 * q)) & 255u];
+    }
+    STAMP_SUB(a, 6);
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        rowp[ch[w] ? (pos + ch[w] - 1) << sh : dump] = (uint8_t)hk[w];
+        pos += NC;
+        pos -= pos >= wrap ? wrap : 0;
     }
 }
 
@@ -769,7 +841,7 @@ __device__ __forceinline__ void lidar_march_world(const LDS_AS uint8_t* ag, int 
     rot += rot < 0 ? B : 0;
     for (int w0 = 0; w0 < B; w0 += 8) {
         uint32_t first[8];
-        int kc[8], beam[8];
+        int kc[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) { first[i] = 0; kc[i] = 0; }
         // Scalar loads and LDS reads share one counter (lgkmcnt) and scalar loads return out of order, so a wait for offsets drains
@@ -800,9 +872,9 @@ __device__ __forceinline__ void lidar_march_world(const LDS_AS uint8_t* ag, int 
             for (int i = 0; i < 8; i++) word[i] = (c[i][0] | (c[i][1] << 8)) | ((c[i][2] | (c[i][3] << 8)) << 16);
             if (!__any(lidar_round(word, k0, first, kc))) break;
         }
-#pragma unroll
-        for (int i = 0; i < 8; i++) { const int b = w0 + i + rot; beam[i] = b - (b >= B ? B : 0); }
-        lidar_hits(first, kc, beam, B - w0, R, NC, sh, chan_of_item, rowp, dump);
+        int b0 = w0 + rot;
+        b0 -= b0 >= B ? B : 0;
+        lidar_hits(first, kc, b0 * NC, B - w0, R, NC, B * NC, sh, chan_of_item, rowp, dump);
     }
 }
 
@@ -813,9 +885,9 @@ __device__ __forceinline__ void lidar_march_table(const LDS_AS uint8_t* ag, int 
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     for (int b0 = 0; b0 < B; b0 += 8) {
         uint32_t first[8];
-        int kc[8], beam[8];
+        int kc[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) { first[i] = 0; kc[i] = 0; beam[i] = b0 + i; }
+        for (int i = 0; i < 8; i++) { first[i] = 0; kc[i] = 0; }
         for (int k0 = 0; k0 < R; k0 += 4) {
             u32x2 o[8];
 #pragma unroll
@@ -827,7 +899,7 @@ __device__ __forceinline__ void lidar_march_table(const LDS_AS uint8_t* ag, int 
                 word[i] = lidar_cells4(ag, (int16_t)(o[i].x & 0xFFFFu), (int16_t)(o[i].x >> 16), (int16_t)(o[i].y & 0xFFFFu), (int16_t)(o[i].y >> 16));
             if (!__any(lidar_round(word, k0, first, kc))) break;
         }
-        lidar_hits(first, kc, beam, B - b0, R, NC, sh, chan_of_item, rowp, dump);
+        lidar_hits(first, kc, b0 * NC, B - b0, R, NC, B * NC, sh, chan_of_item, rowp, dump);
     }
 }
 
@@ -839,16 +911,26 @@ static_assert(offsetof(NgwLidarDev, chan_of_item) == 16 * LIDAR_TAB16 && offseto
 
 // The observation of the wave's 64 envs: `agent` = the lane's agent cell in its LDS map, `inv` = its inventory row in LDS; the two
 // item tables are in LDS at a.off_litem (the caller's prologue put them there).  Whole-wave call (barriers inside).
-__device__ __forceinline__ void lidar_epilogue(const NgwLaunch& a, uint32_t* lds, int tid, bool live, const int8_t* agent, int f, const int32_t* inv) {
+// The observation tile starts as zeros.  A step kernel does this in its PROLOGUE, while its global loads are in flight (the wave has
+// nothing else to do there for ~1 100 cycles); only a launch whose cold path used the tile's region for something else (the reset
+// path's Philox ring shares it) zeroes it again in the epilogue.
+__device__ __forceinline__ void lidar_zero_tile(const NgwLaunch& a, uint32_t* lds, int tid) {
+    const int npc = 4 * a.l_rb;
+    LDS_AS u32x4* t4 = (LDS_AS u32x4*)(lds + a.off_ltile);
+    for (int base = 0; base < npc; base += EPB * 4) {                              // (a piece index beyond the tile zeroes the last piece again)
+#pragma unroll
+        for (int j = 0; j < 4; j++) t4[min(base + tid + EPB * j, npc - 1)] = u32x4{0u, 0u, 0u, 0u};
+    }
+}
+
+__device__ __forceinline__ void lidar_epilogue(const NgwLaunch& a, uint32_t* lds, int tid, bool live, const int8_t* agent, int f, const int32_t* inv,
+                                               bool zeroed = false) {
     const int B = a.l_beams, R = a.l_range, NC = a.l_chan, NI = a.l_inv, rb = a.l_rb, npc = 4 * rb;   // 64 rows = 4 * rb pieces of 16 B
     const int sh = a.l_fmt == NGW_LFMT_I32 ? 2 : (a.l_fmt == NGW_LFMT_I16 ? 1 : 0);                   // beam entry = 1 << sh bytes
     LDS_AS u32x4* t4 = (LDS_AS u32x4*)(lds + a.off_ltile);
     wave_lds_sync();
     STAMP_SUB(a, 0);
-    for (int base = 0; base < npc; base += EPB * 4) {                              // (a piece index beyond the tile zeroes the last piece again)
-#pragma unroll
-        for (int j = 0; j < 4; j++) t4[min(base + tid + EPB * j, npc - 1)] = u32x4{0u, 0u, 0u, 0u};
-    }
+    if (!zeroed) lidar_zero_tile(a, lds, tid);
     if (!a.l_world) {                                                              // (uniform) the per-lane ray table, staged now: 8 KiB
         const u32x4* src = reinterpret_cast<const u32x4*>(a.lcfg->off);
         LDS_AS u32x4* dst = (LDS_AS u32x4*)(lds + a.off_ltab);
@@ -865,7 +947,8 @@ __device__ __forceinline__ void lidar_epilogue(const NgwLaunch& a, uint32_t* lds
     if (live) {
         const LDS_AS uint8_t* ag = (const LDS_AS uint8_t*)agent;
         const int dump = EPB * rb - tid * rb + tid;                                // the 64 bytes behind the tile: one per lane
-        if (a.l_world) lidar_march_world(ag, f, B, R, NC, sh, a.lcfg, chan_of_item, rowp, dump);
+        if (a.l_world == 2) lidar_march_const8<NGW_LIDAR_CONST_S>(a, ag, f, NC, sh, chan_of_item, rowp, dump);     // (the host checked table and range: R = 11)
+        else if (a.l_world) lidar_march_world(ag, f, B, R, NC, sh, a.lcfg, chan_of_item, rowp, dump);
         else lidar_march_table(ag, f, B, R, NC, sh, (const LDS_AS int16_t*)(lds + a.off_ltab), chan_of_item, rowp, dump);
     }
     STAMP_SUB(a, 3);
@@ -1116,6 +1199,21 @@ __global__ __launch_bounds__(256) void ngw_diff_kernel(const NgwDiff p) {
         if (c[i] != s[i]) { s[i] = c[i]; h[i] = c[i]; }
 }
 
+// Narrow wire format of the host step (NgwWire, ngw_step_host_packed): one lane per env narrows pose / reward / done / info into
+// four dense arrays of a staging payload (reads 22 B, writes 11 B per env; coalesced both ways).  Rewards are small integers
+// (-25 .. 50 in the reference); a spec with a reward beyond int16 is refused by the host before this format is used.
+__global__ __launch_bounds__(256) void ngw_wire_kernel(const NgwWire p) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e == 0) *p.flags_out = *p.flags;
+    if (e >= p.n) return;
+    const int r = p.loc[2 * e], c = p.loc[2 * e + 1], f = p.facing[e];
+    const uint32_t sel = p.selected[e];
+    p.pose[e] = (uint32_t)(r & 255) | ((uint32_t)(c & 255) << 8) | ((uint32_t)(f & 255) << 16) | (sel << 24);
+    p.reward16[e] = (int16_t)p.reward[e];
+    p.done8[e] = p.done[e];
+    p.info32[e] = p.info[e];
+}
+
 // Region copies (NgwPack): region blockIdx.y, grid-stride over 16-byte pieces; tails and unaligned regions go by bytes.
 // The destination may be host memory mapped into the GPU's address space (the stores then travel over PCIe).
 __global__ __launch_bounds__(256) void ngw_pack_kernel(const NgwPack p) {
@@ -1168,6 +1266,11 @@ extern "C" hipError_t ngw_pack_launch(const NgwPack* p, hipStream_t stream) {
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(ngw_pack_kernel, dim3((unsigned)blocks, (unsigned)p->n_regions), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t ngw_wire_launch(const NgwWire* p, hipStream_t stream) {
+    hipLaunchKernelGGL(ngw_wire_kernel, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
 

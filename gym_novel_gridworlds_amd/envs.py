@@ -62,8 +62,7 @@ class _NovelGridworldEnv(_EnvBase):
         self.inventory_items_quantity = {item: 0 for item in self.items}
         self.selected_item = ''
         self.entities = sp.entities
-        self.available_locations = []
-        self.not_available_locations = []
+        self._avail, self._not_avail, self._avail_stale = [], [], False   # available_locations / not_available_locations (properties below)
         self.actions_id = sp.actions_id
         self.manipulation_actions_id = sp.manipulation_actions_id
         self.recipes = sp.recipes
@@ -246,8 +245,7 @@ class _NovelGridworldEnv(_EnvBase):
             self.items_quantity.clear(); self.items_quantity.update(items_quantity)
         self.inventory_items_quantity = {item: 0 for item in self.items}
         self.selected_item = ''
-        self.available_locations = []
-        self.not_available_locations = []
+        self._avail, self._not_avail, self._avail_stale = [], [], True      # rebuilt from the new map when somebody looks (properties below)
         self.last_action = 'Forward'
         self.step_count = 0
         self.last_step_cost = 0
@@ -374,15 +372,51 @@ class _NovelGridworldEnv(_EnvBase):
                     self.map[rr][cc] = 0
                     self.inventory_items_quantity[names[ent]] += 1
 
+    # `available_locations` / `not_available_locations` (:136-138, :181).  In the reference they are what reset()'s placement loop
+    # left behind: the interior candidates [2, S-3]^2 it never drew (+ the agent's cell), and the ones it drew and popped.  reset()
+    # here runs that loop in the kernels on a per-episode Philox stream, so WHICH blocked candidates were drawn and discarded is not
+    # known on the host; what is known is the invariant that matters to a later add_item_to_map(): every cell that can still take an
+    # item (itself and its four neighbours air) was never drawn - a drawn one would hold an item - so it is still a candidate.  The
+    # lists are therefore rebuilt from the map when first looked at after a reset(): candidates = interior cells that hold no item
+    # (row-major; the agent's cell among them, as in the reference), popped = interior cells that hold one.  A later
+    # add_item_to_map() then draws the same distribution over the cells that can take the item, and "Cannot place items" fires under
+    # the same condition (no such cell left) - after more discarded draws than in the reference, whose list is shorter.
+    def _rebuild_locations(self):
+        self._avail_stale = False
+        inner = range(2, self.map_size - 2)
+        grid = self.map
+        self._avail = [(r, c) for r in inner for c in inner if not grid[r][c]]
+        self._not_avail = [(r, c) for r in inner for c in inner if grid[r][c]]
+
+    @property
+    def available_locations(self):
+        if self._avail_stale:
+            self._rebuild_locations()
+        return self._avail
+
+    @available_locations.setter
+    def available_locations(self, value):
+        if self._avail_stale:
+            self._rebuild_locations()
+        self._avail = value
+
+    @property
+    def not_available_locations(self):
+        if self._avail_stale:
+            self._rebuild_locations()
+        return self._not_avail
+
+    @not_available_locations.setter
+    def not_available_locations(self, value):
+        if self._avail_stale:
+            self._rebuild_locations()
+        self._not_avail = value
+
     def add_item_to_map(self, item, num_items):
         """Public form of the placement loop (:159-181) on the host attributes, drawing from the global numpy stream like the
         reference: a random remaining candidate; the agent's cell is dropped; a cell whose 4-neighbourhood is all air takes the
         item; every drawn candidate leaves the list.  (reset() itself runs the same loop in the kernels, on its per-episode
-        Philox stream; the candidate list this call works on is whatever the caller left in `available_locations` - after a
-        reset() that is empty here, and the interior [2, S-3]^2 in row-major order is taken instead.)"""
-        if not self.available_locations:
-            inner = range(2, self.map_size - 2)
-            self.available_locations = [(r, c) for r in inner for c in inner]
+        Philox stream; the candidate list this call works on is `available_locations` - see above for what it holds after a reset().)"""
         candidates, grid, placed = self.available_locations, self.map, 0
         item_id = self.items_id[item]
         while placed != num_items:

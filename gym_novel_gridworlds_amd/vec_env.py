@@ -34,6 +34,10 @@ class StepInfo(dict):
     LAZY = ('result', 'step_cost_code', 'message_code', 'message_arg', 'step_cost')
 
     def __missing__(self, key):
+        if key == 'final_observation' and dict.__contains__(self, '_final_fn'):      # terminal observations (set_terminal_capture): fetched when asked for
+            v = dict.__getitem__(self, '_final_fn')()
+            dict.__setitem__(self, key, v)
+            return v
         if key in StepInfo.LAZY:
             if key == 'step_cost':
                 v = _COST_F64[self['step_cost_code']]
@@ -46,7 +50,7 @@ class StepInfo(dict):
         raise KeyError(key)
 
     def __contains__(self, key):
-        return key in StepInfo.LAZY or dict.__contains__(self, key)
+        return key in StepInfo.LAZY or dict.__contains__(self, key) or (key == 'final_observation' and dict.__contains__(self, '_final_fn'))
 
     def get(self, key, default=None):
         return self[key] if key in self else default
@@ -57,13 +61,13 @@ class StepInfo(dict):
         return self
 
     def keys(self):
-        return [k for k in dict.keys(self._all()) if k != '_words']
+        return [k for k in dict.keys(self._all()) if k not in ('_words', '_final_fn')]
 
     def items(self):
-        return [(k, v) for k, v in dict.items(self._all()) if k != '_words']
+        return [(k, v) for k, v in dict.items(self._all()) if k not in ('_words', '_final_fn')]
 
     def values(self):
-        return [v for k, v in dict.items(self._all()) if k != '_words']
+        return [v for k, v in dict.items(self._all()) if k not in ('_words', '_final_fn')]
 
     def __iter__(self):
         return iter(self.keys())
@@ -75,9 +79,47 @@ class StepInfo(dict):
         return StepInfo(dict(self.items()))
 
 
+class LazyObs(dict):
+    """The Dict observation of a big batch's step(): 'map' and 'inventory_items_quantity' are sections of the page-locked block the
+    step refreshes; the agent's pose crosses PCIe as four bytes per env (ngw_step_host_packed) and 'agent_location' [N, 2] int32 /
+    'agent_facing_id' [N] int32 are widened from those bytes into the same two arrays when somebody reads them (a 65 536-env widening
+    costs more than the step kernel; a loop that feeds a policy from the map or the lidar rows never asks).  A dict in every other way."""
+    __slots__ = ('_pose', '_dirty')
+
+    def _sync(self):
+        if self._dirty:
+            self._dirty = False
+            pose = self._pose
+            loc = dict.__getitem__(self, 'agent_location')
+            loc[:, 0] = pose[:, 0]
+            loc[:, 1] = pose[:, 1]
+            dict.__getitem__(self, 'agent_facing_id')[:] = pose[:, 2]
+
+    def __getitem__(self, key):
+        if key != 'map' and key != 'inventory_items_quantity':
+            self._sync()
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def items(self):
+        self._sync()
+        return dict.items(self)
+
+    def values(self):
+        self._sync()
+        return dict.values(self)
+
+    def copy(self):
+        self._sync()
+        return dict(self)
+
+
 class VecNovelGridworld:
     def __init__(self, env_id='NovelGridworld-Pogostick-v1', num_envs=1, map_size=None, novelty=None, device=0,
-                 seed=0, autoreset=False, horizon=0, env_index_base=0, spec=None, reset_prefetch='auto', reset_prefetch_depth=0):
+                 seed=0, autoreset=False, horizon=0, env_index_base=0, spec=None, reset_prefetch='auto', reset_prefetch_depth=0,
+                 terminal_capture=False):
         if spec is None:
             spec = make_spec(env_id, map_size)
             if novelty:
@@ -92,6 +134,7 @@ class VecNovelGridworld:
         self.autoreset, self.horizon = bool(autoreset), int(horizon)
         # what the caller chose for the prepared next episodes ('auto' / 0 = the library's own defaults); rebuild() re-applies it
         self._prefetch_arg, self._depth_arg = reset_prefetch, int(reset_prefetch_depth)
+        self.terminal_capture = bool(terminal_capture)         # keep the observation an episode ENDED in (set_terminal_capture)
         self.lidar, self.lidar_fused, self.lidar_len, self.lidar_dtype, self.lidar_packed = None, False, 0, np.dtype(np.int16), False   # set by lidar_configure()
         self._h = C.c_void_p()
         self._open(spec)
@@ -124,18 +167,36 @@ class VecNovelGridworld:
             self.set_reset_prefetch(self._prefetch_arg)
         self._flags_word = C.c_uint32(0)
         self._host = None                                     # host mirrors of the host API: allocated on first use
+        if self.__dict__.get('_stream_arg'):                  # the caller's stream and output bindings travel with the env (rebuild)
+            self.set_stream(self._stream_arg)
+        if self.__dict__.get('_rollout_out_args'):
+            self.rollout_outputs(*self._rollout_out_args)
+        if self.terminal_capture:
+            self.set_terminal_capture(True)
         if self.lidar is not None:                            # the observation setup travels with the env (rebuild)
             self.lidar_configure(self.lidar, fused=self.lidar_fused, dtype='packed' if self.lidar_packed else self.lidar_dtype)
 
     def rebuild(self, spec):
         """The same batched env - same object, same shard of the global env index space (`env_index_base`), same autoreset /
-        horizon / prepared-episode / lidar settings - on an edited spec.  In place: the reference's novelty wrappers mutate
-        the env they wrap and keep its identity (novelty_wrappers.py:1586-1674), so a rank-local shard stays that shard.
-        The state is undefined until the next reset(), as after construction."""
-        self.close()
-        for name in VecNovelGridworld._HOST_ATTRS + ('_host', '_step_args', '_step1_args', '_step1_fn', '_step1_mv', '_state1_mv', '_reset1_args', '_last_state_views', '_lidar_host', '_view_host', '_last_actions'):
+        horizon / prepared-episode / lidar / terminal-capture settings, same stream and rollout-output bindings - on an edited spec.
+        In place: the reference's novelty wrappers mutate the env they wrap and keep its identity (novelty_wrappers.py:1586-1674), so a
+        rank-local shard stays that shard.  The NEW handle is created first: a spec the library refuses (ngw_create's checks) raises
+        and leaves the env as it was - the reference, too, asserts before it changes anything.  The state is undefined until the
+        next reset(), as after construction."""
+        old_h, old_attrs = self._h, dict(self.__dict__)
+        for name in VecNovelGridworld._HOST_ATTRS + ('_host', '_step_args', '_step1_args', '_step1_fn', '_step1_mv', '_state1_mv', '_reset1_args', '_last_state_views', '_lidar_host', '_view_host', '_last_actions', '_packed_block', '_steps_stale', '_reward_i32'):
             self.__dict__.pop(name, None)
-        self._open(spec)
+        self._h = C.c_void_p()
+        try:
+            self._open(spec)
+        except Exception:
+            if self._h:
+                _cabi.lib().ngw_destroy(self._h)
+            self.__dict__.clear()
+            self.__dict__.update(old_attrs)                   # the old handle, spec and host mirrors: nothing happened
+            raise
+        if old_h:
+            _cabi.lib().ngw_destroy(old_h)
         return self
 
     _HOST_ATTRS = ('_obs', '_reward', '_done', '_act_pinned', '_sel_host', '_steps_host', '_result', '_cost', '_msg', '_arg', '_flags_np', '_info_words')
@@ -146,6 +207,9 @@ class VecNovelGridworld:
         if name in VecNovelGridworld._HOST_ATTRS:
             if self.__dict__.get('_host') is None:
                 N, S, K = self.num_envs, self.map_size, self.n_items
+                if self._one_block_path() and hasattr(_cabi.lib(), 'ngw_step_host_packed'):
+                    self._make_packed_host()
+                    return self.__dict__[name]
                 # ONE page-locked block laid out as ngw_host_step_layout says: a big batch's step() then comes back with a single
                 # copy across PCIe (one pack launch on the device) instead of nine
                 offs = (C.c_uint64 * 11)()
@@ -168,6 +232,29 @@ class VecNovelGridworld:
             return self.__dict__[name]
         raise AttributeError(name)
 
+    def _make_packed_host(self):
+        """Host mirrors of a big batch: ONE page-locked block in the narrow wire format (include/ngw.h ngw_host_step_layout_packed) -
+        map and inventory refreshed by deltas, pose as four bytes per env, reward int16, done uint8, packed info words."""
+        N, S, K = self.num_envs, self.map_size, self.n_items
+        offs = (C.c_uint64 * 8)()
+        _cabi.check(_cabi.lib().ngw_host_step_layout_packed(self._h, offs))
+        block = _cabi.pinned_array((int(offs[7]),), np.uint8)
+
+        def sec(i, shape, dt):
+            nb = int(np.prod(shape)) * np.dtype(dt).itemsize
+            return block[int(offs[i]):int(offs[i]) + nb].view(dt).reshape(shape)
+        pose = sec(2, (N, 4), np.uint8)
+        obs = LazyObs({'map': sec(0, (N, S, S), np.int8), 'agent_location': np.zeros((N, 2), np.int32),
+                       'agent_facing_id': np.zeros(N, np.int32), 'inventory_items_quantity': sec(1, (N, K), np.int32)})
+        obs._pose, obs._dirty = pose, False
+        self.__dict__['_host'] = dict(
+            _obs=obs, _reward=sec(3, (N,), np.int16), _done=sec(4, (N,), np.uint8), _info_words=sec(5, (N,), np.uint32), _flags_np=sec(6, (1,), np.uint32),
+            _sel_host=pose[:, 3], _steps_host=np.zeros(N, np.int32), _act_pinned=np.zeros(N, np.int32),
+            _result=np.zeros(N, np.uint8), _cost=np.zeros(N, np.uint8), _msg=np.zeros(N, np.uint16), _arg=np.zeros(N, np.uint16))
+        self.__dict__.update(self.__dict__['_host'])
+        self.__dict__['_packed_block'] = block
+        self.__dict__['_steps_stale'] = False
+
     # ------------------------------------------------------------------ lifecycle
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
@@ -188,6 +275,7 @@ class VecNovelGridworld:
 
     def set_stream(self, hip_stream_ptr):
         _cabi.check(_cabi.lib().ngw_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+        self._stream_arg = hip_stream_ptr                     # (rebuild() puts the new handle on the same stream)
 
     def stream_order(self, other_stream_ptr, handle_waits):
         """Order this env's stream and another HIP stream behind each other without a host wait (include/ngw.h ngw_stream_order)."""
@@ -229,8 +317,27 @@ class VecNovelGridworld:
         `messages(info, actions)` formats the reference's strings lazily."""
         a = np.ascontiguousarray(actions, np.int32)
         assert a.shape == (self.num_envs,)
-        self._act_pinned[...] = a
         o = self._obs
+        block = self.__dict__.get('_packed_block')
+        if block is not None:
+            # big batch, narrow wire format (ngw_step_host_packed): the actions are narrowed to bytes on their way into a buffer the step
+            # kernel reads in place, map / inventory come back as deltas, pose + reward + done + info as 11 B per env in one copy
+            rc = _cabi.lib().ngw_step_host_packed(self._h, C.c_void_p(a.__array_interface__['data'][0]), _cabi._ptr(block, np.uint8), int(bool(with_obs)))
+            if rc:
+                _cabi.check(rc)
+            self._last_actions = a
+            o._dirty = True
+            self._steps_stale = True
+            obs = None if not with_obs else ({k: v.copy() for k, v in o.items()} if copy else o)
+            reward, done = (self._reward.copy(), self._done.view(np.bool_).copy()) if copy else (self._reward, self._done.view(np.bool_))
+            info = StepInfo({'_words': self._info_words.copy() if copy else self._info_words})
+            if self._flags_np[0]:
+                self._raise_flags()
+            if self.terminal_capture:
+                dict.__setitem__(info, '_final_fn', self.terminal_observation)
+                info['_final_observation'] = done
+            return obs, reward, done, info
+        self._act_pinned[...] = a
         cache = self.__dict__.setdefault('_step_args', {})
         args = cache.get(bool(with_obs))
         if args is None:                                             # the host arrays never move: the argument list is built once
@@ -254,7 +361,38 @@ class VecNovelGridworld:
             reward, done, info = self._step_out_views(copy)
         if self._flags_np[0]:
             self._raise_flags()
+        if self.terminal_capture:                             # gym.vector convention: info['final_observation'] (rows valid where the mask is set)
+            dict.__setitem__(info, '_final_fn', self.terminal_observation)
+            info['_final_observation'] = done
         return obs, reward, done, info
+
+    def set_terminal_capture(self, on=True):
+        """Keep, for every env that ends an episode in a step() under autoreset, the observation that episode ENDED in (the step
+        itself returns the next episode's first observation): include/ngw.h ngw_set_terminal_capture.  step() then puts
+        info['_final_observation'] (= done) and a lazily fetched info['final_observation'] into its info; terminal_observation() reads
+        the side set directly.  Off by default; fused rollouts refuse to run while it is on."""
+        _cabi.check(_cabi.lib().ngw_set_terminal_capture(self._h, int(bool(on))))
+        self.terminal_capture = bool(on)
+
+    def terminal_observation(self, device=False):
+        """Dict observation rows of the states episodes ended in ([N, ...] arrays like get_observation(); row e is meaningful for
+        the envs whose `done` the last step() set, and keeps its value until env e ends an episode again).  device=True: zero-copy
+        torch views of the side set."""
+        N, S, K = self.num_envs, self.map_size, self.n_items
+        if device:
+            import torch
+            p = [C.c_void_p() for _ in range(4)]
+            _cabi.check(_cabi.lib().ngw_terminal_device_ptrs(self._h, *[C.byref(x) for x in p]))
+            dev = 'cuda:%d' % self.device
+            return {'map': torch.as_tensor(_DevArray(p[0].value, (N, S, S), '|i1'), device=dev),
+                    'agent_location': torch.as_tensor(_DevArray(p[1].value, (N, 2), '<i4'), device=dev),
+                    'agent_facing_id': torch.as_tensor(_DevArray(p[2].value, (N,), '<i4'), device=dev),
+                    'inventory_items_quantity': torch.as_tensor(_DevArray(p[3].value, (N, K), '<i4'), device=dev)}
+        out = {'map': np.zeros((N, S, S), np.int8), 'agent_location': np.zeros((N, 2), np.int32), 'agent_facing_id': np.zeros(N, np.int32),
+               'inventory_items_quantity': np.zeros((N, K), np.int32)}
+        _cabi.check(_cabi.lib().ngw_get_terminal_obs(self._h, _cabi._ptr(out['map'], np.int8), _cabi._ptr(out['agent_location'], np.int32),
+                                                     _cabi._ptr(out['agent_facing_id'], np.int32), _cabi._ptr(out['inventory_items_quantity'], np.int32)))
+        return out
 
     def _one_block_path(self):
         """Does ngw_step_host take its one-block path (pack + one copy, delta refresh) for this env's full step()?  The rule of
@@ -309,6 +447,11 @@ class VecNovelGridworld:
     def last_state(self):
         """State after the last step() as get_state() would return it, from the host buffers that call filled (no device
         traffic; `episode` is not part of it)."""
+        if self.__dict__.get('_packed_block') is not None:
+            self._obs._sync()
+            if self._steps_stale:                             # (step_count does not travel in the narrow wire format: fetched when asked for)
+                _cabi.check(_cabi.lib().ngw_get_state(self._h, 0, self.num_envs, None, None, None, None, None, _cabi._ptr(self._steps_host, np.int32), None))
+                self._steps_stale = False
         st = self.__dict__.get('_last_state_views')
         if st is None:                                        # views of the host buffers every step fills: built once
             o = self._obs
@@ -318,12 +461,23 @@ class VecNovelGridworld:
 
     def get_observation(self, copy=False):
         o = self._obs
+        if isinstance(o, LazyObs):
+            o._dirty = False                                  # (the pose arrays are filled from the device below)
         _cabi.check(_cabi.lib().ngw_get_obs(self._h, _cabi._ptr(o['map'], np.int8), _cabi._ptr(o['agent_location'], np.int32),
                                             _cabi._ptr(o['agent_facing_id'], np.int32),
                                             _cabi._ptr(o['inventory_items_quantity'], np.int32)))
         return {k: v.copy() for k, v in o.items()} if copy else o
 
     def get_step_out(self, copy=False):
+        if self._reward.dtype != np.int32:                    # (big batches: step() keeps the reward in the wire format's int16 section)
+            r32 = self.__dict__.get('_reward_i32')
+            if r32 is None:
+                r32 = self._reward_i32 = np.zeros(self.num_envs, np.int32)
+            _cabi.check(_cabi.lib().ngw_get_step_out(self._h, _cabi._ptr(r32, np.int32), _cabi._ptr(self._done, np.uint8),
+                                                     _cabi._ptr(self._result, np.uint8), _cabi._ptr(self._cost, np.uint8),
+                                                     _cabi._ptr(self._msg, np.uint16), _cabi._ptr(self._arg, np.uint16)))
+            reward, done, info = self._step_out_views(copy)
+            return (r32.copy() if copy else r32), done, info
         _cabi.check(_cabi.lib().ngw_get_step_out(self._h, _cabi._ptr(self._reward, np.int32), _cabi._ptr(self._done, np.uint8),
                                                  _cabi._ptr(self._result, np.uint8), _cabi._ptr(self._cost, np.uint8),
                                                  _cabi._ptr(self._msg, np.uint16), _cabi._ptr(self._arg, np.uint16)))
@@ -411,6 +565,7 @@ class VecNovelGridworld:
         [T, row_stride] in device memory (0 = off), and per-env episode accumulators kept across rollout calls."""
         _cabi.check(_cabi.lib().ngw_rollout_outputs(self._h, C.c_void_p(int(reward_rows_ptr)) if reward_rows_ptr else None,
                                                     C.c_void_p(int(done_rows_ptr)) if done_rows_ptr else None, int(row_stride), int(bool(accumulate))))
+        self._rollout_out_args = (reward_rows_ptr, done_rows_ptr, row_stride, accumulate)   # (rebuild() re-binds them)
 
     def episode_stats(self, clear=False):
         """dict of int32 [N] host arrays: return / length of the running episodes, sum of returns / count of the finished ones."""

@@ -356,6 +356,30 @@ int ngw_pack_obs(ngw_handle* h, void* payload_dev);
 int ngw_unpack_obs(ngw_handle* h, const void* payloads_dev, int32_t world, int8_t* map, int32_t* loc, int32_t* facing,
                    int32_t* inv, int32_t* reward, uint8_t* done, uint32_t* info);
 
+/* The host step in its NARROW WIRE FORMAT (big batches; what VecNovelGridworld.step() uses from a few thousand envs on).  One
+ * page-locked block holds everything a step returns; ngw_host_step_layout_packed gives its section offsets (index: 0 map int8
+ * [n][S*S], 1 inventory int32 [n][K], 2 pose uint32 [n] = r | c << 8 | facing << 16 | selected << 24, 3 reward int16 [n], 4 done
+ * uint8 [n], 5 info uint32 [n] (NGW_INFO_*), 6 error flags uint32; sections padded to 256 bytes, offsets8[7] = the block's size).
+ * ngw_step_host_packed(h, actions, block, with_map): int32 actions from host memory are validated and narrowed to bytes on the way
+ * into a buffer the step kernel reads in place (no copy call); map and inventory are refreshed by deltas as in ngw_step_host (the block
+ * is a mirror the caller hands in call after call; with_map = 0 skips the map's delta for this call); the dense sections 2-6 - 11 B per
+ * env instead of the 26 B of the int32 arrays - come back with one copy.  Widening (pose bytes -> int32 arrays) is the caller's, when
+ * he needs it.  Rewards travel as int16: a spec with a larger reward is refused (NGW_E_INVALID_ARG; use ngw_step_host). */
+int ngw_host_step_layout_packed(ngw_handle* h, uint64_t* offsets8);
+int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block, int with_map);
+
+/* Terminal observations under same-step autoreset.  A step that ends an env's episode (done, or the horizon) returns the NEXT
+ * episode's first observation (ngw_set_autoreset); the reference's loops look at the last observation of the old one before they
+ * reset (tests/test.py:30-41, enjoy.py:107-116), and a learner bootstraps from it at a horizon cut.  enable = 1: the envs that reset in
+ * a step launch first copy the state their episode ended in - map row, pose, inventory row - into a side set, which
+ * ngw_get_terminal_obs copies out whole ([n_envs] rows; row e is meaningful for the envs whose `done` the last step set, and keeps its
+ * value until env e ends an episode again) and ngw_terminal_device_ptrs exposes in place.  Off by default; when off the step kernels'
+ * hot path is untouched (the copy sits behind the "some lane resets" branch).  Fused rollouts keep their state on chip between steps and
+ * refuse to run while the capture is on (NGW_E_INVALID_ARG). */
+int ngw_set_terminal_capture(ngw_handle* h, int enable);
+int ngw_get_terminal_obs(ngw_handle* h, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv);
+int ngw_terminal_device_ptrs(ngw_handle* h, void** map, void** loc, void** facing, void** inv);
+
 /* Which per-launch step kernel this handle's ngw_step* calls run right now: *map_in_place = 1 - the one that reads the <= 14 map
  * cells a step needs straight from HBM (every map size but 10 x 10 and 6 x 6), 0 - the one that stages the wave's 64 maps through
  * LDS (10 x 10, 6 x 6, and any size while the fused lidar epilogue is on).  What bench.py prices its byte models on. */

@@ -286,6 +286,99 @@ def test_full_size_properties_pogostick_65536():
             assert (os_[k][0] == st[k][e]).all(), (k, e)
 
 
+@pytest.mark.parametrize('wl', ['C2', 'C3', 'C4'])
+def test_bench_call_sequence_matches_oracle_at_full_size(wl):
+    """bench.py's own sequence at the workload's full size - reset, set_state(step_count) so that the horizon falls inside the timed
+    launches, W = 5 then K = 20 one-step launches from ngw_step_device_many (eager, prepared rows consumed by the whole-wave copy at
+    the horizon, default refill cadence), actions drawn on the device exactly as bench.py draws them - with EVERY env held to the
+    oracle afterwards: state, episode counters and the last step's reward / done / info.  What the headline number times is what
+    the parity suite checks."""
+    import torch
+    import bench
+    from gym_novel_gridworlds_amd import apply_novelty
+    env_id, S, nov, n, _ = bench.WORKLOADS[wl]
+    spec = make_spec(env_id, S)
+    if nov:
+        np.random.seed(0)
+        apply_novelty(spec, *nov)
+    A = len(spec.actions_id)
+    H, steps, warmup = bench.HORIZON, 20, 5
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=0, autoreset=True, horizon=H)
+    o = Oracle(spec.compile(), n, seed=0, autoreset=True, horizon=H)
+    v.reset(); o.reset()
+    hit = warmup + max(1, steps // 2)
+    s0 = (H - hit) % H
+    v.set_state(0, step_count=np.full(n, s0, np.int32))
+    o.st.step_count[:] = s0
+    g = torch.Generator(device='cuda')
+    g.manual_seed(bench.ACTION_SEED)
+    acts = torch.randint(0, A, (warmup + steps, n), dtype=torch.int32, device='cuda', generator=g)
+    torch.cuda.synchronize()
+    ep0 = int(v.get_state(0, 1)['episode'][0])
+    v.step_device_many(acts[0].data_ptr(), n, warmup)
+    v.step_device_many(acts[warmup].data_ptr(), n, steps)
+    v.sync()
+    assert v.error_flags() == 0
+    an = acts.cpu().numpy()
+    for t in range(warmup + steps):
+        o.step(an[t])
+    assert_state_equal(v, o, 'bench sequence ' + wl)
+    out = v.device_outputs()
+    assert (out['reward'].cpu().numpy() == o.reward).all() and (out['done'].cpu().numpy() == o.done).all()
+    assert (out['info'].cpu().numpy().view(np.uint32) == o.info).all()
+    assert int(v.get_state(0, 1)['episode'][0]) == ep0 + 1          # the reset of every env sat inside the 20 timed launches
+
+
+@pytest.mark.parametrize('cfg,n,H,prefetch', [('pogo10', 3000, 9, 'auto'), ('fire10h', 2000, 50, 4), ('bow20', 700, 7, 0), ('axe10', 1500, 11, 3),
+                                              ('add32', 200, 5, 'auto'), ('pogo13', 900, 64, 'auto'), ('fencer10m', 640, 8, 2)])
+def test_terminal_observations_under_autoreset(cfg, n, H, prefetch):
+    """ngw_set_terminal_capture: an env that ends an episode in a step (done, a FireWall death, or the horizon cut) keeps the state that
+    episode ENDED in - what a second oracle, stepped from the same pre-step state WITHOUT autoreset, holds - while step() returns the new
+    episode's first observation as before.  Staggered episode ends (a few lanes of a wave reset per step), whole-wave ends, prepared
+    rows on and off, staged and in-place step kernels; fused rollouts refuse to run while the capture is on."""
+    spec = T.build_spec(cfg)
+    A, S, K = len(spec.actions_id), spec.map_size, len(spec.items_id)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=3, autoreset=True, horizon=H, reset_prefetch=prefetch, terminal_capture=True)
+    o = Oracle(spec.compile(), n, seed=3, autoreset=True, horizon=H)
+    o2 = Oracle(spec.compile(), n, seed=3, autoreset=False, horizon=0)
+    v.reset(); o.reset()
+    sc = (np.arange(n) * 7 % H).astype(np.int32)
+    sc[:128] = 0                                                      # the first two waves end their episodes together (whole-wave copy)
+    v.set_state(0, step_count=sc)
+    o.st.step_count[:] = sc
+    rs = np.random.RandomState(5)
+    ended = 0
+    for t in range(3 * H + 5 if H < 30 else 70):
+        for dst, src in zip(o2.st.arrays() + [o2.st.episode], o.st.arrays() + [o.st.episode]):
+            dst[...] = src
+        a = rs.randint(0, A, size=n).astype(np.int32)
+        if t % 11 == 3:                                               # goal items now and then: `done` endings, not only horizon cuts
+            inv = o.st.inv.copy()
+            inv[rs.randint(0, n, size=n // 50), spec.items_id[spec.goal_item_to_craft]] = 1
+            o.st.inv[...] = inv; o2.st.inv[...] = inv
+            v.set_state(0, inv=inv)
+        obs, reward, done, info = v.step(a)
+        o.step(a); o2.step(a)
+        assert (done == o.done.astype(bool)).all() and (reward == o.reward).all(), t
+        assert (info['_final_observation'] == done).all()
+        idx = np.nonzero(done)[0]
+        ended += idx.size
+        fo = info['final_observation']
+        assert (fo['map'].reshape(n, -1)[idx] == o2.st.map[idx]).all(), (t, 'map')
+        assert (fo['agent_location'][idx] == o2.st.loc[idx]).all() and (fo['agent_facing_id'][idx] == o2.st.facing[idx]).all(), (t, 'pose')
+        assert (fo['inventory_items_quantity'][idx] == o2.st.inv[idx]).all(), (t, 'inventory')
+        dev = v.terminal_observation(device=True)
+        assert (dev['map'].cpu().numpy() == fo['map']).all() and (dev['inventory_items_quantity'].cpu().numpy() == fo['inventory_items_quantity']).all()
+        assert (obs['map'].reshape(n, -1) == o.st.map).all() and (obs['agent_location'] == o.st.loc).all(), (t, 'the returned observation is the new episode')
+    assert_state_equal(v, o, 'terminal capture ' + cfg)
+    assert ended > n                                                  # every env ended at least one episode on average
+    with pytest.raises(ValueError, match='terminal'):
+        v.rollout(5)
+    v.set_terminal_capture(False)
+    v.rollout(5, action_seed=1, t0=0); o.rollout(5, 1, 0)
+    assert_state_equal(v, o, 'rollout after the capture was switched off')
+
+
 def test_thirty_million_envs_match_oracle_slices():
     """33 554 432 envs on one GPU straight through the C-ABI (5.6 GB of state, 524 288 wavefronts; the map array alone
     exceeds 2^31 bytes - the 288 GB of HBM would hold 50x that): slices at the start, across the 2^31-byte mark of the map

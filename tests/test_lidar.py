@@ -207,8 +207,13 @@ def test_lidar_row_formats_and_marches(cfg, beams, dtype, monkeypatch):
     lc = LidarConfig(spec, beams)
     cc = lc.compile(spec)
     n = 700
-    for world in (('1', '0') if beams % 4 == 0 else ('1',)):
-        monkeypatch.setenv('NGW_LIDAR_WORLD', world)
+    # NGW_LIDAR_WORLD unset: the library's choice (the constant-offset march for the reference's default 8 beams on a 10 x 10 map, else
+    # the world-frame one where it applies); 1: the table-driven world-frame march; 0: the per-lane table
+    for world in ((None, '1', '0') if beams % 4 == 0 else (None,)):
+        if world is None:
+            monkeypatch.delenv('NGW_LIDAR_WORLD', raising=False)
+        else:
+            monkeypatch.setenv('NGW_LIDAR_WORLD', world)
         for fused in (False, True):
             v = G.VecNovelGridworld(spec=spec, num_envs=n, seed=21, autoreset=True, horizon=13)
             v.lidar_configure(lc, fused=fused, dtype=dtype)

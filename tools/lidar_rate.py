@@ -53,18 +53,20 @@ s.close()
 v = env()
 replay(v, 'plain step')
 v.close()
-for world in ('1', '0'):
-    os.environ['NGW_LIDAR_WORLD'] = world
+for world in ('', '1', '0'):
+    os.environ.pop('NGW_LIDAR_WORLD', None)
+    if world:
+        os.environ['NGW_LIDAR_WORLD'] = world
     for dt_, name in ((np.int32, 'int32'), (np.int16, 'int16'), ('packed', 'packed u8+i16')):
         v = env()
         v.lidar_configure(num_beams=8, fused=True, dtype=dt_)
-        replay(v, 'fused lidar, %s rows (%d B/env), %s rays' % (name, v.lidar_row_bytes, 'world-frame' if world == '1' else 'per-lane table'))
-        if world == '1':
+        replay(v, 'fused lidar, %s rows (%d B/env), %s rays' % (name, v.lidar_row_bytes, {'': 'default (constant-offset at 10x10)', '1': 'world-frame', '0': 'per-lane table'}[world]))
+        if world == '':
             v.rollout(100, 1, 0); v.sync()
             v.timing_begin(); v.rollout(1000, 1, 100); ms = v.timing_end()
-            print('    fused rollout, observation of the final state: %.2f us per batched step -> %.1f G env-steps/s' % (ms, n / ms / 1e6), flush=True)
+            print("    fused rollout (1000 steps), observation of the final state: %.3f us per batched step -> %.1f G env-steps/s" % (ms, n / ms / 1e3), flush=True)
         v.close()
-os.environ['NGW_LIDAR_WORLD'] = '1'
+os.environ.pop('NGW_LIDAR_WORLD', None)
 v = env()
 v.lidar_configure(num_beams=8, fused=False, dtype=np.int16)
 v.reset()

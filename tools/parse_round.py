@@ -225,6 +225,74 @@ for label, dirs, pick, per in (('C2 step kernel `ngw_step_lean<0, true>` (per la
                                     'issue_share_of_wave_cycles': round(vals.get('SQ_ACTIVE_INST_ANY', 0) / vals.get('SQ_WAVE_CYCLES', 1), 3),
                                     'source': 'profiles/%s_pmc.md (rocprofv3 --pmc SQ_*, 200-step launch)' % ROUND}
 open(os.path.join(DST, ROUND + '_pmc.md'), 'w').write('\n'.join(pm) + '\n')
+
+# ---------------------------------------------------------------- the fused LidarInFront step
+ld = ['# The step with the fused LidarInFront observation (%s)\n' % ROUND,
+      'Reference: `gym_novel_gridworlds/observation_wrappers.py:10-80` - the observation every reference training / evaluation script wraps the env in.  '
+      'Kernel `ngw_step_lean<0, true, false, true>`: the batched step of C2 (Pogostick-v1 10x10, 65 536 envs) with the observation rows (8 beams x 7 lidar '
+      'items + 7 inventory entries = 63 values per env) built in the same launch.  Commands: `python3 bench.py --no-cpu-baseline --no-side --lidar <format> ...` '
+      '(`tools/profile_round.sh`, section 5); the default bench line reports the same three formats untraced under `lidar`.\n']
+ld.append('## Kernel trace per row format (400 timed steps, hipGraph replay)\n')
+ld.append('| rows | bytes per env | bench line while traced: us per batched step | `ngw_step_lean<..., true>` launches | average ns (kernel_stats.csv) | median us (kernel trace) |')
+ld.append('|---|---|---|---|---|---|')
+for F in ('int32', 'int16', 'packed'):
+    f = first('stats_lidar_%s/**/*kernel_stats.csv' % F)
+    ln = bench_line('stats_lidar_%s.log' % F)
+    if not f or not ln:
+        continue
+    row = [r for r in csv.DictReader(open(f)) if 'step_lean' in r['Name']]
+    tr = first('stats_lidar_%s/**/*kernel_trace.csv' % F)
+    dur = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in csv.DictReader(open(tr)) if 'step_lean' in r['Kernel_Name']]
+    if row:
+        ld.append('| %s | %d | %.2f | %s | %.1f | %.2f |' % (F, ln['config']['fused_lidar']['row_bytes'], ln['ms_per_step'] * 1e3, row[0]['Calls'], float(row[0]['AverageNs']),
+                                                       st.median(dur) if dur else float('nan')))
+ld.append('\n(As for the plain step kernel, a traced dispatch shows its whole un-overlapped launch; the untraced figures are the bench line\'s `lidar` key and `tools/lidar_rate.py`.)\n')
+ld.append('## HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes)\n')
+ld.append('| rows | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes per launch (corrected) | per env-step | of which observation rows |')
+ld.append('|---|---|---|---|---|---|')
+for F in ('int16', 'packed'):
+    f_by, w_by = counters('pmc_lidar_%s_FETCH_SIZE' % F), counters('pmc_lidar_%s_WRITE_SIZE' % F)
+    ln = bench_line('pmc_lidar_%s_FETCH_SIZE.log' % F)
+    for (k, cn), v in f_by.items():
+        if 'step_lean' not in k:
+            continue
+        fv, wv = st.median(v), st.median(w_by.get((k, 'WRITE_SIZE'), [0]))
+        total = fv * 1024 * ff + wv * 1024 * wf
+        rb = ln['config']['fused_lidar']['row_bytes'] if ln else 0
+        ld.append('| %s | %.1f | %.1f | %.0f | %.1f | %d |' % (F, fv, wv, total, total / 65536, rb))
+        traffic['C2_lidar_%s_step' % F] = {'hbm_bytes_per_launch': round(total), 'env_steps_per_launch': 65536, 'hbm_bytes_per_env_step': round(total / 65536, 1),
+                                           'source': 'profiles/%s_lidar.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)' % ROUND}
+ld.append('\n## SQ counters (int16 rows)\n')
+vals = {}
+for d in ('sq_lidar_1', 'sq_lidar_2', 'sq_lidar_3'):
+    for (k, cn), v in counters(d).items():
+        if 'step_lean' in k:
+            vals[cn] = st.median(v)
+if vals:
+    waves = vals.get('SQ_WAVES', 1024) or 1024
+    ld.append('| counter | per launch | per wave |')
+    ld.append('|---|---|---|')
+    for cn in sorted(vals):
+        ld.append('| %s | %.0f | %.1f |' % (cn, vals[cn], vals[cn] / waves))
+    if 'SQ_WAVE_CYCLES' in vals:
+        wc = vals['SQ_WAVE_CYCLES']
+        ld.append('\nwaiting (SQ_WAIT_ANY) %.0f %% of the wave cycles, issuing (SQ_ACTIVE_INST_ANY) %.0f %%\n' % (100 * vals.get('SQ_WAIT_ANY', 0) / wc, 100 * vals.get('SQ_ACTIVE_INST_ANY', 0) / wc))
+for F in ('int16', 'packed', 'int32'):                    # the stamped timelines of tools/lidar_probe.sh, if that ran in this round
+    lg = os.path.join(ROOT, 'gpurun_out', ROUND, 'stamp_lidar_%s.log' % F)
+    if os.path.exists(lg):
+        ld.append('## In-kernel timeline, %s rows (`tools/lidar_probe.sh`: diagnostics build with clock stamps, C2, last launch of a replayed graph)\n' % F)
+        ld.append('```')
+        ld += [x.rstrip() for x in open(lg) if 'amdgpu.ids' not in x]
+        ld.append('```\n')
+lr = os.path.join(ROOT, 'gpurun_out', ROUND, 'lidar_rate.log')
+if os.path.exists(lr):
+    ld.append('## Untraced rates (`tools/lidar_rate.py`: 64-step hipGraph replayed 16 times, default prepared-episode cadence)\n')
+    ld.append('```')
+    ld += [x.rstrip() for x in open(lr) if 'amdgpu.ids' not in x]
+    ld.append('```\n')
+open(os.path.join(DST, ROUND + '_lidar.md'), 'w').write('\n'.join(ld) + '\n')
+
+
 def _read(name):
     try:
         return open(os.path.join(SRC, name)).read().strip()

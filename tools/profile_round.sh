@@ -7,6 +7,7 @@
 #      count is known exactly (calibrates FETCH_SIZE: gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md §HBM)
 #   3. SQ counters (wave cycles, waiting, issue mix) of the C2 step kernel and of the C2 fused rollout
 #   4. FETCH_SIZE / WRITE_SIZE of the new-episode kernel (explicit resets of every env, prepared episodes off): C3, C5, X1
+#   5. the fused LidarInFront step: kernel trace per row format, FETCH / WRITE and SQ counters (int16 rows) -> profiles/<round>_lidar.md
 # Outputs land in gpurun_out/prof_<round>/ ; tools/parse_round.py <round> turns them into profiles/<round>_*.md + profiles/pmc_traffic.json.
 ROUND=${1:-r04}
 OUT=gpurun_out/prof_$ROUND
@@ -36,6 +37,20 @@ for c in FETCH_SIZE WRITE_SIZE; do
   for W in C3 C5 X1; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_reset_${W}_$c -- python3 tools/reset_pmc.py $W > $OUT/pmc_reset_${W}_$c.log 2>&1 || echo "pmc reset $W $c failed"
   done
+done
+# 5. the step with the FUSED LidarInFront observation (ngw_step_lean<., true, ., true>): kernel trace per row format, HBM traffic and SQ counters (int16 rows)
+for F in int32 int16 packed; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lidar_$F -- $B --lidar $F > $OUT/stats_lidar_$F.log 2>&1 || echo "stats lidar $F failed"
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  for F in int16 packed; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_lidar_${F}_$c -- $P --lidar $F > $OUT/pmc_lidar_${F}_$c.log 2>&1 || echo "pmc lidar $F $c failed"
+  done
+done
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/sq_lidar_$i -- $P --lidar int16 > $OUT/sq_lidar_$i.log 2>&1 || echo "sq lidar $i failed"
 done
 git rev-parse --short HEAD > $OUT/commit.txt 2>/dev/null || echo unknown > $OUT/commit.txt
 date -u +%Y-%m-%dT%H:%MZ > $OUT/date.txt

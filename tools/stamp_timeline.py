@@ -78,8 +78,9 @@ def main():
             d = cy[:, 6] - cy[:, 5]
             print('  outputs begin -> outputs issued, percentiles 10/25/50/75/90/99: ' + ' '.join('%.0f' % np.percentile(d, q) for q in (10, 25, 50, 75, 90, 99)))
         if sub.max() > 0:                                # stamps inside the LidarInFront row builder (STAMP_SUB in lidar_rows)
-            sn = ['epilogue entered', 'tile zeroed', 'march done', 'hits written', 'inventory written', 'rows stored (issued)']
-            have = [i for i in range(len(sn)) if sub[:, i].max() > 0]
+            sn = ['epilogue entered', 'tile zeroed', 'cells read', 'hits written', 'inventory written', 'rows stored (issued)', 'rays resolved']
+            order = [0, 1, 2, 6, 3, 4, 5]                  # (slot 6 sits between 'cells read' and 'hits written')
+            have = [i for i in order if sub[:, i].max() > 0]
             print('  inside the lidar epilogue, shader cycles (median / p90):')
             for a_, b_ in zip(have[:-1], have[1:]):
                 d = sub[:, b_] - sub[:, a_]
