@@ -693,15 +693,15 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     if (const char* v = getenv("NGW_HOST_DELTA")) h->host_delta = atoi(v) != 0;
     if (const char* v = getenv("NGW_ZC_BYTES")) { h->zc_bytes = (size_t)atoll(v); if (!h->zc_bytes) h->zc_bytes = 1; }
     {
-        // Which per-launch step kernel: the one that stages the wave's maps through LDS only where that is the faster one - maps whose
-        // 64 rows arrive in ONE round of loads (S*S <= 128) and land in LDS as they are (S*S a multiple of 4 with S*S / 4 odd: the
-        // conflict-free stride needs no padding), i.e. 10 x 10 and 6 x 6.  Every other size reads its <= 14 cells in place
-        // (tools/size_sweep.py, 65 536 envs: 11 x 11 6.6 -> 4.0 us per step, 12 x 12 5.3 -> 3.9, 13 x 13 8.2 -> 4.3, 14 x 14 4.5 -> 4.1,
-        // 15 x 15 9.4 -> 4.2; at 10 x 10 the two are within 4 % of each other, either way round depending on the batch size).
-        // NGW_NOSTAGE=<min S*S> (A/B): the round-2 rule "in place from that size on" (0 = never).
+        // Which per-launch step kernel: the one that reads the <= 14 cells a step needs straight from HBM, at EVERY map size.  Up to
+        // round 3 the 10 x 10 (and 6 x 6) maps - whose 64 rows arrive in one round of loads and land in LDS as they are - kept the
+        // kernel that stages them through LDS ("within 4 % of each other, either way round depending on the batch size").  With the
+        // cold path out of the hot path's register allocation (round 4) the in-place kernel is the faster one at every batch size
+        // measured (tools/ab_stage.sh, us per replayed launch, staged / in place: 64 envs 2.9 / 2.7, 4 096 3.2 / 3.1, 16 384 3.3 / 3.2,
+        // 32 768 (C4) 4.1 / 4.0, 65 536 (C2) 4.2 / 3.8), so it is the one that runs; the staged kernel remains what the fused lidar
+        // epilogue rides on (it marches over the maps in LDS).  NGW_NOSTAGE=<min S*S> (A/B): in place from that size on (0 = never).
         const int s2 = spec->map_size * spec->map_size;
-        const bool straight_one_round = (s2 & 3) == 0 && ((s2 >> 2) & 1) && s2 <= 128;
-        h->nostage = !straight_one_round;
+        h->nostage = 1;
         if (const char* v = getenv("NGW_NOSTAGE")) { const int min_s2 = atoi(v); h->nostage = min_s2 > 0 && s2 >= min_s2; }
     }
 

@@ -17,9 +17,10 @@ from .vec_env import VecNovelGridworld
 
 
 class LidarInFront(NoveltyWrapper):
-    def __init__(self, env, num_beams=8, fused=True, dtype=np.int16):
+    def __init__(self, env, num_beams=8, fused=True, dtype=np.int16, copy=False):
         super().__init__(env)
         self.num_beams = num_beams
+        self._copy = bool(copy)                                 # batched envs: hand out a copy of the host rows instead of the rows themselves (valid until the next step)
         self._dtype = dtype if isinstance(dtype, str) else np.dtype(dtype)   # batched envs: int16 (default), int32 or 'packed' rows (vec_env.lidar_configure)
         self._fused = fused                                     # batched envs: compute the observation inside the step launch
         self._vec = env if isinstance(env, VecNovelGridworld) else None
@@ -55,7 +56,7 @@ class LidarInFront(NoveltyWrapper):
         """lidar signal + inventory of the current state (:67-78)."""
         if self._vec is not None:
             self._ensure(self._vec)
-            return self._vec.lidar_observation(copy=True)
+            return self._vec.lidar_observation(copy=self._copy)
         base = self._base()
         vec = base._backend()
         base._push(vec)                     # host attributes are the truth between calls (envs.py)

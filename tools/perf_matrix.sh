@@ -24,9 +24,11 @@ timeout -k 10 300 python tools/reset_time.py C2 C3 C4 C5 X1 X2 X3 > $OUT/reset_t
 NGW_FAST_RESET=0 timeout -k 10 300 python tools/reset_time.py > $OUT/reset_time_general.log 2>&1
 timeout -k 10 100 python tools/adapter_latency.py > $OUT/adapter.log 2>&1
 timeout -k 10 200 python tools/api_latency.py > $OUT/api.log 2>&1
+timeout -k 10 300 python tools/lidar_rate.py > $OUT/lidar.log 2>&1
+ROUND=matrix_$ROUND bash tools/ab_stage.sh > $OUT/ab_stage.log 2>&1
 if [ -f gym_novel_gridworlds_amd/libngw_hip_stamps.so ]; then
   NGW_LIB=$PWD/gym_novel_gridworlds_amd/libngw_hip_stamps.so timeout -k 10 300 python tools/stamp_timeline.py C2 C3 C4 C5 > $OUT/stamps.log 2>&1
-  NGW_LIB=$PWD/gym_novel_gridworlds_amd/libngw_hip_stamps.so NGW_LEAN=0 timeout -k 10 300 python tools/stamp_timeline.py C2 > $OUT/stamps_general.log 2>&1
+  NGW_LIB=$PWD/gym_novel_gridworlds_amd/libngw_hip_stamps.so NGW_NOSTAGE=0 timeout -k 10 300 python tools/stamp_timeline.py C2 > $OUT/stamps_staged.log 2>&1
   NGW_LIB=$PWD/gym_novel_gridworlds_amd/libngw_hip_stamps.so timeout -k 10 300 python tools/stamp_reset.py C3 C5 X1 > $OUT/stamps_reset.log 2>&1
 fi
 echo matrix done

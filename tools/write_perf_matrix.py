@@ -15,8 +15,7 @@ def trim(x):
          'resets_in_timed_region': x['resets_in_timed_region'], 'roofline_frac': r['frac'], 'roofline_bytes_model': r.get('bytes_model'),
          'kernel_us_avg': round(r['kernel_ms_avg'] * 1e3, 3), 'traffic_bytes': r.get('traffic'),
          'frac_on_measured_traffic': r.get('frac_of_peak_on_measured_traffic'), 'prepared_episodes': x.get('prepared_episodes')}
-    if 'frac_on_survey_8d_bytes' in r:
-        o['survey_8d_bytes_over_time_over_peak'] = r['frac_on_survey_8d_bytes']
+    o['kernel'] = r.get('kernel')
     if 'gather' in x:
         o['gather'] = {k: x['gather'][k] for k in ('ms', 'GBps_into_root', 'payload_bytes_per_rank', 'ranks', 'backend')}
     if 'fused_rollout' in x:
@@ -27,6 +26,15 @@ def trim(x):
         o['staggered_prepared_G'] = round(x['staggered_resets']['prepared_next_episodes']['value'] / 1e9, 2)
     if 'api_mode' in x:
         o['api_mode_G'] = round(x['api_mode']['value'] / 1e9, 3)
+    if 'api_mode_lidar' in x:
+        o['api_mode_lidar_G'] = round(x['api_mode_lidar']['value'] / 1e9, 3)
+    if 'lidar' in x:
+        o['fused_lidar_us_per_step'] = {k: round(v['ms_per_step'] * 1e3, 2) for k, v in x['lidar'].items() if isinstance(v, dict)}
+    if 'repeats' in x:
+        o['repeats_us_device'] = {k: round(v * 1e3, 3) for k, v in x['repeats']['ms_per_step_device'].items()}
+    if 'cold_region' in x:
+        o['cold_region_us_per_step'] = round(x['cold_region']['ms_per_step'] * 1e3, 2)
+    o['roofline_frac_wall'] = r.get('frac_wall')
     if 'c1_single_env' in x:
         o['c1_steps_per_s'] = {k: v['value'] for k, v in x['c1_single_env'].items()}
     if 'cpu_baseline' in x:
@@ -56,7 +64,8 @@ for f, title in [('reset_time.log', 'Reset launches (`tools/reset_time.py`, HIP 
                  ('lidar.log', 'LidarInFront observation (`tools/lidar_rate.py`, C2, 8 beams)'),
                  ('adapter.log', 'Single-env adapter (`tools/adapter_latency.py`)'), ('api.log', 'Host API by batch size (`tools/api_latency.py`)'),
                  ('stamps.log', 'In-kernel timelines of one step launch (`tools/stamp_timeline.py`, stamps build)'),
-                 ('stamps_general.log', "The same for round 1's general kernel at C2 (`NGW_LEAN=0`)")]:
+                 ('stamps_staged.log', 'The same for the step kernel that stages the maps through LDS, at C2 (`NGW_NOSTAGE=0`)'),
+                 ('ab_stage.log', '10 x 10: map staged through LDS against map read in place, by batch size (`tools/ab_stage.sh`, 1000-step graph replay)')]:
     if os.path.exists(d + f):
         text = ''.join(ln for ln in open(d + f) if 'amdgpu.ids' not in ln).strip()
         if 'Traceback (most recent call last)' in text:
