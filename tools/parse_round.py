@@ -48,12 +48,12 @@ def bench_line(log):
 out = ['# rocprofv3 --kernel-trace --stats summaries (%s)\n' % ROUND,
        'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-side --steps 400 --warmup 100 '
        '--workload <W> [--mode rollout]`, and the driver\'s own `python3 bench.py --gpus 1 --steps 20 --warmup 5` (`tools/profile_round.sh %s`; raw CSVs under `gpurun_out/prof_%s/`).\n' % (ROUND, ROUND),
-       '**How to read the step-kernel durations.**  The step kernels of this round run 2.3-3.0 us of wave activity (in-kernel clock '
-       'stamps, `tools/stamp_timeline.py`, below) inside a 4.4-4.9 us launch period when the launches are replayed back to back from a '
+       '**How to read the step-kernel durations.**  The step kernels of this round run 2.0-2.6 us of wave activity (in-kernel clock '
+       'stamps, `tools/stamp_timeline.py`) inside a 3.7-4.9 us launch period when the launches are replayed back to back from a '
        'hipGraph (what `bench.py` times with a HIP event pair: the command processor prepares dispatch i+1 while dispatch i runs).  Under '
        '`rocprofv3 --kernel-trace` every dispatch is bracketed by profiling signals and its start stamp is taken when the packet is picked '
        'up, so a kernel this short shows its whole un-overlapped dispatch: the same bench command reports %s us per batched step while it '
-       'is being traced (its own JSON line below) against 4.3 us untraced, and the per-kernel average of the trace sits '
+       'is being traced (its own JSON line below) against 3.7-3.9 us untraced, and the per-kernel average of the trace sits '
        'between the two.  Both numbers are given; `roofline.achieved` uses the untraced event-pair average, as the bench contract says.\n',
        '**The ~1 600 `ngw_rollout_lean` + refill (`ngw_kernel<., 3, .>`) launches at the top of every table** are `bench.py`\'s 250 ms device clock '
        'warm-up on a SCRATCH handle (`--clock-warm-ms`), before anything is measured; the measured handle\'s launches are the `ngw_step_lean` rows '
@@ -127,7 +127,7 @@ wf = n_cal * 166 / (cal['WRITE_SIZE'] * 1024) if 'WRITE_SIZE' in cal else 1.0
 pm.append('## Calibration on a known byte count\n')
 pm.append('Staging-only diagnostic kernel (`ngw_debug_launch` mode 9) at 1 048 576 envs (state far beyond the 256 MiB Infinity Cache): every launch reads '
           '%d B and writes %d B.  FETCH_SIZE reported %.0f KiB -> factor **%.3f** (the guide\'s x2 for wide coalesced reads on gfx950), WRITE_SIZE %.0f KiB -> factor **%.3f**.  '
-          'The no-stage step kernels (C3, C5) read the map with byte loads, an access width the guide calls uncalibrated: their corrected read figure is an estimate '
+          'The step kernels read their few map cells with byte loads, an access width the guide calls uncalibrated: their corrected read figure is an estimate '
           '(L2 fills are 128-B lines either way; the expected line traffic, ~1.5 map lines + 57 B of scalars and inventory per env, agrees with it within 15 %%).\n'
           % (n_cal * 157, n_cal * 166, cal.get('FETCH_SIZE', 0), ff, cal.get('WRITE_SIZE', 0), wf))
 pm.append('## Step kernels\n')
@@ -146,11 +146,10 @@ for W in ('C2', 'C3', 'C4', 'C5'):
         traffic['%s_step' % W] = {'hbm_bytes_per_launch': round(total), 'env_steps_per_launch': n, 'hbm_bytes_per_env_step': round(total / n, 1),
                                   'source': 'profiles/%s_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x%.3f)' % (ROUND, ff)}
 pm.append('\nThe step kernels move well under the 2*S*S + 12*K + 45 bytes the survey prices for a read-pack-write design: the observation buffers are the '
-          'state, updated in place, and from 16 x 16 up a step reads only the map lines around the agent (no-stage kernel).  `bench.py` therefore prices the '
-          'no-stage workloads (C3, C5) on the bytes the design has to move (`roofline.bytes_model`, `design_bytes_per_env_step`: three 32-byte map sectors + the '
-          'inventory row + scalars + the write-through) and prints the survey figure beside it, labelled as not being a roofline fraction; the staged workloads '
-          '(C2, C4 - the configuration the metric is quoted on) stay on the survey figure.  `roofline.frac_of_peak_on_measured_traffic` divides the bytes of this '
-          'table by the launch time.\n')
+          'state, updated in place, and a step reads only the map lines around the agent (since round 4 at every map size: `ngw_step_lean<., false, ., .>`).  '
+          '`bench.py` prices `roofline.achieved` / `frac` on the survey figure for every workload (the figure all rounds are compared on - for the big maps it '
+          'exceeds 1, which says how the step compares with a read-pack-write design at the peak, not how busy HBM is), reports the bytes this design has to move '
+          'as a separate, labelled field (`design_bytes_per_env_step`) and divides the bytes of THIS table by the launch time in `frac_of_peak_on_measured_traffic`.\n')
 pm.append('## Other launches of the same passes\n')
 for W in ('C2', 'C3', 'C4', 'C5'):
     f_by, w_by = counters('pmc_%s_FETCH_SIZE' % W), counters('pmc_%s_WRITE_SIZE' % W)
@@ -198,8 +197,8 @@ if rows:
 # SQ
 pm.append('## SQ counters\n')
 pm.append('Two `--pmc` passes of 7 / 6 SQ counters each (the SQ block has 8 slots).  `SQ_WAVE_CYCLES`, `SQ_WAIT_*`, `SQ_ACTIVE_INST_*` count quad-cycles.\n')
-for label, dirs, pick, per in (('C2 step kernel `ngw_step_lean<0, true>` (per launch: 1024 waves, one batched step)', ('sq_step_1', 'sq_step_2'), 'step_lean', 1),
-                               ('C2 fused rollout `ngw_rollout_lean<0, false>` (200 steps per launch, prepared episodes off)', ('sq_rollout_1', 'sq_rollout_2'), 'rollout_lean', 200)):
+for label, dirs, pick, per in (('C2 step kernel `ngw_step_lean<0, false, false, false>` (per launch: 1024 waves, one batched step)', ('sq_step_1', 'sq_step_2'), 'step_lean', 1),
+                               ('C2 fused rollout `ngw_rollout_lean<0, false, false, false>` (200 steps per launch, prepared episodes off)', ('sq_rollout_1', 'sq_rollout_2'), 'rollout_lean', 200)):
     vals = {}
     for d in dirs:
         for (k, cn), v in counters(d).items():
