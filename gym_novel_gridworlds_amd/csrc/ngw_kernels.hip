@@ -27,6 +27,16 @@
 #include "../../include/ngw.h"
 #include "ngw_device.h"
 
+// The library is built from this file SIX times, in parallel (Makefile): -DNGW_PART=n keeps the launchers - and with them the
+// kernel instantiations - of one part; without NGW_PART (make asm) everything is in one unit.
+//   0: ngw_launch + the general kernel   1: step kernels   2 / 3 / 4: rollout kernels per map addressing mode
+//   5: new-episode (reset_fast), lidar, diff / wire / pack / agent-view kernels
+#ifdef NGW_PART
+#define NGW_HAS(p) (NGW_PART == (p))
+#else
+#define NGW_HAS(p) 1
+#endif
+
 static_assert(NGW_MAX_PASSES == 4, "ResetArgs carries four pass words");
 static_assert(sizeof(NgwDevSpec) % 4 == 0, "the spec blob is copied to LDS by dwords");
 
@@ -1176,6 +1186,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_lidar_kernel(const NgwLaunch a) {
     lidar_epilogue(a, lds, tid, live, mp + r * S + c, f, lds_inv + tid * a.KP);     // (its first barrier makes the staging visible)
 }
 
+#if NGW_HAS(5)
 // Delta refresh of a host mirror (NgwDiff, ngw_step_host): region blockIdx.y is compared, 16 bytes at a time, with the shadow
 // copy of what the host holds; only pieces that differ are stored - to the shadow, and straight into the host's page-locked
 // mirror across PCIe (mapped memory).  A step changes a few bytes of an env's map / inventory, so this moves ~1 % of what a
@@ -1255,9 +1266,11 @@ __global__ __launch_bounds__(256) void ngw_agent_view_kernel(const int8_t* __res
     }
     out[t] = word;
 }
+#endif  // NGW_HAS(5)
 
 }  // namespace
 
+#if NGW_HAS(5)
 extern "C" hipError_t ngw_pack_launch(const NgwPack* p, hipStream_t stream) {
     if (p->n_regions < 1) return hipSuccess;
     uint64_t most = 0;
@@ -1309,9 +1322,11 @@ extern "C" hipError_t ngw_lidar_launch(const NgwLaunch* a, int map_mode, unsigne
     }
     return hipGetLastError();
 }
+#endif  // NGW_HAS(5)
 
 namespace {
 
+#if NGW_HAS(0)
 template <int MAPMODE, int MODE, bool LIDAR>
 hipError_t launch_one(const NgwDevSpec* dspec, const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     // CDNA4 has 160 KiB of LDS per CU; anything above the 64 KiB default needs an explicit opt-in per device.
@@ -1344,9 +1359,11 @@ static hipError_t launch_general(const NgwDevSpec* dspec, const NgwLaunch* a, bo
 }
 
 __global__ void ngw_nop_kernel(const NgwDevSpec* dspec, const NgwLaunch a) {}
+#endif  // NGW_HAS(0)
 
 }  // namespace
 
+#if NGW_HAS(5)
 extern "C" hipError_t ngw_reset_fast_launch(const NgwDevSpec* dspec, const NgwResetFast* a, int nw, int subset, unsigned grid, size_t lds_bytes,
                                             hipStream_t stream) {
     const void* fn = nullptr;
@@ -1361,8 +1378,64 @@ extern "C" hipError_t ngw_reset_fast_launch(const NgwDevSpec* dspec, const NgwRe
     void* args[] = {const_cast<NgwDevSpec**>(&dspec), const_cast<NgwResetFast*>(a)};
     return hipLaunchKernel(fn, dim3(grid), dim3(NGW_EPB), args, lds_bytes, stream);
 }
+#endif  // NGW_HAS(5)
 
 // feat: 1 = fused LidarInFront epilogue, 2 = wrapper predicates (EXT), 8 = no-stage step (maps read in place)
+extern "C" hipError_t ngw_part_step(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int feat, unsigned grid, size_t lds_bytes,
+                                    hipStream_t stream);
+extern "C" hipError_t ngw_part_rollout_straight(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t ngw_part_rollout_dword(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t ngw_part_rollout_byte(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
+
+#if NGW_HAS(1)
+// ONE batched step(): ngw_step_lean
+extern "C" hipError_t ngw_part_step(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int feat, unsigned grid, size_t lds_bytes,
+                                    hipStream_t stream) {
+    const bool lidar = (feat & 1) != 0, ext = (feat & 2) != 0;
+    if (feat & 8) {                                                     // no-stage (the lidar epilogue needs the staged form)
+        if (lidar) return hipErrorInvalidValue;
+        return ext ? launch_lean<NGW_MAP_STRAIGHT, false, true, false>(dspec, a, grid, lds_bytes, stream)
+                   : launch_lean<NGW_MAP_STRAIGHT, false, false, false>(dspec, a, grid, lds_bytes, stream);
+    }
+#define NGW_LEAN_STEP(MM) (lidar ? (ext ? launch_lean<MM, true, true, true>(dspec, a, grid, lds_bytes, stream)      \
+                                        : launch_lean<MM, true, false, true>(dspec, a, grid, lds_bytes, stream))    \
+                                 : (ext ? launch_lean<MM, true, true, false>(dspec, a, grid, lds_bytes, stream)     \
+                                        : launch_lean<MM, true, false, false>(dspec, a, grid, lds_bytes, stream)))
+    switch (map_mode) {
+    case NGW_MAP_STRAIGHT: return NGW_LEAN_STEP(NGW_MAP_STRAIGHT);
+    case NGW_MAP_DWORD: return NGW_LEAN_STEP(NGW_MAP_DWORD);
+    default: return NGW_LEAN_STEP(NGW_MAP_BYTE);
+    }
+#undef NGW_LEAN_STEP
+}
+#endif  // NGW_HAS(1)
+
+// fused rollout: ngw_rollout_lean, one part per map addressing mode (eight kernels each: the heaviest to compile)
+#define NGW_ROLLOUT_PART(NAME, MM)                                                                                                     \
+    extern "C" hipError_t NAME(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream) { \
+        const bool lidar = (feat & 1) != 0, ext = (feat & 2) != 0;                                                                     \
+        if (a->mode == NGW_MODE_ROLLOUT_ACT)                                                                                           \
+            return lidar ? (ext ? launch_rollout_lean<MM, true, true, true>(dspec, a, grid, lds_bytes, stream)                         \
+                                : launch_rollout_lean<MM, true, false, true>(dspec, a, grid, lds_bytes, stream))                       \
+                         : (ext ? launch_rollout_lean<MM, true, true, false>(dspec, a, grid, lds_bytes, stream)                        \
+                                : launch_rollout_lean<MM, true, false, false>(dspec, a, grid, lds_bytes, stream));                     \
+        return lidar ? (ext ? launch_rollout_lean<MM, false, true, true>(dspec, a, grid, lds_bytes, stream)                            \
+                            : launch_rollout_lean<MM, false, false, true>(dspec, a, grid, lds_bytes, stream))                          \
+                     : (ext ? launch_rollout_lean<MM, false, true, false>(dspec, a, grid, lds_bytes, stream)                           \
+                            : launch_rollout_lean<MM, false, false, false>(dspec, a, grid, lds_bytes, stream));                        \
+    }
+#if NGW_HAS(2)
+NGW_ROLLOUT_PART(ngw_part_rollout_straight, NGW_MAP_STRAIGHT)
+#endif
+#if NGW_HAS(3)
+NGW_ROLLOUT_PART(ngw_part_rollout_dword, NGW_MAP_DWORD)
+#endif
+#if NGW_HAS(4)
+NGW_ROLLOUT_PART(ngw_part_rollout_byte, NGW_MAP_BYTE)
+#endif
+#undef NGW_ROLLOUT_PART
+
+#if NGW_HAS(0)
 extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int feat, unsigned grid,
                                  size_t lds_bytes, hipStream_t stream) {
     if (a->mode >= 10 && a->mode <= 12) {       // diagnostics: empty kernels with other workgroup shapes over the same lanes
@@ -1370,42 +1443,19 @@ extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, in
         hipLaunchKernelGGL(ngw_nop_kernel, dim3(grid * NGW_EPB / tpb), dim3(tpb), a->mode == 12 ? lds_bytes * 2 : 0, stream, dspec, *a);
         return hipGetLastError();
     }
-    const bool lidar = (feat & 1) != 0, ext = (feat & 2) != 0;
-    if (a->mode == NGW_MODE_STEP) {                                     // ONE batched step(): ngw_step_lean
-        if (feat & 8) {                                                 // no-stage (the lidar epilogue needs the staged form)
-            if (lidar) return hipErrorInvalidValue;
-            return ext ? launch_lean<NGW_MAP_STRAIGHT, false, true, false>(dspec, a, grid, lds_bytes, stream)
-                       : launch_lean<NGW_MAP_STRAIGHT, false, false, false>(dspec, a, grid, lds_bytes, stream);
-        }
-#define NGW_LEAN_STEP(MM) (lidar ? (ext ? launch_lean<MM, true, true, true>(dspec, a, grid, lds_bytes, stream)      \
-                                        : launch_lean<MM, true, false, true>(dspec, a, grid, lds_bytes, stream))    \
-                                 : (ext ? launch_lean<MM, true, true, false>(dspec, a, grid, lds_bytes, stream)     \
-                                        : launch_lean<MM, true, false, false>(dspec, a, grid, lds_bytes, stream)))
+    if (a->mode == NGW_MODE_STEP) return ngw_part_step(dspec, a, map_mode, feat, grid, lds_bytes, stream);
+    if (a->mode == NGW_MODE_ROLLOUT || a->mode == NGW_MODE_ROLLOUT_ACT) {
         switch (map_mode) {
-        case NGW_MAP_STRAIGHT: return NGW_LEAN_STEP(NGW_MAP_STRAIGHT);
-        case NGW_MAP_DWORD: return NGW_LEAN_STEP(NGW_MAP_DWORD);
-        default: return NGW_LEAN_STEP(NGW_MAP_BYTE);
+        case NGW_MAP_STRAIGHT: return ngw_part_rollout_straight(dspec, a, feat, grid, lds_bytes, stream);
+        case NGW_MAP_DWORD: return ngw_part_rollout_dword(dspec, a, feat, grid, lds_bytes, stream);
+        default: return ngw_part_rollout_byte(dspec, a, feat, grid, lds_bytes, stream);
         }
-#undef NGW_LEAN_STEP
     }
-    if (a->mode == NGW_MODE_ROLLOUT || a->mode == NGW_MODE_ROLLOUT_ACT) {   // fused rollout: ngw_rollout_lean
-        const bool sup = a->mode == NGW_MODE_ROLLOUT_ACT;
-#define NGW_LEAN_RO2(MM, SUP) (lidar ? (ext ? launch_rollout_lean<MM, SUP, true, true>(dspec, a, grid, lds_bytes, stream)      \
-                                            : launch_rollout_lean<MM, SUP, false, true>(dspec, a, grid, lds_bytes, stream))    \
-                                     : (ext ? launch_rollout_lean<MM, SUP, true, false>(dspec, a, grid, lds_bytes, stream)     \
-                                            : launch_rollout_lean<MM, SUP, false, false>(dspec, a, grid, lds_bytes, stream)))
-#define NGW_LEAN_RO(MM) (sup ? NGW_LEAN_RO2(MM, true) : NGW_LEAN_RO2(MM, false))
-        switch (map_mode) {
-        case NGW_MAP_STRAIGHT: return NGW_LEAN_RO(NGW_MAP_STRAIGHT);
-        case NGW_MAP_DWORD: return NGW_LEAN_RO(NGW_MAP_DWORD);
-        default: return NGW_LEAN_RO(NGW_MAP_BYTE);
-        }
-#undef NGW_LEAN_RO
-#undef NGW_LEAN_RO2
-    }
+    const bool lidar = (feat & 1) != 0;
     switch (map_mode) {
     case NGW_MAP_STRAIGHT: return launch_general<NGW_MAP_STRAIGHT>(dspec, a, lidar, grid, lds_bytes, stream);
     case NGW_MAP_DWORD: return launch_general<NGW_MAP_DWORD>(dspec, a, lidar, grid, lds_bytes, stream);
     default: return launch_general<NGW_MAP_BYTE>(dspec, a, lidar, grid, lds_bytes, stream);
     }
 }
+#endif  // NGW_HAS(0)
