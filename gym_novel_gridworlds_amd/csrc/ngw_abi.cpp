@@ -257,46 +257,71 @@ int layout_lds(ngw_handle* h) {
     NgwLaunch& p = h->proto;
     const int S = p.S, S2 = p.S2;
     const uint32_t guard = h->lidar_fused ? (uint32_t)((h->lidar_range * (S + 1) + 15) / 16 * 4) : 0u;
-    uint32_t off = guard;
-    p.off_map = off; off += (uint32_t)(NGW_EPB * p.MS / 4) + guard;
-    off = (off + 3u) & ~3u;
-    p.off_inv = off; off += (uint32_t)(p.KP * NGW_EPB);
-    p.off_cand = off; off += (uint32_t)(p.CW * NGW_EPB);
-    p.off_act = off; off += (uint32_t)(NGW_MAX_PLACE / 4);              // the placement sequence of the reset paths
-    p.perm_lds = 0; p.off_perm = off;
-    if (h->spec.n_passes) {
-        // Shuffle array in LDS only while the wave's LDS stays small (<= 32 KiB, 5 waves/CU).  Measured at S = 32: the
-        // extra 64 KiB halves the resident waves per CU and costs more (step 50 -> 115 us) than the HBM scratch column.
-        const uint32_t perm_dw = (uint32_t)(S2 * 32 * 2 / 4);
-        if ((size_t)(off + perm_dw) * 4 <= 32 * 1024) { p.perm_lds = 1; off += perm_dw; }
-    }
-    p.lcfg = nullptr; p.lout = nullptr; p.lidar_len = 0; p.off_litem = p.off_ltab = p.off_ltile = 0;
-    uint32_t tile_dw = 0;
+    auto waves_per_cu = [](uint32_t dwords) { return (160u * 1024u) / (((dwords * 4u + 511u) / 512u) * 512u); };
+    // One pass over the regions.  `alias`: the lidar observation tile shares the candidate masks' region.  The masks are live only
+    // inside a new-episode path, and every epilogue that follows one zeroes the tile again (lidar_epilogue, zeroed = false), so the
+    // two never hold data at once; the Philox ring, which is live together with the masks, then sits behind them.
+    auto pass = [&](bool alias) -> uint32_t {
+        uint32_t off = guard;
+        p.off_map = off; off += (uint32_t)(NGW_EPB * p.MS / 4) + guard;
+        off = (off + 3u) & ~3u;
+        p.off_inv = off; off += (uint32_t)(p.KP * NGW_EPB);
+        const uint32_t cand_dw = (uint32_t)(p.CW * NGW_EPB);
+        uint32_t tile_dw = 0, tile_all = 0;
+        p.lcfg = nullptr; p.lout = nullptr; p.lidar_len = 0; p.off_litem = p.off_ltab = p.off_ltile = 0;
+        if (h->lidar_fused) {
+            lidar_format(h, p);
+            tile_dw = (uint32_t)(NGW_EPB * p.l_rb / 4);                 // (l_rb is even: 64 rows are a whole number of 16-byte pieces)
+            tile_all = tile_dw + NGW_EPB / 4;                           // + one dump byte per lane (rays that report nothing store there)
+        }
+        off = (off + 3u) & ~3u;
+        p.off_cand = off;
+        if (alias) { p.off_ltile = off; off += cand_dw > tile_all ? cand_dw : tile_all; }
+        else off += cand_dw;
+        p.off_act = off; off += (uint32_t)(NGW_MAX_PLACE / 4);          // the placement sequence of the reset paths
+        p.perm_lds = 0; p.off_perm = off;
+        if (h->spec.n_passes) {
+            // Shuffle array in LDS only while the wave's LDS stays small (<= 32 KiB, 5 waves/CU).  Measured at S = 32: the
+            // extra 64 KiB halves the resident waves per CU and costs more (step 50 -> 115 us) than the HBM scratch column.
+            const uint32_t perm_dw = (uint32_t)(S2 * 32 * 2 / 4);
+            if ((size_t)(off + perm_dw) * 4 <= 32 * 1024) { p.perm_lds = 1; off += perm_dw; }
+        }
+        if (h->lidar_fused) {
+            off = (off + 3u) & ~3u;
+            p.off_litem = off; off += 2 * NGW_MAX_ITEMS / 4;
+            off = (off + 3u) & ~3u;
+            p.off_ltab = off; if (!h->lidar_world) off += 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE * 2 / 4;
+            if (!alias) { p.off_ltile = off; off += tile_all; }
+        }
+        // Philox word ring of the reset path (ngw_kernels.hip PHILOX_RING, 8 KB).  With the fused lidar epilogue it shares the
+        // observation tile's region when that is big enough (the tile is rebuilt after any reset, the ring is dead by then): 8 KB
+        // more would take an int32-row wave past 40 KB and a CU from four resident waves to three - measured as 13.6 -> 21.7 us per
+        // batched step.  The ring is used when the reset has no shuffled-subset pass (those draw hundreds of words per lane:
+        // register blocks, PhiloxRegs) and when its LDS does not cost a resident wave per CU (C5: 76 KB + 8 KB would halve the occupancy).
+        h->off_rng = 0xFFFFFFFFu;                                      // = PhiloxRegs
+        if (h->spec.n_passes == 0) {
+            const uint32_t ring_dw = (uint32_t)(NGW_EPB * 32);
+            if (h->lidar_fused && !alias && tile_dw >= ring_dw) h->off_rng = p.off_ltile;
+            else if (h->lidar_fused && alias && tile_dw >= cand_dw + ring_dw) h->off_rng = p.off_ltile + cand_dw;
+            else if (waves_per_cu(off + ring_dw) == waves_per_cu(off) || waves_per_cu(off + ring_dw) >= 4) { h->off_rng = off; off += ring_dw; }
+        }
+        return off;
+    };
+    uint32_t off = pass(false);
+    bool alias = false;
     if (h->lidar_fused) {
-        lidar_format(h, p);
-        off = (off + 3u) & ~3u;
-        p.off_litem = off; off += 2 * NGW_MAX_ITEMS / 4;
-        off = (off + 3u) & ~3u;
-        p.off_ltab = off; if (!h->lidar_world) off += 4 * NGW_LIDAR_MAX_BEAMS * NGW_LIDAR_MAX_RANGE * 2 / 4;
-        tile_dw = (uint32_t)(NGW_EPB * p.l_rb / 4);                     // (l_rb is even: 64 rows are a whole number of 16-byte pieces)
-        p.off_ltile = off; off += tile_dw + NGW_EPB / 4;                // + one dump byte per lane (rays that report nothing store there)
-    }
-    // Philox word ring of the reset path (ngw_kernels.hip PHILOX_RING, 8 KB).  With the fused lidar epilogue it shares the
-    // observation tile's region when that is big enough (the tile is rebuilt after any reset, the ring is dead by then): 8 KB
-    // more would take an int32-row wave past 40 KB and a CU from four resident waves to three - measured as 13.6 -> 21.7 us per
-    // batched step.  The ring is used when the reset has no shuffled-subset pass (those draw hundreds of words per lane:
-    // register blocks, PhiloxRegs) and when its LDS does not cost a resident wave per CU (C5: 76 KB + 8 KB would halve the occupancy).
-    {
-        const bool passes = h->spec.n_passes != 0;
-        auto waves_per_cu = [](uint32_t dwords) { return (160u * 1024u) / (((dwords * 4u + 511u) / 512u) * 512u); };
-        h->off_rng = 0xFFFFFFFFu;                                  // = PhiloxRegs
-        if (!passes) {
-            if (h->lidar_fused && tile_dw >= NGW_EPB * 32) h->off_rng = p.off_ltile;
-            else if (waves_per_cu(off + NGW_EPB * 32) == waves_per_cu(off) || waves_per_cu(off + NGW_EPB * 32) >= 4) {
-                h->off_rng = off; off += (uint32_t)(NGW_EPB * 32);
-            }
+        // share only where it buys a resident wave per CU (32 x 32 with int16 / packed rows: 87 KB -> 80.5 KB, one wave -> two); the
+        // layouts of the small maps stay as they were measured.  NGW_LDS_ALIAS=0: A/B.
+        const char* v = getenv("NGW_LDS_ALIAS");
+        if (!(v && atoi(v) == 0)) {
+            const uint32_t off_alias = pass(true);
+            if (off_alias * 4u <= 160u * 1024u && ((size_t)off * 4 > 160 * 1024 || waves_per_cu(off_alias) > waves_per_cu(off))) { off = off_alias; alias = true; }
+            else off = pass(false);
         }
     }
+    if (getenv("NGW_DEBUG_LDS"))
+        fprintf(stderr, "[ngw] LDS per wavefront: %zu B (S = %d, lidar %d, tile over candidate masks %d, ring %s) -> %u waves per CU\n", (size_t)off * 4, S,
+                h->lidar_fused, (int)alias, h->off_rng == 0xFFFFFFFFu ? "registers" : "LDS", waves_per_cu(off));
     if ((size_t)off * 4 > 160 * 1024)
         return fail(NGW_E_INVALID_ARG, "map_size %d%s needs %zu B of LDS per wavefront (> 160 KiB)", S,
                     h->lidar_fused ? " with the fused lidar observation" : "", (size_t)off * 4);

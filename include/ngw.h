@@ -381,8 +381,8 @@ int ngw_get_terminal_obs(ngw_handle* h, int8_t* map, int32_t* loc, int32_t* faci
 int ngw_terminal_device_ptrs(ngw_handle* h, void** map, void** loc, void** facing, void** inv);
 
 /* Which per-launch step kernel this handle's ngw_step* calls run right now: *map_in_place = 1 - the one that reads the <= 14 map
- * cells a step needs straight from HBM (every map size but 10 x 10 and 6 x 6), 0 - the one that stages the wave's 64 maps through
- * LDS (10 x 10, 6 x 6, and any size while the fused lidar epilogue is on).  What bench.py prices its byte models on. */
+ * cells a step needs straight from HBM (the default at every map size), 0 - the one that stages the wave's 64 maps through
+ * LDS (any size while the fused lidar epilogue is on, or where NGW_NOSTAGE says so).  What bench.py names its kernel from. */
 int ngw_step_kernel_info(ngw_handle* h, int32_t* map_in_place);
 
 /* LidarInFront: configure once, then ngw_lidar() computes the observation of the CURRENT state of every env into a device

@@ -144,7 +144,9 @@ def test_lidar_wrapper_on_vec_env_follows_steps():
                                                   ('pogo10', 3000, 60, 5), ('bow20', 500, 40, 3), ('fire10h', 1500, 50, 4),
                                                   ('fencer10m', 800, 40, 0), ('crate12h', 600, 40, 2),
                                                   # staged maps of more than 64 sixteen-byte chunks: prepared rows reach the LDS copy in several rounds
-                                                  ('add36e', 150, 40, 3), ('add36e', 100, 30, 7)])
+                                                  ('add36e', 150, 40, 3), ('add36e', 100, 30, 7),
+                                                  # 32 x 32: the observation tile shares the candidate masks' LDS (layout_lds), inline and prepared resets
+                                                  ('add32', 128, 30, 3)])
 def test_fused_lidar_epilogue_matches_oracle(cfg, n, steps, prefetch):
     """ngw_lidar_fuse: reset / step / rollout launches refresh the lidar observation themselves; it equals the oracle's
     lidar of the oracle's state after every launch, and the plain state stays bit-exact too."""

@@ -1,7 +1,7 @@
 """Time the LidarInFront observation at C2 (65 536 envs, 10 x 10, 8 beams), device-resident: the plain step, the stand-alone lidar
 launch, and the step with the FUSED epilogue in every row format (int32 / int16 / packed) and with both marches (world-frame
 rays, per-lane table: NGW_LIDAR_WORLD=0), each as a 64-step hipGraph replayed 16 times (default prepared-episode cadence).
-    python tools/lidar_rate.py [n_envs] [workload: C2 | C3]"""
+    python tools/lidar_rate.py [n_envs] [workload: C2 | C3 | C5]"""
 import os
 import sys
 import time
@@ -14,7 +14,13 @@ from gym_novel_gridworlds_amd import VecNovelGridworld, _cabi, make_spec  # noqa
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 wl = sys.argv[2] if len(sys.argv) > 2 else 'C2'
-spec = make_spec('NovelGridworld-Pogostick-v1', 10) if wl == 'C2' else make_spec('NovelGridworld-Bow-v1', 20)
+if wl == 'C5':                                        # bench.py's C5: Pogostick-v1 + inject_novelty('additem','hard','arrow'), 32 x 32
+    from gym_novel_gridworlds_amd import apply_novelty
+    spec = make_spec('NovelGridworld-Pogostick-v1', 32)
+    np.random.seed(0)
+    apply_novelty(spec, 'additem', 'hard', 'arrow', '')
+else:
+    spec = make_spec('NovelGridworld-Pogostick-v1', 10) if wl == 'C2' else make_spec('NovelGridworld-Bow-v1', 20)
 A = len(spec.actions_id)
 L = _cabi.lib()
 acts = None
@@ -53,7 +59,7 @@ s.close()
 v = env()
 replay(v, 'plain step')
 v.close()
-for world in ('', '1', '0'):
+for world in (('', '1', '0') if os.environ.get('NGW_LIDAR_SWEEP', '1') != '0' else ('',)):
     os.environ.pop('NGW_LIDAR_WORLD', None)
     if world:
         os.environ['NGW_LIDAR_WORLD'] = world
