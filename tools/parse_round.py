@@ -19,6 +19,21 @@ import sys
 ROUND = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tree_commit():
+    """HEAD of the tree being parsed, taken BEFORE this script writes anything: '-dirty' only if a file outside profiles/ (this script's
+    own output directory) differs from HEAD.  The GPU box gets a snapshot without .git, so the tree gpurun sent is the one parsed here."""
+    import subprocess
+    try:
+        head = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+        dirt = subprocess.run(['git', 'status', '--porcelain', '--', '.', ':(exclude)profiles'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    except OSError:
+        return 'unknown'
+    return (head or 'unknown') + ('-dirty' if dirt else '') + ' (tree at parse time)'
+
+
+TREE_COMMIT = _tree_commit()
 SRC = os.path.join(ROOT, 'gpurun_out', 'prof_' + ROUND)
 DST = os.path.join(ROOT, 'profiles')
 WL = {'C2': (65536, 353, 'Pogostick-v1 10x10, 65 536 envs'), 'C3': (65536, 953, 'Bow-v1 20x20, 65 536 envs'),
@@ -300,12 +315,8 @@ def _read(name):
 
 
 commit = _read('commit.txt')
-if commit == 'unknown':                                  # (the GPU box gets a snapshot without .git: the tree that was sent is the one parsed here)
-    import subprocess
-    try:
-        commit = subprocess.run(['git', 'describe', '--always', '--dirty'], cwd=ROOT, capture_output=True, text=True).stdout.strip() + ' (tree at parse time)'
-    except OSError:
-        pass
+if commit == 'unknown':                                  # (no .git on the GPU box)
+    commit = TREE_COMMIT
 traffic['_provenance'] = {'round': ROUND, 'commit': commit, 'measured': _read('date.txt'),
                           'how': 'tools/profile_round.sh %s on one MI355X (gpurun), parsed by tools/parse_round.py' % ROUND}
 json.dump(traffic, open(os.path.join(DST, 'pmc_traffic.json'), 'w'), indent=1)
