@@ -61,6 +61,7 @@ struct ngw_handle {
     uint8_t* mirror_dev = nullptr;
     bool mirror_valid = false;
     int host_delta = 1;                   // NGW_HOST_DELTA=0: every ngw_step_host copies the whole observation (A/B)
+    int wire_direct = 1;                  // NGW_WIRE_DIRECT=0: ngw_step_host_packed narrows into device staging and copies it across (A/B)
     size_t zc_bytes = (size_t)256 << 10;  // NGW_ZC_BYTES: largest ngw_step_host result written straight into mapped host memory (read at ngw_create)
     std::vector<void*> allocs;
     std::vector<void*> host_allocs;       // single-wavefront handles: the host mirror of the state (GPU-addressable page-locked memory)
@@ -716,6 +717,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     if (const char* v = getenv("NGW_FAST_RESET")) h->fast_reset = atoi(v);
     if (const char* v = getenv("NGW_ADAPT_PREFETCH")) h->adapt = atoi(v) != 0;
     if (const char* v = getenv("NGW_HOST_DELTA")) h->host_delta = atoi(v) != 0;
+    if (const char* v = getenv("NGW_WIRE_DIRECT")) h->wire_direct = atoi(v) != 0;
     if (const char* v = getenv("NGW_ZC_BYTES")) { h->zc_bytes = (size_t)atoll(v); if (!h->zc_bytes) h->zc_bytes = 1; }
     {
         // Which per-launch step kernel: the one that reads the <= 14 cells a step needs straight from HBM, at EVERY map size.  Up to
@@ -1608,12 +1610,15 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
     }
     NgwWire w = {};
     w.loc = h->b.loc; w.facing = h->b.facing; w.selected = h->b.selected; w.reward = h->b.reward; w.done = h->b.done; w.info = h->b.info; w.flags = h->b.flags;
-    uint8_t* const st = h->wire_stage - off[2];                       // (staging holds sections 2 .. 6 at their block offsets)
+    // In delta mode the block is mapped into the GPU's address space (mirror_dev): the narrowing kernel stores pose / reward / done /
+    // info straight into it across PCIe, like the delta kernel before it - no staging, no copy operation behind the kernels.
+    const bool direct = h->wire_direct && delta;
+    uint8_t* const st = direct ? h->mirror_dev : h->wire_stage - off[2];   // (staging holds sections 2 .. 6 at their block offsets)
     w.pose = reinterpret_cast<uint32_t*>(st + off[2]); w.reward16 = reinterpret_cast<int16_t*>(st + off[3]); w.done8 = st + off[4];
     w.info32 = reinterpret_cast<uint32_t*>(st + off[5]); w.flags_out = reinterpret_cast<uint32_t*>(st + off[6]);
     w.n = (int64_t)n;
     HIP_TRY(ngw_wire_launch(&w, h->stream));
-    HIP_TRY(hipMemcpyAsync(blk + off[2], h->wire_stage, (size_t)(off[7] - off[2]), hipMemcpyDefault, h->stream));
+    if (!direct) HIP_TRY(hipMemcpyAsync(blk + off[2], h->wire_stage, (size_t)(off[7] - off[2]), hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     // (a delta step that skipped the map leaves the map's shadow describing what the block holds: the next step that wants the map
     //  brings every change since across)

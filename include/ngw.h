@@ -363,7 +363,8 @@ int ngw_unpack_obs(ngw_handle* h, const void* payloads_dev, int32_t world, int8_
  * ngw_step_host_packed(h, actions, block, with_map): int32 actions from host memory are validated and narrowed to bytes on the way
  * into a buffer the step kernel reads in place (no copy call); map and inventory are refreshed by deltas as in ngw_step_host (the block
  * is a mirror the caller hands in call after call; with_map = 0 skips the map's delta for this call); the dense sections 2-6 - 11 B per
- * env instead of the 26 B of the int32 arrays - come back with one copy.  Widening (pose bytes -> int32 arrays) is the caller's, when
+ * env instead of the 26 B of the int32 arrays - are stored straight into the block by the narrowing kernel once the block is a mirror (mapped
+ * into the GPU's address space; the first call on a block, and a block that cannot be mapped, bring them across with one copy).  Widening (pose bytes -> int32 arrays) is the caller's, when
  * he needs it.  Rewards travel as int16: a spec with a larger reward is refused (NGW_E_INVALID_ARG; use ngw_step_host). */
 int ngw_host_step_layout_packed(ngw_handle* h, uint64_t* offsets8);
 int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block, int with_map);
