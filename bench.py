@@ -454,8 +454,10 @@ def main():
         f_dt = time.perf_counter() - t1
         fused = {'value': round(n * steps / f_dt, 1), 'unit': 'env-steps/s', 'ms_per_step': round(f_dt / steps * 1e3, 6), 'kernel_ms': round(f_ms, 4),
                  'bound': 'issue',
-                 'what': 'ngw_rollout: all %d steps in ONE launch, uniform actions generated in-kernel, state kept in LDS, only the bytes '
-                         'a step changes are written through to the observation buffers (instruction-issue bound; not an HBM figure)' % steps}
+                 'what': 'ONE ngw_rollout call of %d steps, uniform actions generated in-kernel, state kept in LDS between the steps of a launch, only the bytes '
+                         'a step changes are written through to the observation buffers (instruction-issue bound; not an HBM figure).  With prepared next '
+                         'episodes on (the default, reset_prefetch %d) the library issues the call as one launch per refill interval with a refill launch '
+                         'between them; inline_resets_one_launch is the same call with prepared episodes off' % (steps, v.reset_prefetch)}
         tr, src = traffic_of('rollout', n * steps)
         if tr:
             fused['hbm_traffic_bytes'], fused['traffic_source'] = tr, src
@@ -474,6 +476,22 @@ def main():
             fused['with_supplied_actions'] = {'value': round(n * rows_a / (a_ms * 1e-3), 1), 'unit': 'env-steps/s',
                                               'ms_per_step': round(a_ms / rows_a, 6), 'steps': rows_a,
                                               'what': 'ngw_rollout_actions: one launch, step t reads the [t, :] int32 action row resident in HBM'}
+        # the same call with prepared episodes off: ONE launch, resets placed inline by the lanes that need them.  Faster when the
+        # whole batch ends its episodes together (as here), several times slower when episode ends are spread (staggered_resets below).
+        if v.reset_prefetch:
+            keep = v.reset_prefetch
+            v.set_reset_prefetch(0)
+            v.rollout(max(warmup, 1), ACTION_SEED, 2 * 10 ** 6)
+            fence()
+            v.timing_begin()
+            t1 = time.perf_counter()
+            v.rollout(steps, ACTION_SEED, 2 * 10 ** 6 + warmup)
+            i_ms = v.timing_end()
+            fence()
+            i_dt = time.perf_counter() - t1
+            fused['inline_resets_one_launch'] = {'value': round(n * steps / i_dt, 1), 'unit': 'env-steps/s', 'ms_per_step': round(i_dt / steps * 1e3, 6),
+                                                 'kernel_ms': round(i_ms, 4), 'steps': steps}
+            v.set_reset_prefetch(keep)
         assert v.error_flags() == 0
 
     # side measurement: the SAME workload with episode ends spread over the batch (step_count offset e * 7919 % H: about
@@ -598,7 +616,7 @@ def main():
                        'fused_lidar': ({'format': args.lidar, 'row_bytes': v.lidar_row_bytes, 'row_len': v.lidar_len} if args.lidar else None),
                        'reset_prefetch': v.reset_prefetch,
                        'mode': ('one launch per batched step (%s), actions in HBM' % ('hipGraph replay' if use_graph else 'eager')) if args.mode == 'step'
-                               else 'fused rollout: all steps in one launch, actions generated in-kernel',
+                               else ('fused rollout: one ngw_rollout call, actions generated in-kernel; ' + ('one launch per refill interval (prepared next episodes, every %d steps)' % v.reset_prefetch if v.reset_prefetch else 'ONE launch, resets inline')),
                        'parallelism': 'envs sharded x%d, no collective in the step path' % world,
                        'dist': {'backend': (args.dist_backend + (' (RCCL)' if args.dist_backend == 'nccl' else '')) if world > 1 else None,
                                 'world_size_initialised': dist.get_world_size() if world > 1 else 1,
