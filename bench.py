@@ -456,8 +456,8 @@ def main():
                  'bound': 'issue',
                  'what': 'ONE ngw_rollout call of %d steps, uniform actions generated in-kernel, state kept in LDS between the steps of a launch, only the bytes '
                          'a step changes are written through to the observation buffers (instruction-issue bound; not an HBM figure).  With prepared next '
-                         'episodes on (the default, reset_prefetch %d) the library issues the call as one launch per refill interval with a refill launch '
-                         'between them; inline_resets_one_launch is the same call with prepared episodes off' % (steps, v.reset_prefetch)}
+                         'episodes on (the default; refill cadence %d) the library issues the call as horizon-sized launches (%d steps) with a refill launch '
+                         'after each; inline_resets_one_launch is the same call with prepared episodes off' % (steps, v.reset_prefetch, HORIZON)}
         tr, src = traffic_of('rollout', n * steps)
         if tr:
             fused['hbm_traffic_bytes'], fused['traffic_source'] = tr, src
@@ -616,7 +616,7 @@ def main():
                        'fused_lidar': ({'format': args.lidar, 'row_bytes': v.lidar_row_bytes, 'row_len': v.lidar_len} if args.lidar else None),
                        'reset_prefetch': v.reset_prefetch,
                        'mode': ('one launch per batched step (%s), actions in HBM' % ('hipGraph replay' if use_graph else 'eager')) if args.mode == 'step'
-                               else ('fused rollout: one ngw_rollout call, actions generated in-kernel; ' + ('one launch per refill interval (prepared next episodes, every %d steps)' % v.reset_prefetch if v.reset_prefetch else 'ONE launch, resets inline')),
+                               else ('fused rollout: one ngw_rollout call, actions generated in-kernel; ' + ('horizon-sized launches (%d steps) with a refill launch after each (prepared next episodes, cadence %d)' % (HORIZON, v.reset_prefetch) if v.reset_prefetch else 'ONE launch, resets inline')),
                        'parallelism': 'envs sharded x%d, no collective in the step path' % world,
                        'dist': {'backend': (args.dist_backend + (' (RCCL)' if args.dist_backend == 'nccl' else '')) if world > 1 else None,
                                 'world_size_initialised': dist.get_world_size() if world > 1 else 1,
