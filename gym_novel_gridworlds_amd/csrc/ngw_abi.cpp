@@ -61,6 +61,7 @@ struct ngw_handle {
     uint8_t* mirror_dev = nullptr;
     bool mirror_valid = false;
     int host_delta = 1;                   // NGW_HOST_DELTA=0: every ngw_step_host copies the whole observation (A/B)
+    int wire_merge = 1;                   // NGW_WIRE_MERGE=0: delta refresh and narrowing as two launches (A/B)
     int wire_direct = 1;                  // NGW_WIRE_DIRECT=0: ngw_step_host_packed narrows into device staging and copies it across (A/B)
     size_t zc_bytes = (size_t)256 << 10;  // NGW_ZC_BYTES: largest ngw_step_host result written straight into mapped host memory (read at ngw_create)
     std::vector<void*> allocs;
@@ -718,6 +719,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     if (const char* v = getenv("NGW_ADAPT_PREFETCH")) h->adapt = atoi(v) != 0;
     if (const char* v = getenv("NGW_HOST_DELTA")) h->host_delta = atoi(v) != 0;
     if (const char* v = getenv("NGW_WIRE_DIRECT")) h->wire_direct = atoi(v) != 0;
+    if (const char* v = getenv("NGW_WIRE_MERGE")) h->wire_merge = atoi(v) != 0;
     if (const char* v = getenv("NGW_ZC_BYTES")) { h->zc_bytes = (size_t)atoll(v); if (!h->zc_bytes) h->zc_bytes = 1; }
     {
         // Which per-launch step kernel: the one that reads the <= 14 cells a step needs straight from HBM, at EVERY map size.  Up to
@@ -1587,14 +1589,15 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
     uint8_t* const blk = static_cast<uint8_t*>(block);
     const void* const srcs[2] = {h->b.map, h->b.inv};
     const uint64_t nb[2] = {n * S2, n * K * 4};
+    NgwDiff d = {};
+    const bool merged = delta && h->wire_direct && h->wire_merge;     // steady state: delta refresh + narrowing in one launch (below)
     if (delta) {
-        NgwDiff d = {};
         int k = 0;
         for (int r = with_map ? 0 : 1; r < 2; r++, k++) {
             d.cur[k] = static_cast<const uint8_t*>(srcs[r]); d.shadow[k] = h->shadow[r]; d.host[k] = h->mirror_dev + off[r]; d.nbytes[k] = nb[r];
         }
         d.n_regions = k;
-        HIP_TRY(ngw_diff_launch(&d, h->stream));
+        if (!merged) HIP_TRY(ngw_diff_launch(&d, h->stream));
     } else {
         for (int r = 0; r < 2; r++) HIP_TRY(hipMemcpyAsync(blk + off[r], srcs[r], (size_t)nb[r], hipMemcpyDefault, h->stream));
         if (h->host_delta) {                                          // (re-)seed the shadows: the block mirrors the state from here on
@@ -1617,7 +1620,8 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
     w.pose = reinterpret_cast<uint32_t*>(st + off[2]); w.reward16 = reinterpret_cast<int16_t*>(st + off[3]); w.done8 = st + off[4];
     w.info32 = reinterpret_cast<uint32_t*>(st + off[5]); w.flags_out = reinterpret_cast<uint32_t*>(st + off[6]);
     w.n = (int64_t)n;
-    HIP_TRY(ngw_wire_launch(&w, h->stream));
+    if (merged) HIP_TRY(ngw_diff_wire_launch(&d, &w, h->stream));
+    else HIP_TRY(ngw_wire_launch(&w, h->stream));
     if (!direct) HIP_TRY(hipMemcpyAsync(blk + off[2], h->wire_stage, (size_t)(off[7] - off[2]), hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     // (a delta step that skipped the map leaves the map's shadow describing what the block holds: the next step that wants the map

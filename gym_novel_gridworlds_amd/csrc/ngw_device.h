@@ -312,6 +312,11 @@ hipError_t ngw_wire_launch(const struct NgwWire* p, hipStream_t stream);
 #ifdef __cplusplus
 extern "C"
 #endif
+/* delta refresh (NgwDiff) and narrowing (NgwWire) as ONE launch */
+hipError_t ngw_diff_wire_launch(const struct NgwDiff* p, const struct NgwWire* w, hipStream_t stream);
+#ifdef __cplusplus
+extern "C"
+#endif
 /* AgentMap window gather: out = [n][2V+1][2V+1] int8 packed as n_dwords dwords */
 hipError_t ngw_agent_view_launch(const int8_t* map, const int32_t* loc, uint32_t* out, uint32_t n_dwords, int S, int V,
                                  hipStream_t stream);

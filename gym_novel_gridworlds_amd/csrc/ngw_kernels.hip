@@ -1225,6 +1225,39 @@ __global__ __launch_bounds__(256) void ngw_wire_kernel(const NgwWire p) {
     p.info32[e] = p.info[e];
 }
 
+// Delta refresh and narrowing in ONE launch (ngw_step_host_packed's steady state: the block is a mirror and takes direct stores): slices
+// y < n_regions are ngw_diff_kernel's regions, the last slice narrows pose / reward / done / info with a grid-stride loop over the envs.
+__global__ __launch_bounds__(256) void ngw_diff_wire_kernel(const NgwDiff p, const NgwWire w) {
+    const int r = blockIdx.y;
+    const uint64_t stride = (uint64_t)gridDim.x * 256u, t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (r == p.n_regions) {
+        if (t == 0) *w.flags_out = *w.flags;
+        for (uint64_t e = t; e < (uint64_t)w.n; e += stride) {
+            const int rr = w.loc[2 * e], c = w.loc[2 * e + 1], f = w.facing[e];
+            const uint32_t sel = w.selected[e];
+            w.pose[e] = (uint32_t)(rr & 255) | ((uint32_t)(c & 255) << 8) | ((uint32_t)(f & 255) << 16) | (sel << 24);
+            w.reward16[e] = (int16_t)w.reward[e];
+            w.done8[e] = w.done[e];
+            w.info32[e] = w.info[e];
+        }
+        return;
+    }
+    const uint64_t nb = p.nbytes[r];
+    const uint8_t* c = p.cur[r];
+    uint8_t* s = p.shadow[r];
+    uint8_t* h = p.host[r];
+    const uint64_t n16 = nb >> 4;
+    for (uint64_t i = t; i < n16; i += stride) {
+        const u32x4 a = reinterpret_cast<const u32x4*>(c)[i], b = reinterpret_cast<const u32x4*>(s)[i];
+        if (a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w) {
+            reinterpret_cast<u32x4*>(s)[i] = a;
+            reinterpret_cast<u32x4*>(h)[i] = a;
+        }
+    }
+    for (uint64_t i = (n16 << 4) + t; i < nb; i += stride)
+        if (c[i] != s[i]) { s[i] = c[i]; h[i] = c[i]; }
+}
+
 // Region copies (NgwPack): region blockIdx.y, grid-stride over 16-byte pieces; tails and unaligned regions go by bytes.
 // The destination may be host memory mapped into the GPU's address space (the stores then travel over PCIe).
 __global__ __launch_bounds__(256) void ngw_pack_kernel(const NgwPack p) {
@@ -1295,6 +1328,16 @@ extern "C" hipError_t ngw_diff_launch(const NgwDiff* p, hipStream_t stream) {
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(ngw_diff_kernel, dim3((unsigned)blocks, (unsigned)p->n_regions), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t ngw_diff_wire_launch(const NgwDiff* p, const NgwWire* w, hipStream_t stream) {
+    uint64_t most = ((uint64_t)w->n + 15u) / 16u * 16u;                            // (the narrowing slice: one env per lane and round)
+    for (int r = 0; r < p->n_regions; r++) most = p->nbytes[r] > most ? p->nbytes[r] : most;
+    uint64_t blocks = (most / 16u + 255u) / 256u;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ngw_diff_wire_kernel, dim3((unsigned)blocks, (unsigned)p->n_regions + 1u), dim3(256), 0, stream, *p, *w);
     return hipGetLastError();
 }
 
