@@ -27,10 +27,10 @@
 #include "../../include/ngw.h"
 #include "ngw_device.h"
 
-// The library is built from this file SIX times, in parallel (Makefile): -DNGW_PART=n keeps the launchers - and with them the
+// The library is built from this file EIGHT times, in parallel (Makefile): -DNGW_PART=n keeps the launchers - and with them the
 // kernel instantiations - of one part; without NGW_PART (make asm) everything is in one unit.
-//   0: ngw_launch + the general kernel   1: step kernels   2 / 3 / 4: rollout kernels per map addressing mode
-//   5: new-episode (reset_fast), lidar, diff / wire / pack / agent-view kernels
+//   0: ngw_launch + the general kernel   1 / 6 / 7: step kernels per map addressing mode (1 also holds the in-place ones)
+//   2 / 3 / 4: rollout kernels per map addressing mode   5: new-episode (reset_fast), lidar, diff / wire / pack / agent-view kernels
 #ifdef NGW_PART
 #define NGW_HAS(p) (NGW_PART == (p))
 #else
@@ -1430,28 +1430,41 @@ extern "C" hipError_t ngw_part_rollout_straight(const NgwDevSpec* dspec, const N
 extern "C" hipError_t ngw_part_rollout_dword(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
 extern "C" hipError_t ngw_part_rollout_byte(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
 
+// ONE batched step(): ngw_step_lean.  The staged kernels of one map addressing mode (four each) are a unit of their own.
+#define NGW_STEP_PART(NAME, MM)                                                                                                         \
+    extern "C" hipError_t NAME(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream) { \
+        const bool lidar = (feat & 1) != 0, ext = (feat & 2) != 0;                                                                      \
+        return lidar ? (ext ? launch_lean<MM, true, true, true>(dspec, a, grid, lds_bytes, stream)                                      \
+                            : launch_lean<MM, true, false, true>(dspec, a, grid, lds_bytes, stream))                                    \
+                     : (ext ? launch_lean<MM, true, true, false>(dspec, a, grid, lds_bytes, stream)                                     \
+                            : launch_lean<MM, true, false, false>(dspec, a, grid, lds_bytes, stream));                                  \
+    }
+extern "C" hipError_t ngw_part_step_straight(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t ngw_part_step_dword(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t ngw_part_step_byte(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
 #if NGW_HAS(1)
-// ONE batched step(): ngw_step_lean
+NGW_STEP_PART(ngw_part_step_straight, NGW_MAP_STRAIGHT)
 extern "C" hipError_t ngw_part_step(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int feat, unsigned grid, size_t lds_bytes,
                                     hipStream_t stream) {
-    const bool lidar = (feat & 1) != 0, ext = (feat & 2) != 0;
     if (feat & 8) {                                                     // no-stage (the lidar epilogue needs the staged form)
-        if (lidar) return hipErrorInvalidValue;
-        return ext ? launch_lean<NGW_MAP_STRAIGHT, false, true, false>(dspec, a, grid, lds_bytes, stream)
-                   : launch_lean<NGW_MAP_STRAIGHT, false, false, false>(dspec, a, grid, lds_bytes, stream);
+        if (feat & 1) return hipErrorInvalidValue;
+        return (feat & 2) ? launch_lean<NGW_MAP_STRAIGHT, false, true, false>(dspec, a, grid, lds_bytes, stream)
+                          : launch_lean<NGW_MAP_STRAIGHT, false, false, false>(dspec, a, grid, lds_bytes, stream);
     }
-#define NGW_LEAN_STEP(MM) (lidar ? (ext ? launch_lean<MM, true, true, true>(dspec, a, grid, lds_bytes, stream)      \
-                                        : launch_lean<MM, true, false, true>(dspec, a, grid, lds_bytes, stream))    \
-                                 : (ext ? launch_lean<MM, true, true, false>(dspec, a, grid, lds_bytes, stream)     \
-                                        : launch_lean<MM, true, false, false>(dspec, a, grid, lds_bytes, stream)))
     switch (map_mode) {
-    case NGW_MAP_STRAIGHT: return NGW_LEAN_STEP(NGW_MAP_STRAIGHT);
-    case NGW_MAP_DWORD: return NGW_LEAN_STEP(NGW_MAP_DWORD);
-    default: return NGW_LEAN_STEP(NGW_MAP_BYTE);
+    case NGW_MAP_STRAIGHT: return ngw_part_step_straight(dspec, a, feat, grid, lds_bytes, stream);
+    case NGW_MAP_DWORD: return ngw_part_step_dword(dspec, a, feat, grid, lds_bytes, stream);
+    default: return ngw_part_step_byte(dspec, a, feat, grid, lds_bytes, stream);
     }
-#undef NGW_LEAN_STEP
 }
 #endif  // NGW_HAS(1)
+#if NGW_HAS(6)
+NGW_STEP_PART(ngw_part_step_dword, NGW_MAP_DWORD)
+#endif
+#if NGW_HAS(7)
+NGW_STEP_PART(ngw_part_step_byte, NGW_MAP_BYTE)
+#endif
+#undef NGW_STEP_PART
 
 // fused rollout: ngw_rollout_lean, one part per map addressing mode (eight kernels each: the heaviest to compile)
 #define NGW_ROLLOUT_PART(NAME, MM)                                                                                                     \
