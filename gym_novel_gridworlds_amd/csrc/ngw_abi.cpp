@@ -537,7 +537,11 @@ void adapt_cadence(ngw_handle* h) {
         }
     } else {
         h->noisy = 0;
-        if (h->cadence < h->prefetch_every && (h->quiet += refills) >= h->quiet_need) {
+        // The upward probe needs reports that stand for a FEW refills each.  A replayed graph reports a whole replay at once (~55 refills at
+        // FireWall's cadence): averaged over that many a cadence looks quiet that is noisy refill by refill, every change re-captures the
+        // graph (~2 ms), and the eager steps around the replays take the change back - tools/x1_probe.py: 18 -> 36 -> 72 -> 36 with a 15 us
+        // region in between.  Such a report still tightens the cadence (above); it does not lengthen it.
+        if (refills <= 4 && h->cadence < h->prefetch_every && (h->quiet += refills) >= h->quiet_need) {
             h->cadence = h->cadence * 2 > h->prefetch_every ? h->prefetch_every : h->cadence * 2;
             h->quiet = 0;
             h->probing = true;
