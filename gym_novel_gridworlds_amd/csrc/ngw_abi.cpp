@@ -1568,6 +1568,11 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
         h->act_pin_dev = static_cast<uint8_t*>(d);
     }
     const int slot = h->act_next; h->act_next ^= 1;
+#ifdef NGW_HOSTTRACE
+    static double pA = 0, pB = 0, pC = 0, pD = 0; static int pn = 0;
+    auto pnow = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
+    const double p0 = pnow();
+#endif
     HIP_TRY(hipEventSynchronize(h->act_ev[slot]));
     uint8_t* const a8 = h->act_pin + (size_t)slot * cap;
     uint32_t bad = 0;
@@ -1584,6 +1589,9 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
     uint64_t off[8];
     host_step_layout_packed(h, off);
     if (!h->wire_stage) { if (int rc = dev_alloc(h, &h->wire_stage, (size_t)(off[7] - off[2]))) return rc; }
+#ifdef NGW_HOSTTRACE
+    const double p1 = pnow();                                          // actions validated and narrowed
+#endif
     const bool delta = h->host_delta && h->mirror_valid && h->mirror_block == block;
     h->launch_use_action0 = false; h->launch_act_u8 = true;
     const int lrc = launch(h, NGW_MODE_STEP, 1, reinterpret_cast<const int32_t*>(h->act_pin_dev + (size_t)slot * cap), nullptr, 0, 0);
@@ -1627,7 +1635,21 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
     if (merged) HIP_TRY(ngw_diff_wire_launch(&d, &w, h->stream));
     else HIP_TRY(ngw_wire_launch(&w, h->stream));
     if (!direct) HIP_TRY(hipMemcpyAsync(blk + off[2], h->wire_stage, (size_t)(off[7] - off[2]), hipMemcpyDefault, h->stream));
+#ifdef NGW_HOSTTRACE
+    const double p2 = pnow();                                          // everything enqueued
+#endif
     HIP_TRY(hipStreamSynchronize(h->stream));
+#ifdef NGW_HOSTTRACE
+    {
+        const double p3 = pnow();                                      // the device is done and the block is written
+        pA += p1 - p0; pB += p2 - p1; pC += p3 - p2; (void)pD;
+        if (++pn == 200) {
+            fprintf(stderr, "[hosttrace packed, %zu envs] narrow actions %.2f us, enqueue %.2f us, wait for the device %.2f us (merged %d, direct %d)\n", n, pA / pn, pB / pn, pC / pn,
+                    (int)merged, (int)direct);
+            pA = pB = pC = 0; pn = 0;
+        }
+    }
+#endif
     // (a delta step that skipped the map leaves the map's shadow describing what the block holds: the next step that wants the map
     //  brings every change since across)
     h->mirror_valid = h->host_delta && h->mirror_block == block;
