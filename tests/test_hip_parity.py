@@ -914,6 +914,42 @@ def test_refill_cadence_adapts_to_short_episodes_and_results_stay_exact():
     assert v.error_flags() == 0
 
 
+def test_graph_replay_reports_do_not_lengthen_the_refill_cadence():
+    """A replayed graph reports a whole replay's refills at once.  Averaged over that many, a cadence looks quiet that is noisy refill by
+    refill: the host used to probe a longer cadence right after the capture, re-capture the graph at every change and take the change back
+    from the eager steps around the replays (tools/x1_probe.py: 18 -> 36 -> 72 -> 36, one region at twice the time).  Such a report may
+    tighten the cadence, never lengthen it - and whatever the cadence is, the state stays the oracle's."""
+    if os.environ.get('NGW_ADAPT_PREFETCH') == '0':
+        pytest.skip('adaptation is switched off (NGW_ADAPT_PREFETCH=0)')
+    import torch
+    spec = T.build_spec('fire10h')
+    A = len(spec.actions_id)
+    n, G = 65536, 300
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=33, autoreset=True, horizon=100)
+    o = Oracle(spec.compile(), n, seed=33, autoreset=True, horizon=100)
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    acts = torch.randint(0, A, (G, n), dtype=torch.int32, device='cuda', generator=g)
+    torch.cuda.synchronize()
+    an = acts.cpu().numpy()
+    v.reset(); o.reset()
+    for i in range(21):                                    # a live loop: a report per refill, the cadence tightens
+        v.step_device_many(acts[100 * (i % 3)].data_ptr(), n, 100); v.sync()
+        for t in range(100):
+            o.step(an[100 * (i % 3) + t])
+    before = v.refill_cadence
+    assert before < v.reset_prefetch, 'FireWall hard at 65 536 envs tightens the refill cadence (precondition of this test)'
+    v.graph_build(acts.data_ptr(), n, G)
+    for rep in range(6):
+        v.graph_launch(1); v.sync()
+        for t in range(G):
+            o.step(an[t])
+        now = v.refill_cadence
+        assert now <= before, 'replay %d lengthened the refill cadence: %d -> %d' % (rep, before, now)
+        before = now
+    assert_state_equal(v, o, 'fire10h, graph replays after eager adaptation')
+    assert v.error_flags() == 0
+
+
 @pytest.mark.parametrize('pack', ['1', '0'])
 @pytest.mark.parametrize('cfg,n', [('add12m', 700), ('add18h', 500), ('add24m', 300), ('add29h', 200), ('add32', 260), ('add36e', 130), ('crate20h', 400),
                                    ('add11e', 300), ('fire10h', 700), ('fire14m', 300), ('replwall12e', 300), ('fire32m', 130)])
