@@ -231,29 +231,30 @@ def main():
         return int(v.get_state(0, 1)['episode'][0])
 
     cold = None
-    if args.clock_warm_ms > 0 and args.mode == 'step' and not args.no_side:
-        # the contract's shape on the device as this process found it (nothing has run on it yet): W warm-up + K timed eager steps
-        g0 = torch.Generator(device='cuda')
-        g0.manual_seed(ACTION_SEED + 31 + rank)
-        kc = min(steps, 200)
-        acts0 = torch.randint(0, A, (warmup + kc, n), dtype=torch.int32, device='cuda', generator=g0)
-        torch.cuda.synchronize()
-        v.reset()
-        if warmup:
-            v.step_device_many(acts0.data_ptr(), n, warmup)
-        v.sync(); torch.cuda.synchronize()
-        t0c = time.perf_counter()
-        v.step_device_many(acts0[warmup].data_ptr(), n, kc)
-        torch.cuda.synchronize()
-        dtc = time.perf_counter() - t0c
-        cold = {'ms_per_step': round(dtc / kc * 1e3, 6), 'value': round(n * kc / dtc, 1), 'steps': kc, 'warmup': warmup,
-                'what': 'the first W + K eager steps this process ran, before the %g ms device-clock warm-up that precedes the contract region' % args.clock_warm_ms}
-        del acts0
     if args.clock_warm_ms > 0:
-        # device clocks: a scratch handle of the same shape runs fused rollouts until the time is up; nothing of it is measured and
-        # the measured handle `v` is not touched (its W warm-up steps and K timed steps follow exactly as the contract says)
+        # A scratch handle of the same shape, never the measured one: (i) `cold_region` - the contract's shape (W warm-up + K timed eager
+        # steps) on the device as this process found it (nothing has run on it yet); (ii) the device-clock warm-up - fused rollouts until
+        # the time is up.  The measured handle `v` is not touched by either: its W warm-up steps and K timed steps follow as the contract says.
         from gym_novel_gridworlds_amd import VecNovelGridworld
         scratch = VecNovelGridworld(spec=spec, num_envs=n, seed=99, autoreset=True, horizon=HORIZON, device=local_rank)
+        if args.mode == 'step' and not args.no_side:
+            g0 = torch.Generator(device='cuda')
+            g0.manual_seed(ACTION_SEED + 31 + rank)
+            kc = min(steps, 200)
+            acts0 = torch.randint(0, A, (warmup + kc, n), dtype=torch.int32, device='cuda', generator=g0)
+            torch.cuda.synchronize()
+            scratch.reset()
+            if warmup:
+                scratch.step_device_many(acts0.data_ptr(), n, warmup)
+            scratch.sync(); torch.cuda.synchronize()
+            t0c = time.perf_counter()
+            scratch.step_device_many(acts0[warmup].data_ptr(), n, kc)
+            torch.cuda.synchronize()
+            dtc = time.perf_counter() - t0c
+            cold = {'ms_per_step': round(dtc / kc * 1e3, 6), 'value': round(n * kc / dtc, 1), 'steps': kc, 'warmup': warmup,
+                    'what': 'the first W + K eager steps this process ran (on a scratch handle of the same shape), before the %g ms device-clock warm-up '
+                            'that precedes the contract region' % args.clock_warm_ms}
+            del acts0
         scratch.reset()
         t_end = time.perf_counter() + args.clock_warm_ms * 1e-3
         while time.perf_counter() < t_end:
@@ -381,14 +382,22 @@ def main():
         med = lambda xs: xs[len(xs) // 2]
         repeats = {'n': args.repeats, 'ms_per_step_wall': {'median': round(med(wall_m), 6), 'min': round(wall_m[0], 6), 'max': round(wall_m[-1], 6)},
                    'ms_per_step_device': {'median': round(med(dev_m), 6), 'min': round(dev_m[0], 6), 'max': round(dev_m[-1], 6)},
-                   'value_median': round(n * world / (med(wall_m) * 1e-3), 1)}
+                   'value_median': round(n * world / (med(wall_m) * 1e-3), 1), '_wall_all': wall_m, '_dev_all': dev_m}
 
-    # roofline: algorithmic bytes per launch / average launch duration (device time of the timed region / launches)
+    # The line's `value` / `ms_per_step`: the MEDIAN of the 1 + R regions of exactly K steps each (contract region first, same handle, same
+    # launches); the contract region alone is `value_contract` / `ms_per_step_contract`.  (One 20-step region is a 92-us sample of a 4-us
+    # step: round 4's driver line recorded 14.3 G from a region whose own repeats had a median of 12.5 G.)
+    wall_all = [dt / steps * 1e3] + (repeats['_wall_all'] if repeats else [])
+    dev_all = [dev_ms / steps] + (repeats['_dev_all'] if repeats else [])
+    if repeats:
+        del repeats['_wall_all'], repeats['_dev_all']
+    ms_step = sorted(wall_all)[len(wall_all) // 2] if args.mode == 'step' else dt / steps * 1e3
+    dev_step = sorted(dev_all)[len(dev_all) // 2] if args.mode == 'step' else dev_ms / steps
+
+    # roofline: SURVEY 8(d)'s algorithmic bytes per env-step x the envs of a launch / the launch period
     launches = 1 if args.mode == 'rollout' else steps
     steps_per_launch = steps if args.mode == 'rollout' else 1
-    launch_ms = dev_ms / launches
     B = algorithmic_bytes(S, K)
-    achieved = B * n * steps_per_launch / (launch_ms * 1e-3) / 1e9
     pmc_file = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     pmc = json.load(open(pmc_file)) if os.path.exists(pmc_file) else {}
 
@@ -401,36 +410,59 @@ def main():
         return None, None
 
     if args.mode == 'step':
-        # `achieved` / `frac`: SURVEY §8(d)'s algorithmic bytes per env-step x the envs of a launch over the average launch duration -
-        # the figure every round and every workload is priced on, whichever kernel ran.  The kernel that reads the map in place (every
-        # size but 10 x 10: ngw_step_kernel_info) legitimately never touches most of the 2*S*S bytes that model charges, so for it the
-        # figure can exceed 1: it says how the step compares with a read-pack-write design at the peak, not how busy HBM is.  What
-        # HBM really carries is `traffic` (PMC counters of this kernel, profiles/) and `frac_of_peak_on_measured_traffic`; the bytes
-        # this design has to move are `design_bytes_per_env_step`, a separate, labelled figure.
+        # `frac` is the figure anyone can recompute from this line and from profiles/: algorithmic bytes x envs / ms_per_step / peak (the
+        # WALL clock per step: it contains the launch gaps, the reset launches and the region's fixed start-up / wake-up cost).  The HIP
+        # event pair's figure (the launch period on the device alone) is `frac_event_pair`.  The in-place kernel never touches most of the
+        # 2*S*S bytes the model charges: what HBM really carries is `traffic` (PMC counters, profiles/) -> `traffic_frac`.  And the kernel
+        # is not bound by HBM at this batch size but by latency (one wave per SIMD): `floor` prices the launch as "empty-kernel launch
+        # period of this run + the stamped wave life" and `frac_of_floor` says how close the measured launch period is to that.
         in_place = bool(v.step_reads_map_in_place)
         D = design_bytes(S, K, in_place)
-        achieved = B * n * steps_per_launch / (launch_ms * 1e-3) / 1e9
-        wall_ms = dt / steps * 1e3
+        bytes_launch = B * n * steps_per_launch
+        achieved = bytes_launch / (ms_step * 1e-3) / 1e9
         roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
-                    'frac_wall': round(B * n * steps_per_launch / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'traffic_frac': None,
+                    'frac_event_pair': round(bytes_launch / (dev_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    'frac_contract_region': round(bytes_launch / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4),
                     'kernel': 'ngw_step_lean<%s>' % ('map read in place' if in_place else 'map staged through LDS'),
-                    'kernel_ms_avg': round(launch_ms, 6), 'launches_timed': launches,
+                    'launch_period_ms_wall': round(ms_step, 6), 'launch_period_ms_event_pair': round(dev_step, 6), 'launches_timed': launches,
                     'bytes_model': 'SURVEY 8(d) (2*S*S + 12*K + 45)',
                     'algorithmic_bytes_per_env_step': B, 'env_steps_per_launch': n * steps_per_launch,
                     'design_bytes_per_env_step': D,
                     'design_bytes_note': 'what this design has to move per env-step (state updated in place; %s): not the model `frac` is priced on'
                                          % ('three 32-byte map sectors instead of the map row' if in_place else 'the whole map row is read'),
-                    'frac_on_design_bytes': round(D * n * steps_per_launch / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    'timing': 'frac: HIP event pair on the kernel stream around the timed launches (includes inter-launch gaps and the reset launches); '
-                              'frac_wall: the same bytes over ms_per_step (host clock around the region, closed by a device-wide synchronisation)'}
-        if in_place and achieved > HBM_PEAK_GBS:
-            roofline['frac_note'] = 'above 1 because the kernel does not read the 2*S*S bytes the 8(d) model charges; see traffic / design bytes'
+                    'frac_on_design_bytes': round(D * n * steps_per_launch / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    'timing': 'frac = algorithmic bytes per launch / ms_per_step (this line\'s median wall clock per step) / peak - recomputable from the line and '
+                              'comparable with the kernel average in profiles/; frac_event_pair: the same bytes over the HIP event pair recorded on the kernel '
+                              'stream around the timed launches (median region); frac_contract_region: over the contract region\'s own wall clock'}
+        if in_place:
+            roofline['frac_note'] = ('the kernel reads the map in place and never moves the 2*S*S bytes per env-step the 8(d) model charges: `frac` says how the step '
+                                     'compares with a read-pack-write design at the peak, not how busy HBM is - that is `traffic_frac`')
         tr, src = traffic_of('step', n)
         if tr:
             roofline['traffic'], roofline['traffic_source'] = tr, src
             roofline['traffic_provenance'] = pmc.get('_provenance', 'constant of the kernel measured in an earlier profiling run (profiles/pmc_traffic.json)')
-            roofline['frac_of_peak_on_measured_traffic'] = round(tr / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            roofline['traffic_frac'] = round(tr / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        try:
+            import ctypes as C
+            from gym_novel_gridworlds_amd import _cabi
+            fl = _cabi.lib().ngw_debug_launch_floor
+            fl.argtypes, fl.restype = [C.c_void_p, C.c_int32, C.c_int, C.POINTER(C.c_double)], C.c_int
+            us = C.c_double(0)
+            kfl = g_steps if use_graph else steps
+            _cabi.check(fl(v._h, int(kfl), int(bool(use_graph)), C.byref(us)))
+            wl = pmc.get('%s_wave_life' % args.workload, pmc.get('C2_wave_life', {}))
+            life_us = wl.get('median_us')
+            floor_us = us.value + (life_us or 0.0)
+            roofline['floor'] = {'empty_kernel_launch_period_us': round(us.value, 4), 'launch_form': 'hipGraph replay' if use_graph else 'eager',
+                                 'launches': int(kfl), 'stamped_wave_life_us': life_us, 'wave_life_source': wl.get('source'),
+                                 'floor_us': round(floor_us, 4),
+                                 'what': 'launch period of an EMPTY kernel in the step kernel\'s launch shape, issued back to back on this handle in this run '
+                                         '(HIP event pair), + the median life of a wave of the step kernel from the in-kernel clock stamps (profiles/): what one '
+                                         'launch per step() costs when nothing but latency is left'}
+            roofline['frac_of_floor'] = round(floor_us / (dev_step * 1e3), 4)
+        except Exception as ex:       # noqa: BLE001 - a diagnostics entry point: its absence must not cost the line
+            roofline['floor'] = {'error': repr(ex)}
     else:
         # T steps per launch keep the state on chip: HBM sees a few bytes per env-step, the kernel is bound by instruction issue
         roofline = {'bound': 'issue', 'achieved': None, 'peak': None, 'unit': None, 'frac': None, 'traffic': None, 'kernel': 'ngw_rollout_lean',
@@ -607,9 +639,11 @@ def main():
     if rank == 0:
         total = n * world * steps
         line = {
-            'metric': 'env-steps/sec', 'value': round(total / dt, 1), 'unit': 'env-steps/s', 'n_gpus': world,
+            'metric': 'env-steps/sec', 'value': round(n * world / (ms_step * 1e-3), 1), 'unit': 'env-steps/s', 'n_gpus': world,
+            'value_is': 'median of the contract region and %d repeats of it (K steps each)' % (len(wall_all) - 1) if len(wall_all) > 1 else 'the contract region',
+            'value_contract': round(total / dt, 1), 'ms_per_step_contract': round(dt / steps * 1e3, 6),
             'steps': steps, 'warmup': warmup, 'adapt_steps': adapt_steps if args.mode == 'step' else 0, 'clock_warm_ms': args.clock_warm_ms,
-            'prepared_episodes': {'refill_every': v.refill_cadence, 'depth': v.reset_prefetch_depth}, 'ms_per_step': round(dt / steps * 1e3, 6), 'higher_is_better': True,
+            'prepared_episodes': {'refill_every': v.refill_cadence, 'depth': v.reset_prefetch_depth}, 'ms_per_step': round(ms_step, 6), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8/int32', 'data': 'synthetic',
             'config': {'workload': desc, 'name': args.workload, 'envs_per_gpu': n, 'global_envs': n * world,
                        'map_size': S, 'n_items': K, 'n_actions': A, 'horizon': HORIZON, 'autoreset': 'same-step',

@@ -86,7 +86,7 @@ struct ngw_handle {
     NgwLidarDev* lidar_cfg = nullptr;     // device tables
     int32_t* lidar_out = nullptr;
     int lidar_len = 0, lidar_cap = 0;         // lidar_cap: row length lidar_out was allocated for
-    int lidar_bits = 16;                  // row format of the lidar observation (ngw_lidar_set_output): 32, 16 (the default) or 8 = packed
+    int lidar_bits = 32;                  // row format of the lidar observation (ngw_lidar_set_output): 32 (the default: the reference's integers), 16 or 8 = packed
     int lidar_world = 0;                  // the ray table is one world-frame table rotated by the facing (NgwLidarDev::woff)
     NgwLaunch lidar_proto{};              // the stand-alone lidar launch: its own LDS layout
     int lidar_fused = 0, lidar_range = 0, lidar_beams = 0, lidar_chan = 0, lidar_ninv = 0;
@@ -1276,6 +1276,50 @@ int ngw_debug_launch(ngw_handle* h, int mode, int32_t n_launches) {
     for (int i = 0; i < n_launches; i++)
         if (int rc = launch(h, mode, 1, h->actions_dev, nullptr, 0, 0)) return rc;
     return NGW_OK;
+}
+
+/* Diagnostics (bench.py's roofline.floor; not part of include/ngw.h): the launch period of an EMPTY kernel in the step kernel's launch
+ * shape (same grid, 64 lanes per workgroup, the step kernel's LDS request, the same 600-byte argument block) issued back to back
+ * on the handle's stream - eagerly from one host loop, or (graph != 0) as one captured hipGraph replayed once untimed and once
+ * timed - measured with a HIP event pair.  What one launch per step() costs before a single instruction of the step runs. */
+int ngw_debug_launch_floor(ngw_handle* h, int32_t n_launches, int graph, double* us_per_launch) {
+    if (!h || !us_per_launch || n_launches < 1) return fail(NGW_E_INVALID_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    NgwLaunch a = h->nostage ? h->ns_proto : h->proto;
+    a.b = h->b; a.mode = 13; a.actions = h->actions_dev;
+    const size_t lds = h->nostage ? h->ns_lds : h->lds_bytes;
+    const unsigned grid = (unsigned)(h->n_pad / NGW_EPB);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+    int rc = NGW_OK;
+    auto issue = [&]() -> int {
+        for (int i = 0; i < n_launches; i++) HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, 0, grid, lds, h->stream));
+        return NGW_OK;
+    };
+    if (graph) {
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = fail(NGW_E_HIP, "capture failed");
+        if (!rc) rc = issue();
+        if (hipStreamEndCapture(h->stream, &g) != hipSuccess && !rc) rc = fail(NGW_E_HIP, "end capture failed");
+        if (!rc && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) rc = fail(NGW_E_HIP, "instantiate failed");
+        if (!rc && (hipGraphLaunch(ge, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)) rc = fail(NGW_E_HIP, "warm replay failed");
+    } else rc = issue();                                               // (warm pass)
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(NGW_E_HIP, "sync failed");
+    if (!rc) {
+        (void)hipEventRecord(e0, h->stream);
+        if (graph) { if (hipGraphLaunch(ge, h->stream) != hipSuccess) rc = fail(NGW_E_HIP, "replay failed"); }
+        else rc = issue();
+        (void)hipEventRecord(e1, h->stream);
+        if (!rc && hipEventSynchronize(e1) != hipSuccess) rc = fail(NGW_E_HIP, "event sync failed");
+        float ms = 0.f;
+        if (!rc && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(NGW_E_HIP, "elapsed failed");
+        *us_per_launch = (double)ms * 1e3 / n_launches;
+    }
+    if (ge) (void)hipGraphExecDestroy(ge);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
 }
 
 int ngw_sync(ngw_handle* h) {

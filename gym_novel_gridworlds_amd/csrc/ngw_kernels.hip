@@ -1499,6 +1499,10 @@ extern "C" hipError_t ngw_launch(const NgwDevSpec* dspec, const NgwLaunch* a, in
         hipLaunchKernelGGL(ngw_nop_kernel, dim3(grid * NGW_EPB / tpb), dim3(tpb), a->mode == 12 ? lds_bytes * 2 : 0, stream, dspec, *a);
         return hipGetLastError();
     }
+    if (a->mode == 13) {                        // the launch floor: an empty kernel in the STEP kernel's launch shape (ngw_debug_launch_floor)
+        hipLaunchKernelGGL(ngw_nop_kernel, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, dspec, *a);
+        return hipGetLastError();
+    }
     if (a->mode == NGW_MODE_STEP) return ngw_part_step(dspec, a, map_mode, feat, grid, lds_bytes, stream);
     if (a->mode == NGW_MODE_ROLLOUT || a->mode == NGW_MODE_ROLLOUT_ACT) {
         switch (map_mode) {

@@ -1,8 +1,9 @@
 """Observation wrappers with the reference's call shape (gym_novel_gridworlds/observation_wrappers.py).
 
 `LidarInFront(env, num_beams=8)` (reference :10-80) works on the single-env adapter (returns the reference's 1-D
-np.array of ints from reset()/step()) and on `VecNovelGridworld` (returns int16 [N, L] batches - int32 or a packed pair on request - computed in the
-step launch's own epilogue).  As in the reference, the set of lidar items and the beam range are fixed when the wrapper is
+np.array of ints from reset()/step()) and on `VecNovelGridworld` (returns a FRESH int32 [N, L] batch per call, like the
+reference's fresh np.array - computed in the step launch's own epilogue; the fast path is opt-in: `dtype=np.int16` or
+`'packed'` rows and `copy=False`, which hands out the SAME page-locked buffer on every call, overwritten by the next step).  As in the reference, the set of lidar items and the beam range are fixed when the wrapper is
 constructed, while the appended inventory follows the env's current items - so a novelty injected AFTER wrapping adds
 an inventory entry but no lidar channel (tests/random_action.py:24-42 order).
 
@@ -17,11 +18,13 @@ from .vec_env import VecNovelGridworld
 
 
 class LidarInFront(NoveltyWrapper):
-    def __init__(self, env, num_beams=8, fused=True, dtype=np.int16, copy=False):
+    def __init__(self, env, num_beams=8, fused=True, dtype=np.int32, copy=True):
         super().__init__(env)
         self.num_beams = num_beams
-        self._copy = bool(copy)                                 # batched envs: hand out a copy of the host rows instead of the rows themselves (valid until the next step)
-        self._dtype = dtype if isinstance(dtype, str) else np.dtype(dtype)   # batched envs: int16 (default), int32 or 'packed' rows (vec_env.lidar_configure)
+        # batched envs: copy=True (default) returns a fresh array per call, as the reference does (a replay buffer may keep it);
+        # copy=False hands out the page-locked host rows themselves: ONE buffer, overwritten by the next step()
+        self._copy = bool(copy)
+        self._dtype = dtype if isinstance(dtype, str) else np.dtype(dtype)   # batched envs: int32 (default), int16 or 'packed' rows (vec_env.lidar_configure)
         self._fused = fused                                     # batched envs: compute the observation inside the step launch
         self._vec = env if isinstance(env, VecNovelGridworld) else None
         spec = env.spec if self._vec is not None else self._base()._sync_spec()

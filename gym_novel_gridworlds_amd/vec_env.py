@@ -113,7 +113,17 @@ class LazyObs(dict):
 
     def copy(self):
         self._sync()
-        return dict(self)
+        return dict(dict.items(self))
+
+    # dict(obs), {**obs}, other.update(obs), np.savez(**obs): CPython merges a dict SUBCLASS through the fast path that bypasses
+    # __getitem__ unless the subclass overrides __iter__ - with these two the merge walks keys() + __getitem__, which sync
+    def __iter__(self):
+        self._sync()
+        return dict.__iter__(self)
+
+    def keys(self):
+        self._sync()
+        return dict.keys(self)
 
 
 class VecNovelGridworld:
@@ -184,7 +194,7 @@ class VecNovelGridworld:
         and leaves the env as it was - the reference, too, asserts before it changes anything.  The state is undefined until the
         next reset(), as after construction."""
         old_h, old_attrs = self._h, dict(self.__dict__)
-        for name in VecNovelGridworld._HOST_ATTRS + ('_host', '_step_args', '_step1_args', '_step1_fn', '_step1_mv', '_state1_mv', '_reset1_args', '_last_state_views', '_lidar_host', '_view_host', '_last_actions', '_packed_block', '_steps_stale', '_reward_i32'):
+        for name in VecNovelGridworld._HOST_ATTRS + ('_host', '_step_args', '_step1_args', '_step1_fn', '_step1_mv', '_state1_mv', '_reset1_args', '_last_state_views', '_lidar_host', '_view_host', '_last_actions', '_packed_block', '_steps_stale', '_reward_wire'):
             self.__dict__.pop(name, None)
         self._h = C.c_void_p()
         try:
@@ -199,7 +209,7 @@ class VecNovelGridworld:
             _cabi.lib().ngw_destroy(old_h)
         return self
 
-    _HOST_ATTRS = ('_obs', '_reward', '_done', '_act_pinned', '_sel_host', '_steps_host', '_result', '_cost', '_msg', '_arg', '_flags_np', '_info_words')
+    _HOST_ATTRS = ('_obs', '_reward', '_reward_wire', '_done', '_act_pinned', '_sel_host', '_steps_host', '_result', '_cost', '_msg', '_arg', '_flags_np', '_info_words')
 
     def __getattr__(self, name):
         # The host mirrors (10 MB page-locked at 65 536 envs, 157 B per env) exist only for the host API; a handle that is
@@ -207,7 +217,7 @@ class VecNovelGridworld:
         if name in VecNovelGridworld._HOST_ATTRS:
             if self.__dict__.get('_host') is None:
                 N, S, K = self.num_envs, self.map_size, self.n_items
-                if self._one_block_path() and hasattr(_cabi.lib(), 'ngw_step_host_packed'):
+                if self._one_block_path() and self._rewards_fit_int16():   # (a spec with a bigger reward keeps the int32 one-block path)
                     self._make_packed_host()
                     return self.__dict__[name]
                 # ONE page-locked block laid out as ngw_host_step_layout says: a big batch's step() then comes back with a single
@@ -224,7 +234,7 @@ class VecNovelGridworld:
                           'agent_facing_id': sec(2, (N,), np.int32), 'inventory_items_quantity': sec(3, (N, K), np.int32)},
                     _reward=sec(4, (N,), np.int32), _done=sec(5, (N,), np.uint8), _flags_np=sec(7, (1,), np.uint32),
                     # the packed info words of the last step(): big batches (the one-block path of ngw_step_host) decode them lazily
-                    _info_words=sec(6, (N,), np.uint32) if self._one_block_path() else None,
+                    _info_words=sec(6, (N,), np.uint32) if self._one_block_path() else None, _reward_wire=None,
                     _sel_host=sec(8, (N,), np.uint8), _steps_host=sec(9, (N,), np.int32),     # selected item / step_count after the last step()
                     _act_pinned=_cabi.pinned_array((N,), np.int32),
                     _result=np.zeros(N, np.uint8), _cost=np.zeros(N, np.uint8), _msg=np.zeros(N, np.uint16), _arg=np.zeros(N, np.uint16))
@@ -247,8 +257,10 @@ class VecNovelGridworld:
         obs = LazyObs({'map': sec(0, (N, S, S), np.int8), 'agent_location': np.zeros((N, 2), np.int32),
                        'agent_facing_id': np.zeros(N, np.int32), 'inventory_items_quantity': sec(1, (N, K), np.int32)})
         obs._pose, obs._dirty = pose, False
+        # reward: the wire carries int16 (section 3); step() widens it into this persistent int32 array, so the dtype step() returns
+        # does not depend on the batch size (in-dtype arithmetic on an int16 view would overflow at reward * 1000)
         self.__dict__['_host'] = dict(
-            _obs=obs, _reward=sec(3, (N,), np.int16), _done=sec(4, (N,), np.uint8), _info_words=sec(5, (N,), np.uint32), _flags_np=sec(6, (1,), np.uint32),
+            _obs=obs, _reward=np.zeros(N, np.int32), _reward_wire=sec(3, (N,), np.int16), _done=sec(4, (N,), np.uint8), _info_words=sec(5, (N,), np.uint32), _flags_np=sec(6, (1,), np.uint32),
             _sel_host=pose[:, 3], _steps_host=np.zeros(N, np.int32), _act_pinned=np.zeros(N, np.int32),
             _result=np.zeros(N, np.uint8), _cost=np.zeros(N, np.uint8), _msg=np.zeros(N, np.uint16), _arg=np.zeros(N, np.uint16))
         self.__dict__.update(self.__dict__['_host'])
@@ -328,6 +340,7 @@ class VecNovelGridworld:
             self._last_actions = a
             o._dirty = True
             self._steps_stale = True
+            np.copyto(self._reward, self._reward_wire)                   # int16 on the wire, int32 for the caller (~10 us at 65 536 envs)
             obs = None if not with_obs else ({k: v.copy() for k, v in o.items()} if copy else o)
             reward, done = (self._reward.copy(), self._done.view(np.bool_).copy()) if copy else (self._reward, self._done.view(np.bool_))
             info = StepInfo({'_words': self._info_words.copy() if copy else self._info_words})
@@ -393,6 +406,14 @@ class VecNovelGridworld:
         _cabi.check(_cabi.lib().ngw_get_terminal_obs(self._h, _cabi._ptr(out['map'], np.int8), _cabi._ptr(out['agent_location'], np.int32),
                                                      _cabi._ptr(out['agent_facing_id'], np.int32), _cabi._ptr(out['inventory_items_quantity'], np.int32)))
         return out
+
+    def _rewards_fit_int16(self):
+        """The narrow wire format carries rewards as int16 (ngw_step_host_packed refuses a spec with a bigger one): such a spec keeps
+        the int32 one-block path of ngw_step_host."""
+        c = self.cspec
+        vals = [c.reward_step, c.reward_done, c.fire_reward, c.place_reward, c.ext_reward, c.chop_reward, c.axe_reward]
+        vals += list(c.break_reward[:self.n_items]) + list(c.recipe_reward[:c.n_recipes])
+        return all(-32768 <= int(x) <= 32767 for x in vals)
 
     def _one_block_path(self):
         """Does ngw_step_host take its one-block path (pack + one copy, delta refresh) for this env's full step()?  The rule of
@@ -469,15 +490,6 @@ class VecNovelGridworld:
         return {k: v.copy() for k, v in o.items()} if copy else o
 
     def get_step_out(self, copy=False):
-        if self._reward.dtype != np.int32:                    # (big batches: step() keeps the reward in the wire format's int16 section)
-            r32 = self.__dict__.get('_reward_i32')
-            if r32 is None:
-                r32 = self._reward_i32 = np.zeros(self.num_envs, np.int32)
-            _cabi.check(_cabi.lib().ngw_get_step_out(self._h, _cabi._ptr(r32, np.int32), _cabi._ptr(self._done, np.uint8),
-                                                     _cabi._ptr(self._result, np.uint8), _cabi._ptr(self._cost, np.uint8),
-                                                     _cabi._ptr(self._msg, np.uint16), _cabi._ptr(self._arg, np.uint16)))
-            reward, done, info = self._step_out_views(copy)
-            return (r32.copy() if copy else r32), done, info
         _cabi.check(_cabi.lib().ngw_get_step_out(self._h, _cabi._ptr(self._reward, np.int32), _cabi._ptr(self._done, np.uint8),
                                                  _cabi._ptr(self._result, np.uint8), _cabi._ptr(self._cost, np.uint8),
                                                  _cabi._ptr(self._msg, np.uint16), _cabi._ptr(self._arg, np.uint16)))

@@ -102,7 +102,7 @@ def limit_actions_vec(venv, limited_actions):
     # (the prepared-episode settings travel as the caller CHOSE them: 'auto' stays adaptive on the derived env)
     new = VecNovelGridworld(spec=spec, num_envs=venv.num_envs, device=venv.device, seed=venv.seed, autoreset=venv.autoreset,
                             horizon=venv.horizon, env_index_base=venv.env_index_base, reset_prefetch=venv._prefetch_arg,
-                            reset_prefetch_depth=venv._depth_arg)
+                            reset_prefetch_depth=venv._depth_arg, terminal_capture=venv.terminal_capture)
     if venv.lidar is not None:                              # the observation setup travels with the env
-        new.lidar_configure(venv.lidar, fused=venv.lidar_fused, dtype=venv.lidar_dtype)
+        new.lidar_configure(venv.lidar, fused=venv.lidar_fused, dtype='packed' if venv.lidar_packed else venv.lidar_dtype)
     return new

@@ -396,9 +396,9 @@ int ngw_lidar(ngw_handle* h);
  * the state the launch ends in (the buffer holds one row per env). */
 int ngw_lidar_fuse(ngw_handle* h, int enable);
 /* Row format of the observation in the device buffer (and of what ngw_get_lidar copies out):
- *   16 (default)  int16 [len]: half the bytes of the reference's integers; values saturate at 32767 - a beam entry is a range
- *                 <= 64, the inventory tail is the only part that could ever exceed it;
- *   32            int32 [len];
+ *   32 (default)  int32 [len]: what a caller that never calls this function reads (ngw_get_lidar / ngw_lidar_device_ptr);
+ *   16            int16 [len]: half the bytes; values saturate at 32767 - a beam entry is a range <= 64, the inventory tail is the
+ *                 only part that could ever exceed it;
  *    8            packed: uint8 [num_beams * n_chan] beam entries, padded to an even count, then int16 [n_inv] inventory
  *                 (saturating) - 70 B per env for the reference's 8 beams on Pogostick-v1 against 252 B as int32.
  * ngw_lidar_row_layout reports bytes per row, bytes per beam entry, the byte offset of the inventory tail and bytes per

@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: two gloo ranks, envs sharded by global index, observation gather / all_gather == one unsharded batch,
+"""N > 1 path on CPU: two (and eight) gloo ranks, envs sharded by global index, observation gather / all_gather == one unsharded batch,
 also after every rank has called inject_novelty() on its shard.  The local envs are the oracle-backed stand-in of
 tests/ngw_testlib.py (a subclass of the product class with its device hooks replaced); the product path is
 VecNovelGridworld on each GPU (tests/test_multi_gpu_rehearsal.py runs that on the GPU box)."""
@@ -59,17 +59,18 @@ def _worker(rank, world, port, cfg, q, inject):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('cfg,inject', [('pogo10', False), ('axe10', False), ('axe10', True), ('add12m', True)])
-def test_two_rank_sharding_and_gather_match_single_batch(cfg, inject):
+@pytest.mark.parametrize('cfg,inject,world', [('pogo10', False, 2), ('axe10', False, 2), ('axe10', True, 2), ('add12m', True, 2),
+                                              ('axe10', True, 8)])     # world 8: the node's rank count (BASELINE configs 4-5), 12 envs per rank
+def test_sharding_and_gather_match_single_batch(cfg, inject, world):
     ctx = mp.get_context('spawn')
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg, q, inject)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, q, inject)) for r in range(world)]
     for p in procs:
         p.start()
-    gots = [q.get(), q.get()]
+    gots = [q.get() for _ in range(world)]
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
     spec = T.build_spec(cfg)
     ref = T.OracleVec(spec, N, seed=3, autoreset=True, horizon=12)
@@ -79,7 +80,7 @@ def test_two_rank_sharding_and_gather_match_single_batch(cfg, inject):
         ref.step(rs.randint(0, len(spec.actions_id), size=N).astype(np.int32))
     st = ref.o.st
     S = spec.map_size
-    for got in gots:                                     # rank 0's gather and rank 1's all_gather
+    for got in gots:                                     # rank 0's gather and every other rank's all_gather
         assert (got['map'] == st.map.reshape(N, S, S)).all() and (got['agent_location'] == st.loc).all()
         assert (got['agent_facing_id'] == st.facing).all() and (got['inventory_items_quantity'] == st.inv).all()
         assert (got['reward'] == ref.o.reward).all() and (got['done'] == ref.o.done.astype(bool)).all()

@@ -286,7 +286,7 @@ def test_full_size_properties_pogostick_65536():
             assert (os_[k][0] == st[k][e]).all(), (k, e)
 
 
-@pytest.mark.parametrize('wl', ['C2', 'C3', 'C4'])
+@pytest.mark.parametrize('wl', ['C2', 'C3', 'C4', 'C5'])
 def test_bench_call_sequence_matches_oracle_at_full_size(wl):
     """bench.py's own sequence at the workload's full size - reset, set_state(step_count) so that the horizon falls inside the timed
     launches, W = 5 then K = 20 one-step launches from ngw_step_device_many (eager, prepared rows consumed by the whole-wave copy at
@@ -870,6 +870,7 @@ def test_host_step_delta_refresh_matches_oracle(cfg, n, horizon):
             v.refresh_host()                                            # ... and says so
         a = rs.randint(0, A, size=n).astype(np.int32)
         obs, reward, done, info = v.step(a); o.step(a)
+        assert reward.dtype == np.int32                                 # (whatever the batch size: the narrow wire format's int16 is widened)
         assert (reward == o.reward).all() and (done == o.done.astype(bool)).all(), t
         assert (info['message_code'] == o.msg_code).all() and (info['message_arg'] == o.msg_arg).all(), t
         host_equals_oracle(obs, '%s step %d' % (cfg, t))

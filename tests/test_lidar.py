@@ -277,6 +277,30 @@ def test_int16_lidar_output(fused):
     col = lc.num_beams * len(lc.lidar_items_id) + lc.inventory_order(spec).index('plank')
     assert (big[:, col] == 32767).all()
     w = G.LidarInFront(G.VecNovelGridworld(spec=spec, num_envs=64, seed=1), num_beams=8)
-    assert w.reset().dtype == np.int16                                  # the batched wrapper's default row format
-    w = G.LidarInFront(G.VecNovelGridworld(spec=spec, num_envs=64, seed=1), num_beams=8, dtype=np.int32)
-    assert w.reset().dtype == np.int32
+    o1 = w.reset()
+    assert o1.dtype == np.int32                                         # the batched wrapper's default: the reference's integers ...
+    o2, _, _, _ = w.step(np.zeros(64, np.int32))
+    assert not np.shares_memory(o1, o2)                                 # ... in a fresh array per call (a replay buffer may keep them)
+    w = G.LidarInFront(G.VecNovelGridworld(spec=spec, num_envs=64, seed=1), num_beams=8, dtype=np.int16, copy=False)
+    o1 = w.reset()
+    assert o1.dtype == np.int16                                         # the fast path is opt-in: narrow rows, the page-locked buffer itself
+    o2, _, _, _ = w.step(np.zeros(64, np.int32))
+    assert np.shares_memory(o1, o2)
+
+
+@pytest.mark.gpu
+def test_limit_actions_keeps_a_packed_lidar_setup_and_the_terminal_capture():
+    """limit_actions_vec derives a new batched env: the observation setup (incl. the packed row format) and the terminal-observation
+    capture travel with it."""
+    import gym_novel_gridworlds_amd as G
+    from gym_novel_gridworlds_amd.wrappers import limit_actions_vec
+    spec = T.build_spec('pogo10')
+    v = G.VecNovelGridworld(spec=spec, num_envs=256, seed=1, autoreset=True, horizon=20, terminal_capture=True)
+    v.lidar_configure(num_beams=8, fused=True, dtype='packed')
+    w = limit_actions_vec(v, {'Forward', 'Left', 'Right', 'Break', 'Craft_plank'})
+    assert w.lidar_packed and w.lidar_fused and w.terminal_capture and w.lidar_row_bytes == v.lidar_row_bytes
+    w.reset()
+    w.step(np.zeros(256, np.int32))
+    beams, tail = w.lidar_observation()
+    assert beams.dtype == np.uint8 and tail.dtype == np.int16
+    v.close(); w.close()

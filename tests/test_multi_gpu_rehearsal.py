@@ -145,6 +145,56 @@ def test_one_rank_rccl_group_runs_the_device_collectives():
     assert (got['done'] == ref.o.done.astype(bool)).all() and (got['info'].view(np.uint32) == ref.o.info).all()
 
 
+def test_world_8_unpack_on_one_gpu_matches_one_oracle_batch():
+    """The root side of an EIGHT-rank gather on the one GPU a box has (no 8-GPU node reaches this build): eight shards of one global
+    batch (BASELINE config 4's split: axe-medium, 8 x 4 096 envs, shard r = global envs [4096 r, 4096 r + 4096)) are stepped by eight
+    handles, every shard packs its payload with ngw_pack_obs one after another into ONE buffer - what the gather delivers to the
+    root - and a single ngw_unpack_obs(world = 8) (56 regions in one launch) scatters them into global arrays, compared with one
+    unsharded oracle batch of 32 768 envs."""
+    import torch
+    from gym_novel_gridworlds_amd import VecNovelGridworld
+    from gym_novel_gridworlds_amd.dist import shard_range
+    spec = T.build_spec('axe10')
+    world, n, H, steps = 8, 4096, 12, 30
+    Ng, S, K, A = world * n, spec.map_size, len(spec.items_id), len(spec.actions_id)
+    shards = [VecNovelGridworld(spec=spec, num_envs=n, seed=3, autoreset=True, horizon=H, device=0, env_index_base=shard_range(Ng, world, r)[0])
+              for r in range(world)]
+    ref = T.OracleVec(spec, Ng, seed=3, autoreset=True, horizon=H)
+    ref.reset()
+    for v in shards:
+        v.reset()
+    rs = np.random.RandomState(5)
+    for t in range(steps):
+        a = rs.randint(0, A, size=Ng).astype(np.int32)
+        ref.step(a)
+        for r, v in enumerate(shards):
+            v.step(a[r * n:(r + 1) * n])
+    offs = shards[0].pack_layout()
+    assert all(v.pack_layout() == offs for v in shards)                 # equal shards: equal payloads
+    payloads = torch.zeros(world * offs[7], dtype=torch.uint8, device='cuda:0')
+    for r, v in enumerate(shards):
+        v.pack_obs(payloads.data_ptr() + r * offs[7])
+        v.sync()
+    dev = 'cuda:0'
+    out = {'map': torch.zeros((Ng, S, S), dtype=torch.int8, device=dev), 'agent_location': torch.zeros((Ng, 2), dtype=torch.int32, device=dev),
+           'agent_facing_id': torch.zeros(Ng, dtype=torch.int32, device=dev), 'inventory_items_quantity': torch.zeros((Ng, K), dtype=torch.int32, device=dev),
+           'reward': torch.zeros(Ng, dtype=torch.int32, device=dev), 'done': torch.zeros(Ng, dtype=torch.uint8, device=dev),
+           'info': torch.zeros(Ng, dtype=torch.int32, device=dev)}
+    torch.cuda.synchronize()
+    root = shards[0]
+    root.unpack_obs(payloads.data_ptr(), world, [out[k].data_ptr() for k in ('map', 'agent_location', 'agent_facing_id', 'inventory_items_quantity', 'reward', 'done', 'info')])
+    root.sync()
+    st = ref.o.st
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    assert (got['map'] == st.map.reshape(Ng, S, S)).all() and (got['agent_location'] == st.loc).all()
+    assert (got['agent_facing_id'] == st.facing).all() and (got['inventory_items_quantity'] == st.inv).all()
+    assert (got['reward'] == ref.o.reward).all() and (got['done'] == ref.o.done).all()
+    assert (got['info'].view(np.uint32) == ref.o.info).all()
+    assert st.episode.max() >= 2
+    for v in shards:
+        v.close()
+
+
 def test_dist_module_has_no_device_wide_synchronisation():
     src = open(os.path.join(ROOT, 'gym_novel_gridworlds_amd', 'dist.py')).read()
     assert 'cuda.synchronize' not in src and '.sync()' not in src.split('# ------------------------------------------------------------------ the one collective')[1]

@@ -314,6 +314,21 @@ def _read(name):
         return 'unknown'
 
 
+# median life of a wave of the step kernel (in-kernel clock stamps, tools/stamp_timeline.py): what bench.py's roofline.floor adds to the
+# empty-kernel launch period it measures itself
+wl_file = os.path.join(SRC, 'wave_life.json')
+if os.path.exists(wl_file):
+    for wl_name, rec in json.load(open(wl_file)).items():
+        rec['source'] = 'profiles/%s_kernel_stats.md (tools/stamp_timeline.py on the -DNGW_STAMPS build: s_memtime per wave, median over %d waves)' % (ROUND, rec.get('waves', 0))
+        traffic['%s_wave_life' % wl_name] = rec
+    ks_path = os.path.join(DST, ROUND + '_kernel_stats.md')
+    lg = os.path.join(SRC, 'stamps_step.log')
+    if os.path.exists(lg) and os.path.exists(ks_path):
+        with open(ks_path, 'a') as f:
+            f.write('\n## In-kernel timeline of the step kernel (`tools/stamp_timeline.py`, diagnostics build with clock stamps; last launch of a replayed 40-step graph)\n\n```\n')
+            f.write(''.join(x for x in open(lg) if 'amdgpu.ids' not in x))
+            f.write('```\n')
+
 commit = _read('commit.txt')
 if commit == 'unknown':                                  # (no .git on the GPU box)
     commit = TREE_COMMIT

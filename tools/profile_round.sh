@@ -52,6 +52,8 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/sq_lidar_$i -- $P --lidar int16 > $OUT/sq_lidar_$i.log 2>&1 || echo "sq lidar $i failed"
 done
+# 6. in-kernel clock stamps of the step kernel (diagnostics build): the median wave life that bench.py's roofline.floor adds to the empty-kernel launch period
+NGW_STAMP_JSON=$OUT/wave_life.json NGW_LIB=$PWD/gym_novel_gridworlds_amd/libngw_hip_stamps.so python3 tools/stamp_timeline.py C2 C3 C4 C5 > $OUT/stamps_step.log 2>&1 || echo "stamps failed"
 git rev-parse --short HEAD > $OUT/commit.txt 2>/dev/null || echo unknown > $OUT/commit.txt
 date -u +%Y-%m-%dT%H:%MZ > $OUT/date.txt
 find $OUT -name "*.db" -delete 2>/dev/null
