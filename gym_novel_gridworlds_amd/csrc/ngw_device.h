@@ -32,7 +32,17 @@ struct NgwBufs {
     uint32_t* flags;      /* [1] sticky NGW_F_* */
     uint32_t* flags_host; /* single-wavefront handles (host mirror, NgwMirror): the same word in GPU-addressable host memory, or nullptr */
     uint16_t* perm;       /* [S*S][n_pad] shuffle scratch of the subset reset passes, or nullptr */
+    uint32_t* brd;        /* [n_pad][BS] occupancy bit rows of the maps (NGW_BOARD_*), part of the state slab; nullptr for maps beyond 32 x 32 */
 };
+
+/* Occupancy bit rows ("boards") of a map: word r of an env = bit c set iff map[r][c] != 0, BS = S rounded up to a multiple of 4 words per
+ * env (rows >= S are zero), for maps up to 32 x 32.  Auxiliary state of the O(1) LidarInFront observation (ngw_lean.inc, lidar_boards_rows):
+ * the in-place step kernel reads a lane's BS words with its prologue loads, cuts the agent's row, column and two diagonals out of them in
+ * registers and finds a ray's first block with one find-first-bit - no map in LDS, no march.  Kept coherent by whoever changes a map while
+ * the mode is on (NgwLaunch::l_boards): the step kernel's own cell writes, the prepared-episode copies of its cold path, ngw_boards_kernel
+ * after every launch that rewrites maps wholesale (resets, refills, rollouts, ngw_set_state). */
+#define NGW_BOARD_MAX_S 32
+#define NGW_BOARD_STRIDE(S) (((S) + 3) & ~3)
 
 struct NgwLaunch {
     NgwBufs b;
@@ -51,6 +61,8 @@ struct NgwLaunch {
     int32_t l_world;             /* 1: the ray table is one world-frame table rotated by the facing (NgwLidarDev::woff): wave-uniform ray offsets;
                                   * 2: and it is the reference's default 8-beam table on a NGW_LIDAR_CONST_S map: compile-time offsets */
     int32_t l_rb, l_invoff;      /* bytes per observation row in this format; byte offset of its inventory tail */
+    int32_t l_boards;            /* 1: the observation is built from the occupancy bit rows (NgwBufs::brd) by the in-place step kernel / ngw_lidar_boards_kernel */
+    int32_t BS;                  /* words per env in NgwBufs::brd (NGW_BOARD_STRIDE(S)), 0 = no boards for this map size */
     uint32_t off_litem;          /* LDS dword offset of the two item tables (chan_of_item | inv_item: 12 dwords) */
     uint32_t off_ltab, off_ltile; /* ... of the per-lane ray table (8 KiB; only when !l_world) and of the observation tile (64 rows, l_rb bytes each) */
     int32_t perm_lds;            /* AddItem shuffle array: 1 = LDS at off_perm ([S2][32] u16, two half-wave batches), 0 = HBM scratch */
@@ -119,6 +131,7 @@ struct NgwNx {
     int32_t* facing;      /* [depth][n_pad]      */
     int32_t* inv;         /* [depth][n_pad][K]   */
     uint32_t* episode;    /* [depth][n_pad] episode the row was prepared for (0 = nothing prepared) */
+    uint32_t* brd;        /* [depth][n_pad][BS] occupancy bit rows of the prepared maps (valid while the boards mode is on), or nullptr */
     uint32_t* slow;       /* [0] resets that found their row stale and ran the placement loop inside a step (cumulative); [1] refills run so far */
     uint32_t* slow_host;  /* [2] GPU-addressable host words every refill copies `slow` to: the host adapts depth and cadence */
     int64_t stride;       /* rows per slot = n_pad */
@@ -325,5 +338,15 @@ extern "C"
 #endif
 hipError_t ngw_lidar_launch(const NgwLaunch* a /* with the stand-alone launch's own LDS offsets */, int map_mode, unsigned grid, size_t lds_bytes,
                             hipStream_t stream);
+/* Occupancy bit rows (NGW_BOARD_*): rebuild them for `rows` maps (ngw_boards_kernel), and the LidarInFront observation built from them as
+ * its own launch (ngw_lidar_boards_kernel) */
+#ifdef __cplusplus
+extern "C"
+#endif
+hipError_t ngw_boards_launch(const NgwLaunch* a, int map_mode, const int8_t* map, uint32_t* brd, int64_t rows, size_t lds_bytes, hipStream_t stream);
+#ifdef __cplusplus
+extern "C"
+#endif
+hipError_t ngw_lidar_boards_launch(const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream);
 
 #endif

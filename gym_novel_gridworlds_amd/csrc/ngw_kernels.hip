@@ -31,6 +31,7 @@
 // kernel instantiations - of one part; without NGW_PART (make asm) everything is in one unit.
 //   0: ngw_launch + the general kernel   1 / 6 / 7: step kernels per map addressing mode (1 also holds the in-place ones)
 //   2 / 3 / 4: rollout kernels per map addressing mode   5: new-episode (reset_fast), lidar, diff / wire / pack / agent-view kernels
+//   8: the bit-row (boards) lidar: in-place step kernels with the O(1) observation, ngw_boards_kernel, ngw_lidar_boards_kernel
 #ifdef NGW_PART
 #define NGW_HAS(p) (NGW_PART == (p))
 #else
@@ -1141,6 +1142,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
 #endif
 }
 
+#include "ngw_boards.inc"
 #include "ngw_lean.inc"
 #include "ngw_reset.inc"
 
@@ -1442,12 +1444,43 @@ extern "C" hipError_t ngw_part_rollout_byte(const NgwDevSpec* dspec, const NgwLa
 extern "C" hipError_t ngw_part_step_straight(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
 extern "C" hipError_t ngw_part_step_dword(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
 extern "C" hipError_t ngw_part_step_byte(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t ngw_part_step_boards(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
+#if NGW_HAS(8)
+// in-place step + the LidarInFront observation from the occupancy bit rows (ngw_boards.inc): NR = 12 / 20 / 32 register rows
+extern "C" hipError_t ngw_part_step_boards(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream) {
+    const bool ext = (feat & 2) != 0;
+    if (!a->l_boards || a->BS < 4 || a->BS > 32) return hipErrorInvalidValue;
+    if (a->BS <= 12) return ext ? launch_lean<NGW_MAP_STRAIGHT, false, true, true, 12>(dspec, a, grid, lds_bytes, stream)
+                                : launch_lean<NGW_MAP_STRAIGHT, false, false, true, 12>(dspec, a, grid, lds_bytes, stream);
+    if (a->BS <= 20) return ext ? launch_lean<NGW_MAP_STRAIGHT, false, true, true, 20>(dspec, a, grid, lds_bytes, stream)
+                                : launch_lean<NGW_MAP_STRAIGHT, false, false, true, 20>(dspec, a, grid, lds_bytes, stream);
+    return ext ? launch_lean<NGW_MAP_STRAIGHT, false, true, true, 32>(dspec, a, grid, lds_bytes, stream)
+               : launch_lean<NGW_MAP_STRAIGHT, false, false, true, 32>(dspec, a, grid, lds_bytes, stream);
+}
+// bit rows of `rows` (a multiple of 64) maps at `map` -> `brd`; a = the launch's own LDS layout (maps at off_map, word tile at off_ltile, magicK = ceil(2^32 / BS))
+extern "C" hipError_t ngw_boards_launch(const NgwLaunch* a, int map_mode, const int8_t* map, uint32_t* brd, int64_t rows, size_t lds_bytes, hipStream_t stream) {
+    const void* fn = map_mode == NGW_MAP_STRAIGHT ? reinterpret_cast<const void*>(ngw_boards_kernel<NGW_MAP_STRAIGHT>)
+                   : (map_mode == NGW_MAP_DWORD ? reinterpret_cast<const void*>(ngw_boards_kernel<NGW_MAP_DWORD>) : reinterpret_cast<const void*>(ngw_boards_kernel<NGW_MAP_BYTE>));
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    void* args[] = {const_cast<NgwLaunch*>(a), &map, &brd};
+    return hipLaunchKernel(fn, dim3((unsigned)(rows / NGW_EPB)), dim3(NGW_EPB), args, lds_bytes, stream);
+}
+extern "C" hipError_t ngw_lidar_boards_launch(const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
+    if (a->BS <= 12) hipLaunchKernelGGL(ngw_lidar_boards_kernel<12>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, *a);
+    else if (a->BS <= 20) hipLaunchKernelGGL(ngw_lidar_boards_kernel<20>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, *a);
+    else hipLaunchKernelGGL(ngw_lidar_boards_kernel<32>, dim3(grid), dim3(NGW_EPB), lds_bytes, stream, *a);
+    return hipGetLastError();
+}
+#endif  // NGW_HAS(8)
 #if NGW_HAS(1)
 NGW_STEP_PART(ngw_part_step_straight, NGW_MAP_STRAIGHT)
 extern "C" hipError_t ngw_part_step(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int feat, unsigned grid, size_t lds_bytes,
                                     hipStream_t stream) {
-    if (feat & 8) {                                                     // no-stage (the lidar epilogue needs the staged form)
-        if (feat & 1) return hipErrorInvalidValue;
+    if (feat & 8) {                                                     // no-stage: with the lidar observation, the one on the occupancy bit rows
+        if (feat & 1) return ngw_part_step_boards(dspec, a, feat, grid, lds_bytes, stream);
         return (feat & 2) ? launch_lean<NGW_MAP_STRAIGHT, false, true, false>(dspec, a, grid, lds_bytes, stream)
                           : launch_lean<NGW_MAP_STRAIGHT, false, false, false>(dspec, a, grid, lds_bytes, stream);
     }

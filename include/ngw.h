@@ -321,7 +321,7 @@ int ngw_host_free(void* p);
  * wavefront (<= 64 envs: the single-env gym.Env adapter) additionally keep a MIRROR of these rows in page-locked host memory
  * the GPU addresses directly: a step issued by ngw_step_host (an explicit reset by ngw_reset_host) ends by copying the wave's
  * rows there and writing a sequence word the host polls, so such a call is one launch with no copy call and no stream
- * synchronisation (NGW_HOST_STATE=0 in the environment before ngw_create: no mirror, the copy calls of the big handles). */
+ * synchronisation. */
 int ngw_obs_device_ptrs(ngw_handle* h, void** map, void** loc, void** facing, void** inv);
 int ngw_out_device_ptrs(ngw_handle* h, void** reward, void** done, void** info);
 int ngw_sync(ngw_handle* h);

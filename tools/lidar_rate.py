@@ -59,20 +59,24 @@ s.close()
 v = env()
 replay(v, 'plain step')
 v.close()
-for world in (('', '1', '0') if os.environ.get('NGW_LIDAR_SWEEP', '1') != '0' else ('',)):
+for world in (('', 'B0', '1', '0') if os.environ.get('NGW_LIDAR_SWEEP', '1') != '0' else ('',)):
     os.environ.pop('NGW_LIDAR_WORLD', None)
-    if world:
+    os.environ.pop('NGW_LIDAR_BOARDS', None)
+    if world == 'B0':                                 # A/B: the marches over maps staged through LDS instead of the occupancy bit rows
+        os.environ['NGW_LIDAR_BOARDS'] = '0'
+    elif world:
         os.environ['NGW_LIDAR_WORLD'] = world
     for dt_, name in ((np.int32, 'int32'), (np.int16, 'int16'), ('packed', 'packed u8+i16')):
         v = env()
         v.lidar_configure(num_beams=8, fused=True, dtype=dt_)
-        replay(v, 'fused lidar, %s rows (%d B/env), %s rays' % (name, v.lidar_row_bytes, {'': 'default (constant-offset at 10x10)', '1': 'world-frame', '0': 'per-lane table'}[world]))
+        replay(v, 'fused lidar, %s rows (%d B/env), %s rays' % (name, v.lidar_row_bytes, {'': 'default: occupancy bit rows, in-place step' if v.step_reads_map_in_place else 'default march', 'B0': 'staged march (constant-offset at 10x10)', '1': 'world-frame march', '0': 'per-lane table march'}[world]))
         if world == '':
             v.rollout(100, 1, 0); v.sync()
             v.timing_begin(); v.rollout(1000, 1, 100); ms = v.timing_end()
             print("    fused rollout (1000 steps), observation of the final state: %.3f us per batched step -> %.1f G env-steps/s" % (ms, n / ms / 1e3), flush=True)
         v.close()
 os.environ.pop('NGW_LIDAR_WORLD', None)
+os.environ.pop('NGW_LIDAR_BOARDS', None)
 v = env()
 v.lidar_configure(num_beams=8, fused=False, dtype=np.int16)
 v.reset()
