@@ -448,18 +448,22 @@ def main():
             from gym_novel_gridworlds_amd import _cabi
             fl = _cabi.lib().ngw_debug_launch_floor
             fl.argtypes, fl.restype = [C.c_void_p, C.c_int32, C.c_int, C.POINTER(C.c_double)], C.c_int
-            us = C.c_double(0)
-            kfl = g_steps if use_graph else steps
-            _cabi.check(fl(v._h, int(kfl), int(bool(use_graph)), C.byref(us)))
+            us_g, us_e = C.c_double(0), C.c_double(0)
+            kfl = g_steps if use_graph else max(steps, 64)
+            _cabi.check(fl(v._h, int(kfl), 1, C.byref(us_g)))            # replayed from a graph: the device-side boundary between dependent launches
+            _cabi.check(fl(v._h, int(kfl), 0, C.byref(us_e)))            # issued eagerly: what the HOST can sustain (a region below 100 steps is launched this way)
             wl = pmc.get('%s_wave_life' % args.workload, pmc.get('C2_wave_life', {}))
             life_us = wl.get('median_us')
-            floor_us = us.value + (life_us or 0.0)
-            roofline['floor'] = {'empty_kernel_launch_period_us': round(us.value, 4), 'launch_form': 'hipGraph replay' if use_graph else 'eager',
+            # the device needs the boundary + a wave's life per launch; an eager loop cannot go faster than the host issues launches
+            floor_us = max(us_g.value + (life_us or 0.0), 0.0 if use_graph else us_e.value)
+            roofline['floor'] = {'empty_kernel_launch_period_us': {'hipGraph replay': round(us_g.value, 4), 'eager': round(us_e.value, 4)},
+                                 'launch_form_of_this_region': 'hipGraph replay' if use_graph else 'eager',
                                  'launches': int(kfl), 'stamped_wave_life_us': life_us, 'wave_life_source': wl.get('source'),
                                  'floor_us': round(floor_us, 4),
-                                 'what': 'launch period of an EMPTY kernel in the step kernel\'s launch shape, issued back to back on this handle in this run '
-                                         '(HIP event pair), + the median life of a wave of the step kernel from the in-kernel clock stamps (profiles/): what one '
-                                         'launch per step() costs when nothing but latency is left'}
+                                 'what': 'floor = max(empty-kernel launch period replayed from a graph + the median life of a wave of the step kernel (in-kernel clock '
+                                         'stamps, profiles/), and - for an eagerly launched region - the empty-kernel launch period of the host loop): EMPTY kernels '
+                                         'in the step kernel\'s launch shape, issued back to back on this handle in this run (HIP event pair).  What one launch per '
+                                         'step() costs when nothing but latency is left'}
             roofline['frac_of_floor'] = round(floor_us / (dev_step * 1e3), 4)
         except Exception as ex:       # noqa: BLE001 - a diagnostics entry point: its absence must not cost the line
             roofline['floor'] = {'error': repr(ex)}

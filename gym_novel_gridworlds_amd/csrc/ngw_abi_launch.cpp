@@ -262,9 +262,6 @@ int refill_launches(ngw_handle* h) {
 // episodes on, an env's reset inside the launch copies its prepared row - but only the first one, the shadow rows are
 // re-prepared between launches.  Same action stream (keyed by the absolute step), same results as one launch.
 int rollout_chunks(ngw_handle* h, int mode, int32_t n_steps, const int32_t* actions_dev, uint64_t action_seed, int64_t t0, int64_t step_stride) {
-    if (h->term_on)
-        return fail(NGW_E_INVALID_ARG, "fused rollouts keep no terminal observations (the state lives on chip between steps): switch "
-                                       "ngw_set_terminal_capture off, or step with ngw_step / ngw_step_device");
     // a prepared row serves an env's FIRST reset of a launch, and under a horizon H an env resets at most once per H steps
     // (plus the rare early `done`): H-step launches (capped) keep the per-launch staging cost low; no horizon: 4 cadences
     int32_t chunk = n_steps;

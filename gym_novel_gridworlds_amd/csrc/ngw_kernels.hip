@@ -61,11 +61,13 @@ constexpr int EPB = NGW_EPB;   // envs per block = wavefront width
 #define STAMP_STRIDE 32        /* u64 per workgroup: [0, 8) chip clock, [8, 16) shader cycles of the kernel's stamps, [16, 32) shader cycles inside helpers (STAMP_SUB) */
 #define STAMP_FLUSH(a) do { if ((a).stamps && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; i_++) { (a).stamps[(size_t)blockIdx.x * STAMP_STRIDE + i_] = st_rt[i_]; (a).stamps[(size_t)blockIdx.x * STAMP_STRIDE + 8 + i_] = st_cy[i_]; } } } while (0)
 #define STAMP_SUB(a, i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F) /* lgkmcnt(0): LDS work up to here is done */; const uint64_t c_ = __builtin_amdgcn_s_memtime(); if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)blockIdx.x * STAMP_STRIDE + 16 + (i)] = c_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_SUBV(a, i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0) /* every counter: global loads have landed too */; const uint64_t c_ = __builtin_amdgcn_s_memtime(); if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)blockIdx.x * STAMP_STRIDE + 16 + (i)] = c_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_FLUSH(a)
 #define STAMP_SUB(a, i)
+#define STAMP_SUBV(a, i)
 #endif
 
 // ---------------------------------------------------------------- Philox4x32-10 (counter-based, per env & episode)

@@ -383,7 +383,7 @@ class VecNovelGridworld:
         """Keep, for every env that ends an episode in a step() under autoreset, the observation that episode ENDED in (the step
         itself returns the next episode's first observation): include/ngw.h ngw_set_terminal_capture.  step() then puts
         info['_final_observation'] (= done) and a lazily fetched info['final_observation'] into its info; terminal_observation() reads
-        the side set directly.  Off by default; fused rollouts refuse to run while it is on."""
+        the side set directly.  Off by default.  Fused rollouts capture too: afterwards row e is the state env e's last finished episode ended in."""
         _cabi.check(_cabi.lib().ngw_set_terminal_capture(self._h, int(bool(on))))
         self.terminal_capture = bool(on)
 

@@ -375,8 +375,9 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
  * a step launch first copy the state their episode ended in - map row, pose, inventory row - into a side set, which
  * ngw_get_terminal_obs copies out whole ([n_envs] rows; row e is meaningful for the envs whose `done` the last step set, and keeps its
  * value until env e ends an episode again) and ngw_terminal_device_ptrs exposes in place.  Off by default; when off the step kernels'
- * hot path is untouched (the copy sits behind the "some lane resets" branch).  Fused rollouts keep their state on chip between steps and
- * refuse to run while the capture is on (NGW_E_INVALID_ARG). */
+ * hot path is untouched (the copy sits behind the "some lane resets" branch).  Fused rollouts capture too: the lane that resets inside
+ * the T-loop stores its map and inventory row from LDS into the side set first; after a rollout row e holds the state env e's LAST
+ * finished episode ended in (the per-step done rows of ngw_rollout_outputs say which steps ended one). */
 int ngw_set_terminal_capture(ngw_handle* h, int enable);
 int ngw_get_terminal_obs(ngw_handle* h, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv);
 int ngw_terminal_device_ptrs(ngw_handle* h, void** map, void** loc, void** facing, void** inv);

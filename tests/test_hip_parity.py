@@ -335,7 +335,7 @@ def test_terminal_observations_under_autoreset(cfg, n, H, prefetch):
     """ngw_set_terminal_capture: an env that ends an episode in a step (done, a FireWall death, or the horizon cut) keeps the state that
     episode ENDED in - what a second oracle, stepped from the same pre-step state WITHOUT autoreset, holds - while step() returns the new
     episode's first observation as before.  Staggered episode ends (a few lanes of a wave reset per step), whole-wave ends, prepared
-    rows on and off, staged and in-place step kernels; fused rollouts refuse to run while the capture is on."""
+    rows on and off, staged and in-place step kernels, and fused rollouts (rows captured from LDS inside the T-loop)."""
     spec = T.build_spec(cfg)
     A, S, K = len(spec.actions_id), spec.map_size, len(spec.items_id)
     v = VecNovelGridworld(spec=spec, num_envs=n, seed=3, autoreset=True, horizon=H, reset_prefetch=prefetch, terminal_capture=True)
@@ -372,8 +372,29 @@ def test_terminal_observations_under_autoreset(cfg, n, H, prefetch):
         assert (obs['map'].reshape(n, -1) == o.st.map).all() and (obs['agent_location'] == o.st.loc).all(), (t, 'the returned observation is the new episode')
     assert_state_equal(v, o, 'terminal capture ' + cfg)
     assert ended > n                                                  # every env ended at least one episode on average
-    with pytest.raises(ValueError, match='terminal'):
-        v.rollout(5)
+    # fused rollouts capture too (the resetting lane stores its rows from LDS before the next episode overwrites them): the caller's action
+    # rows, every step mirrored on the two oracles; a row keeps its value until its env ends an episode again
+    import torch
+    Tn = 2 * H + 3 if H < 30 else 40
+    acts = torch.randint(0, A, (Tn, n), dtype=torch.int32, device='cuda')
+    torch.cuda.synchronize()
+    an = acts.cpu().numpy()
+    exp = v.terminal_observation()
+    v.rollout_actions(acts.data_ptr(), n, Tn)
+    for t in range(Tn):
+        for dst, src in zip(o2.st.arrays() + [o2.st.episode], o.st.arrays() + [o.st.episode]):
+            dst[...] = src
+        o.step(an[t]); o2.step(an[t])
+        idx = np.nonzero(o.done)[0]
+        exp['map'].reshape(n, -1)[idx] = o2.st.map[idx]
+        exp['agent_location'][idx] = o2.st.loc[idx]; exp['agent_facing_id'][idx] = o2.st.facing[idx]
+        exp['inventory_items_quantity'][idx] = o2.st.inv[idx]
+    got = v.terminal_observation()
+    for k in exp:
+        assert (got[k] == exp[k]).all(), ('rollout', k)
+    assert_state_equal(v, o, 'rollout with the capture on ' + cfg)
+    v.rollout(H + 1, action_seed=9, t0=3); o.rollout(H + 1, 9, 3)      # (generated actions: every env ends an episode; the state stays exact)
+    assert_state_equal(v, o, 'generated-action rollout with the capture on ' + cfg)
     v.set_terminal_capture(False)
     v.rollout(5, action_seed=1, t0=0); o.rollout(5, 1, 0)
     assert_state_equal(v, o, 'rollout after the capture was switched off')

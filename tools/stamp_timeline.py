@@ -80,6 +80,9 @@ def main():
         if sub.max() > 0:                                # stamps inside the LidarInFront row builder (STAMP_SUB in lidar_rows)
             sn = ['epilogue entered', 'tile zeroed', 'cells read', 'hits written', 'inventory written', 'rows stored (issued)', 'rays resolved']
             order = [0, 1, 2, 6, 3, 4, 5]                  # (slot 6 sits between 'cells read' and 'hits written')
+            if v.step_reads_map_in_place:                  # the bit-row form (ngw_boards.inc): its own stations
+                sn = ['epilogue entered', 'lines cut out of the bit rows', 'rays resolved, hit cells requested, inventory tail written', 'hits written', '-', 'rows stored (issued)', 'hit cells landed']
+                order = [0, 1, 2, 6, 3, 5]
             have = [i for i in order if sub[:, i].max() > 0]
             print('  inside the lidar epilogue, shader cycles (median / p90):')
             for a_, b_ in zip(have[:-1], have[1:]):
