@@ -151,7 +151,7 @@ int upload_reset_u(ngw_handle* h) {
             off = (off + 3u) & ~3u;
             q.off_litem = off; off += 2 * NGW_MAX_ITEMS / 4;
             off = (off + 3u) & ~3u;
-            q.off_ltile = off; off += (uint32_t)(NGW_EPB * q.l_rb / 4) + NGW_EPB / 4;
+            q.off_ltile = off; off += (uint32_t)(NGW_EPB * q.l_rb / 4) + NGW_EPB;   // + one dump DWORD per lane (entries that report nothing are stored there)
         }
         h->ns_lds = (size_t)off * 4;
         HIP_TRY(hipMemcpyAsync(&h->dspec->lp_ns, &q, sizeof(q), hipMemcpyDefault, h->stream));
@@ -175,7 +175,7 @@ int upload_reset_u(ngw_handle* h) {
             off = (off + 3u) & ~3u;
             l.off_litem = off; off += 2 * NGW_MAX_ITEMS / 4;
             off = (off + 3u) & ~3u;
-            l.off_ltile = off; off += (uint32_t)(NGW_EPB * l.l_rb / 4) + NGW_EPB / 4;
+            l.off_ltile = off; off += (uint32_t)(NGW_EPB * l.l_rb / 4) + NGW_EPB;
             h->lb_lds = (size_t)off * 4;
         }
     }
@@ -214,7 +214,11 @@ void layout_reset_fast(ngw_handle* h) {
     a.off_dom = off; if (subset) off += NBW;
     a.off_mcol = off; if (subset) off += NBW * NGW_EPB;
     off = (off + 3u) & ~3u;
-    a.off_tile = off; off += (uint32_t)((S2 <= 512 ? (S2 * NGW_EPB + 15) / 16 * 16 : 144 * NGW_EPB) / 4);   // staging tile of the composed rows: the chunk's exact image up to 512-byte rows, else [64][128 + 16] bytes
+    {   // staging tile of the composed rows: the chunk's exact image up to 512-byte rows, else [64][128 + 16] bytes; in the boards mode the
+        // occupancy bit rows of the same maps are staged there afterwards ([64][BS + 1] words)
+        const uint32_t tile_dw = (uint32_t)((S2 <= 512 ? (S2 * NGW_EPB + 15) / 16 * 16 : 144 * NGW_EPB) / 4), brd_dw = (uint32_t)(NGW_EPB * (h->proto.BS + 1));
+        a.off_tile = off; off += tile_dw > brd_dw ? tile_dw : brd_dw;
+    }
     // (every dword counts: at 32 x 32 + AddItem the layout is 38.8 KB and four workgroups share a CU's 160 KB - one per SIMD)
     a.off_ctab = off; off += NGW_EPB + NGW_EPB * NGW_MAX_DEPTH / 2;
     if ((size_t)off * 4 > 160 * 1024) return;

@@ -41,12 +41,12 @@ bool one_block(const ngw_handle* h, const void* map, const void* loc, const void
     return true;
 }
 
-void host_step_layout_packed(const ngw_handle* h, uint64_t off[8]) {
+void host_step_layout_packed(const ngw_handle* h, uint64_t off[9]) {
     const uint64_t n = (uint64_t)h->n, S2 = (uint64_t)h->proto.S2, K = (uint64_t)h->proto.K;
-    const uint64_t bytes[7] = {n * S2, n * K * 4, n * 4, n * 2, n, n * 4, 4};
+    const uint64_t bytes[8] = {n * S2, n * K * 4, n * 4, n * 2, n, n * 4, 4, n * 4};   // (the last one - reward as int32 - is filled on the host, not by the device)
     uint64_t o = 0;
-    for (int i = 0; i < 7; i++) { off[i] = o; o += (bytes[i] + 255) & ~(uint64_t)255; }
-    off[7] = o;
+    for (int i = 0; i < 8; i++) { off[i] = o; o += (bytes[i] + 255) & ~(uint64_t)255; }
+    off[8] = o;
 }
 
 /* Payload of the multi-GPU observation gather: the seven SoA arrays back to back, each section padded to 16 bytes. */
@@ -298,9 +298,9 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
  * 3 reward int16 [n], 4 done uint8 [n], 5 info uint32 [n] (NGW_INFO_*), 6 error flags uint32), each padded to 256 bytes; offsets7[7] =
  * the block's size.  Sections 0-1 are refreshed by deltas (only the 16-byte pieces a step changed cross PCIe), 2-6 are dense and
  * come back with ONE copy: 11 B per env against the 26 B of the int32 SoA arrays of ngw_step_host. */
-int ngw_host_step_layout_packed(ngw_handle* h, uint64_t* offsets8) {
-    if (!h || !offsets8) return fail(NGW_E_INVALID_ARG, "NULL argument");
-    host_step_layout_packed(h, offsets8);
+int ngw_host_step_layout_packed(ngw_handle* h, uint64_t* offsets9) {
+    if (!h || !offsets9) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    host_step_layout_packed(h, offsets9);
     return NGW_OK;
 }
 
@@ -350,7 +350,7 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
         for (size_t i = 0; i < n; i++)
             if (actions_host[i] < 0 || actions_host[i] >= A) return fail(NGW_E_INVALID_ACTION, "%d is not in list", (int)actions_host[i]);   // pogostick_v1_env.py:236
     }
-    uint64_t off[8];
+    uint64_t off[9];
     host_step_layout_packed(h, off);
     if (!h->wire_stage) { if (int rc = dev_alloc(h, &h->wire_stage, (size_t)(off[7] - off[2]))) return rc; }
 #ifdef NGW_HOSTTRACE
@@ -414,6 +414,11 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
         }
     }
 #endif
+    {   // reward: int16 on the wire, int32 for the caller (section 7; plain loop: the compiler vectorises the sign extension)
+        const int16_t* r16 = reinterpret_cast<const int16_t*>(blk + off[3]);
+        int32_t* r32 = reinterpret_cast<int32_t*>(blk + off[7]);
+        for (size_t i = 0; i < n; i++) r32[i] = r16[i];
+    }
     // (a delta step that skipped the map leaves the map's shadow describing what the block holds: the next step that wants the map
     //  brings every change since across)
     h->mirror_valid = h->host_delta && h->mirror_block == block;

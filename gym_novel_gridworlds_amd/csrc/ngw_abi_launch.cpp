@@ -9,7 +9,7 @@ int capture_graph(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride
 namespace {
 int launch_reset_fast(ngw_handle* h, int mode, const uint8_t* mask_dev, bool* taken);
 int launch_lidar_boards(ngw_handle* h);
-int refill_launches(ngw_handle* h);
+int refill_launches(ngw_handle* h, bool* fast);
 int rollout_chunks(ngw_handle* h, int mode, int32_t n_steps, const int32_t* actions_dev, uint64_t action_seed, int64_t t0, int64_t step_stride);
 }
 
@@ -138,9 +138,11 @@ int rebuild_boards(ngw_handle* h, const int8_t* map, uint32_t* brd, int64_t rows
 }
 
 int launch_refill(ngw_handle* h) {
-    if (int rc = refill_launches(h)) return rc;
-    // boards mode: the refill rewrote prepared maps - their bit rows follow (every slot: the rows of untouched maps come out as they were)
-    if (h->boards_on) return rebuild_boards(h, h->nx.map, h->nx.brd, (int64_t)h->n_pad * h->depth);
+    bool fast = false;
+    if (int rc = refill_launches(h, &fast)) return rc;
+    // boards mode: the refill rewrote prepared maps - their bit rows follow.  The dedicated new-episode kernel writes them itself; behind the
+    // general kernel the rebuild launch does (every slot: the rows of untouched maps come out as they were)
+    if (h->boards_on && !fast) return rebuild_boards(h, h->nx.map, h->nx.brd, (int64_t)h->n_pad * h->depth);
     return NGW_OK;
 }
 
@@ -168,7 +170,8 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
         if (int rc = rebuild_boards(h, h->b.map, h->b.brd, h->n_pad)) return rc;
         h->brd_dirty = false;
     }
-    if (mode == NGW_MODE_RESET) { if (int rc = launch_reset_fast(h, NGW_MODE_RESET, mask_dev, &taken)) return rc; }
+    bool fast_took = false;
+    if (mode == NGW_MODE_RESET) { if (int rc = launch_reset_fast(h, NGW_MODE_RESET, mask_dev, &taken)) return rc; fast_took = taken; }
     if (!taken && mode == NGW_MODE_STEP && h->nostage && (!h->lidar_fused || boards)) {   // maps read in place: no-stage step kernel
         NgwLaunch q = h->ns_proto;
         q.b = h->b; q.mode = mode; q.n_steps = 1; q.actions = actions_dev; q.autoreset = h->autoreset; q.horizon = h->horizon; q.stamps = h->proto.stamps;
@@ -184,7 +187,9 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
         HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, (march ? 1 : 0) | (h->ext ? 2 : 0), grid, h->lds_bytes, h->stream));
     }
     if (boards && mode == NGW_MODE_RESET) {
-        if (int rc = rebuild_boards(h, h->b.map, h->b.brd, h->n_pad)) return rc;
+        // (the dedicated new-episode kernel wrote the bit rows of the maps it made or copied; a masked reset leaves the others as they were,
+        //  which is only right if they were right before: a stale set is rebuilt whole)
+        if (!fast_took || h->brd_dirty) { if (int rc = rebuild_boards(h, h->b.map, h->b.brd, h->n_pad)) return rc; }
         h->brd_dirty = false;
         if (int rc = launch_lidar_boards(h)) return rc;
     }
@@ -217,6 +222,7 @@ int launch_reset_fast(ngw_handle* h, int mode, const uint8_t* mask_dev, bool* ta
     NgwResetFast a = h->rf;
     a.main = h->b; a.nx = h->prefetch_every > 0 ? h->nx : NgwNx{}; a.mode = mode; a.reset_mask = mask_dev; a.stamps = h->proto.stamps;
     a.seq = mode == NGW_MODE_RESET ? h->launch_seq : 0u;
+    a.boards = h->boards_on ? 1 : 0; a.BS = h->proto.BS;                            // (boards mode: the kernel writes the bit rows of its maps itself)
     HIP_TRY(ngw_reset_fast_launch(h->dspec, &a, h->rf_nw, h->rf_additem, (unsigned)(h->n_pad / NGW_EPB), h->rf_lds, h->stream));
     *taken = true;
     return NGW_OK;
@@ -230,7 +236,8 @@ int launch_lidar_boards(ngw_handle* h) {
     return NGW_OK;
 }
 
-int refill_launches(ngw_handle* h) {
+int refill_launches(ngw_handle* h, bool* fast) {
+    *fast = false;
     h->since_refill = 0;
     adapt_cadence(h);
     if (h->adapt_error) {                                           // (not fatal: the handle keeps working at the depth it has)
@@ -240,7 +247,7 @@ int refill_launches(ngw_handle* h) {
     h->refill_count++;
     bool taken = false;
     if (int rc = launch_reset_fast(h, NGW_MODE_REFILL, nullptr, &taken)) return rc;
-    if (taken) return NGW_OK;
+    if (taken) { *fast = true; return NGW_OK; }
     // the general kernel prepares one slot per launch (its shadow set is the launch's buffer set)
     const size_t np = (size_t)h->n_pad, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
     for (int slot = 0; slot < h->depth; slot++) {

@@ -234,6 +234,7 @@ struct NgwResetFast {            // kernel arguments (by value)
     int32_t img;                 // rows up to 512 bytes: the LDS tile is the exact image of the wave's 64 rows, stored as one coalesced run
     uint32_t off_ring, off_masks, off_placed, off_tmpl, off_dom, off_mcol, off_tile;    // LDS dword offsets
     uint32_t off_ctab;           // [64] destination rows of a pass (u32) + [64 * NGW_MAX_DEPTH] stale (env, slot) pairs of a compacting refill (u16)
+    int32_t boards, BS;          // boards mode: also write the occupancy bit rows (NgwBufs::brd / NgwNx::brd, BS words per env) of every map made or copied
     uint64_t* stamps;            // diagnostics builds (-DNGW_STAMPS), or nullptr
 };
 #ifdef __cplusplus

@@ -19,7 +19,7 @@ import ctypes as C
 MAX_ITEMS, MAX_ACTIONS, MAX_RECIPES, MAX_RECIPE_INPUTS, MAX_START, MAX_INV_START = 24, 48, 8, 4, 8, 4
 MAX_MAP_SIZE = 64
 MAX_PASSES = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # step_cost values with their Python types (SURVEY.md §8(a) "Distinct step_cost values")
 STEP_COSTS = [0, 24.0, 27.906975, 120.0, 300.0, 360.0, 480.0, 720.0, 840.0, 1200.0, 1800.0, 2400.0, 3600.0,

@@ -246,9 +246,9 @@ class VecNovelGridworld:
         """Host mirrors of a big batch: ONE page-locked block in the narrow wire format (include/ngw.h ngw_host_step_layout_packed) -
         map and inventory refreshed by deltas, pose as four bytes per env, reward int16, done uint8, packed info words."""
         N, S, K = self.num_envs, self.map_size, self.n_items
-        offs = (C.c_uint64 * 8)()
+        offs = (C.c_uint64 * 9)()
         _cabi.check(_cabi.lib().ngw_host_step_layout_packed(self._h, offs))
-        block = _cabi.pinned_array((int(offs[7]),), np.uint8)
+        block = _cabi.pinned_array((int(offs[8]),), np.uint8)
 
         def sec(i, shape, dt):
             nb = int(np.prod(shape)) * np.dtype(dt).itemsize
@@ -257,10 +257,10 @@ class VecNovelGridworld:
         obs = LazyObs({'map': sec(0, (N, S, S), np.int8), 'agent_location': np.zeros((N, 2), np.int32),
                        'agent_facing_id': np.zeros(N, np.int32), 'inventory_items_quantity': sec(1, (N, K), np.int32)})
         obs._pose, obs._dirty = pose, False
-        # reward: the wire carries int16 (section 3); step() widens it into this persistent int32 array, so the dtype step() returns
+        # reward: the wire carries int16 (section 3); the C call widens it into the block's int32 section 7, so the dtype step() returns
         # does not depend on the batch size (in-dtype arithmetic on an int16 view would overflow at reward * 1000)
         self.__dict__['_host'] = dict(
-            _obs=obs, _reward=np.zeros(N, np.int32), _reward_wire=sec(3, (N,), np.int16), _done=sec(4, (N,), np.uint8), _info_words=sec(5, (N,), np.uint32), _flags_np=sec(6, (1,), np.uint32),
+            _obs=obs, _reward=sec(7, (N,), np.int32), _reward_wire=sec(3, (N,), np.int16), _done=sec(4, (N,), np.uint8), _info_words=sec(5, (N,), np.uint32), _flags_np=sec(6, (1,), np.uint32),
             _sel_host=pose[:, 3], _steps_host=np.zeros(N, np.int32), _act_pinned=np.zeros(N, np.int32),
             _result=np.zeros(N, np.uint8), _cost=np.zeros(N, np.uint8), _msg=np.zeros(N, np.uint16), _arg=np.zeros(N, np.uint16))
         self.__dict__.update(self.__dict__['_host'])
@@ -340,7 +340,6 @@ class VecNovelGridworld:
             self._last_actions = a
             o._dirty = True
             self._steps_stale = True
-            np.copyto(self._reward, self._reward_wire)                   # int16 on the wire, int32 for the caller (~10 us at 65 536 envs)
             obs = None if not with_obs else ({k: v.copy() for k, v in o.items()} if copy else o)
             reward, done = (self._reward.copy(), self._done.view(np.bool_).copy()) if copy else (self._reward, self._done.view(np.bool_))
             info = StepInfo({'_words': self._info_words.copy() if copy else self._info_words})

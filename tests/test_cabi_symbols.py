@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_spec_layout():
     L = _cabi.lib()
     from gym_novel_gridworlds_amd.spec import ABI_VERSION
-    assert L.ngw_abi_version() == ABI_VERSION == 2
+    assert L.ngw_abi_version() == ABI_VERSION == 3
     assert L.ngw_spec_size() == C.sizeof(NgwSpec)
 
 
