@@ -152,6 +152,9 @@ int upload_reset_u(ngw_handle* h) {
             q.off_litem = off; off += 2 * NGW_MAX_ITEMS / 4;
             off = (off + 3u) & ~3u;
             q.off_ltile = off; off += (uint32_t)(NGW_EPB * q.l_rb / 4) + NGW_EPB;   // + one dump DWORD per lane (entries that report nothing are stored there)
+            off = (off + 3u) & ~3u;
+            const uint32_t nr = q.BS <= 12 ? 12u : (q.BS <= 20 ? 20u : 32u);       // the kernel's register rows (ngw_part_step_boards picks the same)
+            q.off_ltab = off; off += NGW_EPB * (nr + 4u);                           // the lanes' bit rows, [64][NR + 4] words: rows come back by index from here
         }
         h->ns_lds = (size_t)off * 4;
         HIP_TRY(hipMemcpyAsync(&h->dspec->lp_ns, &q, sizeof(q), hipMemcpyDefault, h->stream));
@@ -381,6 +384,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     if (const char* v = getenv("NGW_ADAPT_PREFETCH")) h->adapt = atoi(v) != 0;
     if (const char* v = getenv("NGW_HOST_DELTA")) h->host_delta = atoi(v) != 0;
     if (const char* v = getenv("NGW_ZC_BYTES")) { h->zc_bytes = (size_t)atoll(v); if (!h->zc_bytes) h->zc_bytes = 1; }
+    if (const char* v = getenv("NGW_API_SLICES")) h->api_slices = atoi(v);
     {
         // Which per-launch step kernel: the one that reads the <= 14 cells a step needs straight from HBM, at EVERY map size.  Up to
         // round 3 the 10 x 10 (and 6 x 6) maps - whose 64 rows arrive in one round of loads and land in LDS as they are - kept the
@@ -597,6 +601,8 @@ int ngw_destroy(ngw_handle* h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->order_ev) (void)hipEventDestroy(h->order_ev);
+    for (hipEvent_t e : h->slice_ev) if (e) (void)hipEventDestroy(e);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return NGW_OK;

@@ -339,6 +339,69 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
 #endif
     HIP_TRY(hipEventSynchronize(h->act_ev[slot]));
     uint8_t* const a8 = h->act_pin + (size_t)slot * cap;
+    uint64_t off[9];
+    host_step_layout_packed(h, off);
+    if (!h->wire_stage) { if (int rc = dev_alloc(h, &h->wire_stage, (size_t)(off[7] - off[2]))) return rc; }
+    const bool delta = h->host_delta && h->mirror_valid && h->mirror_block == block;
+    // Pipelined form (steady state of a big batch on the in-place step kernel): the batch steps in 2 - 4 slices on the handle's stream, and as
+    // soon as a slice's step kernel is done a second stream refreshes that slice's part of the caller's block across PCIe - while the next
+    // slice's actions are still being narrowed on the host and its step kernel runs.  The reference raises for a bad action id BEFORE it
+    // touches any state (pogostick_v1_env.py:236), so every id is checked first (read-only pass); narrowing then goes slice by slice.
+    int nsl = 1;
+    if (delta && h->nostage && (!h->lidar_fused || h->boards_on) && !h->hostres && !h->capturing) {
+        nsl = h->api_slices > 0 ? h->api_slices : (n >= 32768 ? 4 : (n >= 8192 ? 2 : 1));
+        if (nsl > 4) nsl = 4;
+        while (nsl > 1 && n / (size_t)nsl < 1024) nsl >>= 1;
+    }
+    if (nsl > 1) {
+        uint32_t bad = 0;
+        for (size_t i = 0; i < n; i++) bad |= (uint32_t)actions_host[i] >= (uint32_t)A ? 1u : 0u;     // (branch-free: vectorises)
+        if (bad) {
+            h->act_next ^= 1;
+            for (size_t i = 0; i < n; i++)
+                if (actions_host[i] < 0 || actions_host[i] >= A) return fail(NGW_E_INVALID_ACTION, "%d is not in list", (int)actions_host[i]);   // pogostick_v1_env.py:236
+        }
+        if (!h->stream2) {
+            HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+            for (hipEvent_t& e : h->slice_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        uint8_t* const blk = static_cast<uint8_t*>(block);
+        const size_t per = (n / (size_t)nsl + 63) / 64 * 64;
+        int s_i = 0;
+        for (size_t first = 0; first < n; first += per, s_i++) {
+            const size_t count = n - first < per ? n - first : per;
+            for (size_t i = first; i < first + count; i++) a8[i] = (uint8_t)actions_host[i];
+            if (int rc = launch_step_slice(h, h->act_pin_dev + (size_t)slot * cap + first, (int64_t)first, (int64_t)count)) return rc;
+            HIP_TRY(hipEventRecord(h->slice_ev[s_i], h->stream));
+            HIP_TRY(hipStreamWaitEvent(h->stream2, h->slice_ev[s_i], 0));
+            NgwDiff d = {};
+            const uint8_t* const srcs[2] = {reinterpret_cast<const uint8_t*>(h->b.map) + first * S2, reinterpret_cast<const uint8_t*>(h->b.inv) + first * K * 4};
+            const uint64_t so[2] = {first * S2, first * K * 4}, nb[2] = {count * S2, count * K * 4};
+            int k = 0;
+            for (int r = with_map ? 0 : 1; r < 2; r++, k++) {
+                d.cur[k] = srcs[r]; d.shadow[k] = h->shadow[r] + so[r]; d.host[k] = h->mirror_dev + off[r] + so[r]; d.nbytes[k] = nb[r];
+            }
+            d.n_regions = k;
+            NgwWire w = {};
+            w.loc = h->b.loc + 2 * first; w.facing = h->b.facing + first; w.selected = h->b.selected + first; w.reward = h->b.reward + first;
+            w.done = h->b.done + first; w.info = h->b.info + first; w.flags = h->b.flags;
+            uint8_t* const st = h->mirror_dev;
+            w.pose = reinterpret_cast<uint32_t*>(st + off[2]) + first; w.reward16 = reinterpret_cast<int16_t*>(st + off[3]) + first; w.done8 = st + off[4] + first;
+            w.info32 = reinterpret_cast<uint32_t*>(st + off[5]) + first; w.flags_out = reinterpret_cast<uint32_t*>(st + off[6]);
+            w.n = (int64_t)count;
+            HIP_TRY(ngw_diff_wire_launch(&d, &w, h->stream2));
+        }
+        if (int rc = step_slices_done(h)) return rc;
+        HIP_TRY(hipEventRecord(h->act_ev[slot], h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream2));                     // every slice's results are in the block (each waited for its step kernel)
+        {
+            const int16_t* r16 = reinterpret_cast<const int16_t*>(blk + off[3]);
+            int32_t* r32 = reinterpret_cast<int32_t*>(blk + off[7]);
+            for (size_t i = 0; i < n; i++) r32[i] = r16[i];
+        }
+        h->mirror_valid = h->host_delta && h->mirror_block == block;
+        return NGW_OK;
+    }
     uint32_t bad = 0;
     for (size_t i = 0; i < n; i++) {                                  // (branch-free: vectorises)
         const uint32_t a = (uint32_t)actions_host[i];
@@ -350,13 +413,9 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
         for (size_t i = 0; i < n; i++)
             if (actions_host[i] < 0 || actions_host[i] >= A) return fail(NGW_E_INVALID_ACTION, "%d is not in list", (int)actions_host[i]);   // pogostick_v1_env.py:236
     }
-    uint64_t off[9];
-    host_step_layout_packed(h, off);
-    if (!h->wire_stage) { if (int rc = dev_alloc(h, &h->wire_stage, (size_t)(off[7] - off[2]))) return rc; }
 #ifdef NGW_HOSTTRACE
     const double p1 = pnow();                                          // actions validated and narrowed
 #endif
-    const bool delta = h->host_delta && h->mirror_valid && h->mirror_block == block;
     h->launch_use_action0 = false; h->launch_act_u8 = true;
     const int lrc = launch(h, NGW_MODE_STEP, 1, reinterpret_cast<const int32_t*>(h->act_pin_dev + (size_t)slot * cap), nullptr, 0, 0);
     h->launch_act_u8 = false;

@@ -203,6 +203,41 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     return NGW_OK;
 }
 
+// One SLICE [first, first + count) of a batched step through the in-place step kernel (first a multiple of 64): every array pointer of
+// the launch block is shifted to the slice's first env - the kernel's hot path works on those -, bid0 tells the cold path (which reads the
+// blob's unshifted arrays) where the slice starts.  Byte actions (ngw_step_host_packed's page-locked staging).  The caller issues the
+// slices of ONE step back to back and then calls step_slices_done.
+int launch_step_slice(ngw_handle* h, const uint8_t* actions_u8_dev, int64_t first, int64_t count) {
+    if (first == 0) {
+        h->mirror_valid = false;
+        if (h->boards_on && h->brd_dirty) {
+            if (int rc = rebuild_boards(h, h->b.map, h->b.brd, h->n_pad)) return rc;
+            h->brd_dirty = false;
+        }
+    }
+    const int64_t S2 = h->proto.S2, K = h->proto.K, BS = h->proto.BS;
+    NgwLaunch q = h->ns_proto;
+    q.b = h->b;
+    q.b.map += first * S2; q.b.inv += first * K; q.b.loc += first * 2; q.b.facing += first; q.b.selected += first; q.b.step_count += first;
+    q.b.reward += first; q.b.done += first; q.b.info += first;
+    if (q.b.brd) q.b.brd += first * BS;
+    if (q.lout) q.lout = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(q.lout) + first * q.l_rb);
+    q.n = count; q.bid0 = (uint32_t)(first / NGW_EPB);
+    q.mode = NGW_MODE_STEP; q.n_steps = 1; q.actions = reinterpret_cast<const int32_t*>(actions_u8_dev); q.autoreset = h->autoreset; q.horizon = h->horizon;
+    q.stamps = nullptr; q.seq = 0; q.action0 = 0; q.use_action0 = 2;
+    const unsigned grid = (unsigned)((count + NGW_EPB - 1) / NGW_EPB);
+    HIP_TRY(ngw_launch(h->dspec, &q, h->map_mode, 8 | (h->ext ? 2 : 0) | (h->boards_on ? 1 : 0), grid, h->ns_lds, h->stream));
+    return NGW_OK;
+}
+
+int step_slices_done(ngw_handle* h) {
+    if (h->prefetch_every > 0) {
+        h->since_refill += 1;
+        if (h->since_refill >= h->cadence) return launch_refill(h);
+    }
+    return NGW_OK;
+}
+
 void drop_graph(ngw_handle* h) {
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);

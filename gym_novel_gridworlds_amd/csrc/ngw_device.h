@@ -81,6 +81,8 @@ struct NgwLaunch {
     uint8_t* row_done;           /* [n_steps][row_stride]: 1 where the step ended an episode (done, or the horizon under autoreset) */
     int64_t row_stride;
     int32_t* acc;                /* [4][n_pad]: return / length of the running episode, sum of returns / count of the finished ones */
+    uint32_t bid0;               /* a per-launch step over a SLICE of the batch: the slice's first block (first env / 64); b.*, actions and the lidar rows
+                                  * point at the slice's first env, n is the slice's env count, the cold path adds bid0 to index the blob's unshifted arrays */
 };
 
 /* Uniform step parameters: every lane uses the same value, so the kernel reads them with SCALAR loads straight

@@ -79,6 +79,11 @@ struct ngw_handle {
     int hostres = 0;                         // single-wavefront handle with a host mirror (NgwMirror)
     uint32_t step_seq = 0, launch_seq = 0;   // hostres: sequence number the next step launch reports (launch_seq: only while ngw_step_host issues it)
     int32_t launch_action0 = 0; bool launch_use_action0 = false;   // one-env handles: the action of the launch ngw_step_host is issuing
+    // ngw_step_host_packed, pipelined: the batch steps in slices on the handle's stream while a second stream brings the finished slices'
+    // results across PCIe (api_slices: 0 = automatic - 4 slices from 32 768 envs, 2 from 8 192 -, NGW_API_SLICES=<n> fixes it, 1 = off)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t slice_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int api_slices = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing pair
     hipEvent_t order_ev = nullptr;             // ngw_stream_order
     bool ev_marked = false;                    // ngw_timing_mark recorded the closing event already
@@ -160,6 +165,8 @@ void layout_reset_fast(ngw_handle* h);
 // ngw_abi_launch.cpp
 int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, const uint8_t* mask_dev, uint64_t action_seed, int64_t t0);
 int launch_refill(ngw_handle* h);
+int launch_step_slice(ngw_handle* h, const uint8_t* actions_u8_dev, int64_t first, int64_t count);   // one slice of a batched step (byte actions), on the handle's stream
+int step_slices_done(ngw_handle* h);                // the bookkeeping of ONE batched step (refill cadence) once its slices are out
 int publish_nx(ngw_handle* h, bool on);
 int alloc_nx(ngw_handle* h, int depth, bool on);
 void adapt_cadence(ngw_handle* h);

@@ -161,3 +161,35 @@ def test_bit_row_lidar_with_terminal_capture_and_the_switch():
         v.close()
     finally:
         del os.environ['NGW_LIDAR_BOARDS']
+
+
+@pytest.mark.parametrize('n,slices', [(20000, ''), (9000, '3')])
+def test_bit_row_lidar_behind_the_pipelined_host_step(n, slices, monkeypatch):
+    """LidarInFront(VecNovelGridworld).step() on a big batch: the packed host step runs the batch in slices (shifted base pointers for the
+    kernel's hot path, a block offset for its cold path), each slice's launch builds its part of the observation rows."""
+    import gym_novel_gridworlds_amd as G
+    from oracle.ngw_oracle import Oracle, lidar
+    if slices:
+        monkeypatch.setenv('NGW_API_SLICES', slices)
+    spec = T.build_spec('axe10')
+    A, S, K = len(spec.actions_id), spec.map_size, len(spec.items_id)
+    v = G.VecNovelGridworld(spec=spec, num_envs=n, seed=6, autoreset=True, horizon=14)
+    w = G.LidarInFront(v, num_beams=8, dtype=np.int16, copy=False)
+    o = Oracle(spec.compile(), n, seed=6, autoreset=True, horizon=14)
+    cc = w._lidar.compile(spec)
+    first = w.reset(); o.reset()
+    assert (first == lidar(cc, S, K, o.st.map, o.st.loc, o.st.facing, o.st.inv)).all()
+    stag = (np.arange(n) * 5 % 14).astype(np.int32)
+    v.set_state(0, step_count=stag); o.st.step_count[:] = stag
+    rs = np.random.RandomState(8)
+    for t in range(45):
+        a = rs.randint(0, A, size=n).astype(np.int32)
+        obs, reward, done, info = w.step(a); o.step(a)
+        assert (reward == o.reward).all() and (done == o.done.astype(bool)).all(), t
+        exp = lidar(cc, S, K, o.st.map, o.st.loc, o.st.facing, o.st.inv)
+        bad = np.nonzero((obs != exp).any(1))[0]
+        assert bad.size == 0, (t, bad[:5])
+    assert v.step_reads_map_in_place and v.error_flags() == 0
+    st = v.get_state()
+    assert (st['map'] == o.st.map).all() and (st['inv'] == o.st.inv).all() and (st['episode'] == o.st.episode).all()
+    v.close()
