@@ -23,7 +23,7 @@ The JSON line carries, besides the contract's fields,
   repeats         the K-step region run R = 5 more times after the contract's one: median / min / max (device and wall)
   cold_region     the same W + K steps BEFORE the device-clock warm-up (a fresh process finds the GPU in a low power state)
   lidar           the step with the fused LidarInFront observation (what the reference's scripts train on), per row format
-  api_mode_lidar  LidarInFront(venv).step() host loop (PCIe-inclusive)
+  api_mode_lidar  LidarInFront(venv, dtype='packed', copy=False).step() host loop (PCIe-inclusive; the wrapper's opt-in fast path)
   resets_in_timed_region   the timed launches always contain auto-reset work: when K < H the episodes are started so
                   that every env reaches the horizon in the middle of the timed region
   gather          (N > 1) the one collective of the path: per-rank pack launch + torch.distributed.gather of the packed
@@ -605,7 +605,8 @@ def main():
             lv.close()
         del la
         wv = VecNovelGridworld(spec=spec, num_envs=n, seed=0, autoreset=True, horizon=HORIZON, device=local_rank)
-        w = LidarInFront(wv, num_beams=8)                     # (the batched wrapper's default: int16 rows, fused)
+        w = LidarInFront(wv, num_beams=8, dtype='packed', copy=False)   # the wrapper's FAST path, opted into: packed rows (uint8 beams + int16 inventory), the page-locked buffer itself
+                                                              # (its default returns a fresh int32 array per call, like the reference's np.array)
         w.reset()
         rs2 = np.random.RandomState(ACTION_SEED + 1)
         hb = rs2.randint(0, A, size=(8, n)).astype(np.int32)
@@ -617,8 +618,9 @@ def main():
             w.step(hb[i % 8])
         w_dt = time.perf_counter() - tw
         api_lidar = {'value': round(n * kl / w_dt, 1), 'unit': 'env-steps/s', 'ms_per_step': round(w_dt / kl * 1e3, 4), 'steps': kl,
-                     'what': 'LidarInFront(VecNovelGridworld).step(): int32 actions from host memory, the %d-value int16 observation (%d B per env) + reward / done / '
-                             'info back to host arrays every step; PCIe-inclusive' % (wv.lidar_len, wv.lidar_row_bytes)}
+                     'what': "LidarInFront(VecNovelGridworld, dtype='packed', copy=False).step(): int32 actions from host memory, the %d-value observation as packed rows "
+                             '(%d B per env: uint8 beam entries + int16 inventory) delivered by the pipelined host step itself, + reward / done / info, every step; '
+                             'PCIe-inclusive' % (wv.lidar_len, wv.lidar_row_bytes)}
         wv.close()
 
     # the one collective of the path, timed on its own: pack launch per rank + gather to rank 0 + unpack launch there

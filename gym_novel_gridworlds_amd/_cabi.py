@@ -25,7 +25,7 @@ SYMBOLS = ['ngw_abi_version', 'ngw_spec_size', 'ngw_last_error', 'ngw_device_cou
            'ngw_pack_layout', 'ngw_pack_obs', 'ngw_unpack_obs', 'ngw_rollout_outputs', 'ngw_episode_stats', 'ngw_host_step_layout', 'ngw_step_device_many',
            'ngw_set_reset_prefetch_depth', 'ngw_get_reset_prefetch_depth', 'ngw_stream_order', 'ngw_host_mirror_invalidate', 'ngw_reset_host',
            'ngw_lidar_row_layout', 'ngw_step_kernel_info', 'ngw_set_terminal_capture', 'ngw_get_terminal_obs', 'ngw_terminal_device_ptrs',
-           'ngw_host_step_layout_packed', 'ngw_step_host_packed']
+           'ngw_host_step_layout_packed', 'ngw_step_host_packed', 'ngw_lidar_host_rows']
 
 _lib = None
 
@@ -132,6 +132,8 @@ def lib():
     if hasattr(L, 'ngw_lidar_row_layout'):
         L.ngw_lidar_row_layout.argtypes = [vp] + [C.POINTER(C.c_int32)] * 4
     L.ngw_get_lidar.argtypes = [vp, vp]
+    if hasattr(L, 'ngw_lidar_host_rows'):
+        L.ngw_lidar_host_rows.argtypes = [vp, vp]
     L.ngw_lidar_device_ptr.argtypes = [vp, C.POINTER(vp)]
     L.ngw_agent_view.argtypes = [vp, C.c_int]
     L.ngw_get_agent_view.argtypes = [vp, vp]

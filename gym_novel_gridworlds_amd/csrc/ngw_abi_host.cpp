@@ -347,6 +347,10 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
     // soon as a slice's step kernel is done a second stream refreshes that slice's part of the caller's block across PCIe - while the next
     // slice's actions are still being narrowed on the host and its step kernel runs.  The reference raises for a bad action id BEFORE it
     // touches any state (pogostick_v1_env.py:236), so every id is checked first (read-only pass); narrowing then goes slice by slice.
+    // the fused lidar observation's rows ride along when the caller registered a buffer for them (ngw_lidar_host_rows)
+    const bool lrows = h->lidar_host_rows && h->lidar_fused && h->lidar_len;
+    size_t lrb = 0;
+    if (lrows) { NgwLaunch lq{}; lidar_format(h, lq); lrb = (size_t)lq.l_rb; }
     int nsl = 1;
     if (delta && h->nostage && (!h->lidar_fused || h->boards_on) && !h->hostres && !h->capturing) {
         nsl = h->api_slices > 0 ? h->api_slices : (n >= 32768 ? 4 : (n >= 8192 ? 2 : 1));
@@ -390,6 +394,7 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
             w.info32 = reinterpret_cast<uint32_t*>(st + off[5]) + first; w.flags_out = reinterpret_cast<uint32_t*>(st + off[6]);
             w.n = (int64_t)count;
             HIP_TRY(ngw_diff_wire_launch(&d, &w, h->stream2));
+            if (lrows) HIP_TRY(hipMemcpyAsync(h->lidar_host_rows + first * lrb, reinterpret_cast<const uint8_t*>(h->lidar_out) + first * lrb, count * lrb, hipMemcpyDefault, h->stream2));
         }
         if (int rc = step_slices_done(h)) return rc;
         HIP_TRY(hipEventRecord(h->act_ev[slot], h->stream));
@@ -458,6 +463,7 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
     if (merged) HIP_TRY(ngw_diff_wire_launch(&d, &w, h->stream));
     else HIP_TRY(ngw_wire_launch(&w, h->stream));
     if (!direct) HIP_TRY(hipMemcpyAsync(blk + off[2], h->wire_stage, (size_t)(off[7] - off[2]), hipMemcpyDefault, h->stream));
+    if (lrows) HIP_TRY(hipMemcpyAsync(h->lidar_host_rows, h->lidar_out, n * lrb, hipMemcpyDefault, h->stream));
 #ifdef NGW_HOSTTRACE
     const double p2 = pnow();                                          // everything enqueued
 #endif

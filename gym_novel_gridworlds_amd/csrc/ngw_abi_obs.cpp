@@ -141,6 +141,7 @@ int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg) {
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     h->lidar_len = L; h->lidar_world = world;
+    h->lidar_host_rows = nullptr;
     h->lidar_range = cfg->max_range; h->lidar_beams = cfg->num_beams; h->lidar_chan = cfg->n_chan; h->lidar_ninv = cfg->n_inv;
     if (h->lidar_fused) { if (int rc = layout_lds(h)) { h->lidar_fused = 0; layout_lds(h); boards_mode_update(h); upload_reset_u(h); return rc; } }
     const bool was = boards_mode_update(h);
@@ -158,6 +159,7 @@ int ngw_lidar_set_output(ngw_handle* h, int bits) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     drop_graph(h);                                   // captured launches bake the format in
     h->lidar_bits = bits;
+    h->lidar_host_rows = nullptr;                    // (the row size changed: the caller registers a buffer of the new size)
     if (h->lidar_len) {
         if (h->lidar_fused) { if (int rc = layout_lds(h)) return rc; }
         const bool was = boards_mode_update(h);
@@ -215,6 +217,15 @@ int ngw_get_lidar(ngw_handle* h, void* out_host) {
     lidar_format(h, q);
     HIP_TRY(hipMemcpyAsync(out_host, h->lidar_out, (size_t)h->n * (size_t)q.l_rb, hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return NGW_OK;
+}
+
+int ngw_lidar_host_rows(ngw_handle* h, void* rows_host) {
+    if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
+    if (rows_host && !h->lidar_len) return fail(NGW_E_INVALID_ARG, "ngw_lidar_host_rows before ngw_lidar_configure");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->lidar_host_rows = static_cast<uint8_t*>(rows_host);
     return NGW_OK;
 }
 

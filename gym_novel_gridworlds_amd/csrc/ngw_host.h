@@ -93,6 +93,7 @@ struct ngw_handle {
     int lidar_len = 0, lidar_cap = 0;         // lidar_cap: row length lidar_out was allocated for
     int lidar_bits = 32;                  // row format of the lidar observation (ngw_lidar_set_output): 32 (the default: the reference's integers), 16 or 8 = packed
     int lidar_world = 0;                  // the ray table is one world-frame table rotated by the facing (NgwLidarDev::woff)
+    uint8_t* lidar_host_rows = nullptr;   // ngw_lidar_host_rows: the packed host step also brings the observation rows across (the caller's page-locked buffer)
     NgwLaunch lidar_proto{};              // the stand-alone lidar launch: its own LDS layout
     // The O(1) lidar on occupancy bit rows (ngw_boards.inc).  lidar_boards: the configured ray table is the reference's default 8 beams and
     // the map is at most 32 x 32 (ngw_lidar_configure checks it entry by entry); boards_on: that, and the observation is fused - step launches

@@ -296,6 +296,7 @@ class VecNovelGridworld:
     # ------------------------------------------------------------------ reference surface, batched
     def reset(self, mask=None, copy=False):
         """reset() for all envs (or mask != 0).  Returns the Dict observation (host arrays)."""
+        self._lidar_rows_fresh = False
         m = None
         if mask is not None:
             m = np.ascontiguousarray(mask, np.uint8)
@@ -307,6 +308,7 @@ class VecNovelGridworld:
     def reset1(self):
         """reset() of a one-env handle for the gym.Env adapter: one C-ABI call (ngw_reset_host) that fills the host mirrors
         last_state() shows; a placement that cannot succeed raises like reset()."""
+        self._lidar_rows_fresh = False
         args = self.__dict__.get('_reset1_args')
         if args is None:
             assert self.num_envs == 1
@@ -340,6 +342,7 @@ class VecNovelGridworld:
             self._last_actions = a
             o._dirty = True
             self._steps_stale = True
+            self._lidar_rows_fresh = self.lidar_fused                  # (ngw_lidar_host_rows: the rows of this state are in the host buffer)
             obs = None if not with_obs else ({k: v.copy() for k, v in o.items()} if copy else o)
             reward, done = (self._reward.copy(), self._done.view(np.bool_).copy()) if copy else (self._reward, self._done.view(np.bool_))
             info = StepInfo({'_words': self._info_words.copy() if copy else self._info_words})
@@ -349,6 +352,7 @@ class VecNovelGridworld:
                 dict.__setitem__(info, '_final_fn', self.terminal_observation)
                 info['_final_observation'] = done
             return obs, reward, done, info
+        self._lidar_rows_fresh = False
         self._act_pinned[...] = a
         cache = self.__dict__.setdefault('_step_args', {})
         args = cache.get(bool(with_obs))
@@ -429,6 +433,7 @@ class VecNovelGridworld:
     def step1(self, action):
         """step() of a one-env handle for the gym.Env adapter: same C-ABI call, but the argument list is built once and the
         outputs come back as Python scalars: (reward, done, result, cost code, message code, message arg)."""
+        self._lidar_rows_fresh = False
         args = self.__dict__.get('_step1_args')
         if args is None:
             assert self.num_envs == 1
@@ -513,10 +518,12 @@ class VecNovelGridworld:
     # ------------------------------------------------------------------ device-resident path
     def step_device(self, actions_ptr):
         """One batched step with int32 actions already in HBM (`actions_ptr` = device address, e.g. tensor.data_ptr())."""
+        self._lidar_rows_fresh = False
         _cabi.check(_cabi.lib().ngw_step_device(self._h, C.c_void_p(int(actions_ptr))))
 
     def step_device_many(self, actions_ptr, step_stride, n_steps):
         """n_steps batched steps from one call: step i reads int32 actions at device address actions_ptr + 4 * i * step_stride."""
+        self._lidar_rows_fresh = False
         _cabi.check(_cabi.lib().ngw_step_device_many(self._h, C.c_void_p(int(actions_ptr)), int(step_stride), int(n_steps)))
 
     def _default_prefetch(self):
@@ -564,11 +571,13 @@ class VecNovelGridworld:
 
     def rollout(self, n_steps, action_seed=1234, t0=0):
         """Fused mode: n_steps steps in one launch with on-device uniform actions."""
+        self._lidar_rows_fresh = False
         _cabi.check(_cabi.lib().ngw_rollout(self._h, int(n_steps), int(action_seed), int(t0)))
 
     def rollout_actions(self, actions_ptr, step_stride, n_steps):
         """Fused mode with the caller's actions: n_steps steps in one launch, step t reads int32 actions at device address
         actions_ptr + 4 * t * step_stride (e.g. a [T, N] int32 tensor: data_ptr(), N, T)."""
+        self._lidar_rows_fresh = False
         _cabi.check(_cabi.lib().ngw_rollout_actions(self._h, C.c_void_p(int(actions_ptr)), int(step_stride), int(n_steps)))
 
     def rollout_outputs(self, reward_rows_ptr=0, done_rows_ptr=0, row_stride=0, accumulate=False):
@@ -665,6 +674,11 @@ class VecNovelGridworld:
             self._lidar_host = _cabi.pinned_array((self.num_envs, self.lidar_len), self.lidar_dtype)
         self.lidar_fused = bool(fused)
         _cabi.check(L.ngw_lidar_fuse(self._h, int(self.lidar_fused)))
+        # fused: the packed host step of a big batch brings the rows of the state it produced across with its own slices (one call, one
+        # synchronisation): lidar_observation() then hands out this buffer as long as nothing else has stepped the env since
+        self._lidar_rows_fresh = False
+        if self.lidar_fused and hasattr(L, 'ngw_lidar_host_rows'):
+            _cabi.check(L.ngw_lidar_host_rows(self._h, _cabi._ptr(self._lidar_host, self.lidar_dtype)))
 
     def _lidar_split(self, rows):
         """(beams uint8 [N, B * NC], inventory int16 [N, NI]) views of packed rows (numpy array or torch tensor [N, row_bytes])."""
@@ -681,6 +695,9 @@ class VecNovelGridworld:
         packed format the pair (beams, inventory), see lidar_configure."""
         if not self.lidar_fused:
             _cabi.check(_cabi.lib().ngw_lidar(self._h))
+        elif not device and self.__dict__.get('_lidar_rows_fresh'):   # the last call was a packed host step: it delivered the rows already
+            out = self._lidar_host.copy() if copy else self._lidar_host
+            return self._lidar_split(out) if self.lidar_packed else out
         if device:
             import torch
             p = C.c_void_p()
@@ -717,6 +734,7 @@ class VecNovelGridworld:
         return st
 
     def set_state(self, first=0, map=None, loc=None, facing=None, inv=None, selected=None, step_count=None, episode=None):
+        self._lidar_rows_fresh = False
         arrs = [(map, np.int8), (loc, np.int32), (facing, np.int32), (inv, np.int32), (selected, np.int32),
                 (step_count, np.int32), (episode, np.uint32)]
         conv = [None if a is None else np.ascontiguousarray(a, dt) for a, dt in arrs]
@@ -742,6 +760,7 @@ class VecNovelGridworld:
         _cabi.check(_cabi.lib().ngw_graph_build(self._h, C.c_void_p(int(actions_ptr)), int(step_stride), int(n_steps)))
 
     def graph_launch(self, reps=1):
+        self._lidar_rows_fresh = False
         _cabi.check(_cabi.lib().ngw_graph_launch(self._h, int(reps)))
 
     def timing_mark(self):

@@ -408,6 +408,11 @@ int ngw_lidar_fuse(ngw_handle* h, int enable);
 int ngw_lidar_set_output(ngw_handle* h, int bits);
 int ngw_lidar_row_layout(ngw_handle* h, int32_t* row_bytes, int32_t* beam_bytes, int32_t* inv_offset, int32_t* inv_bytes);
 int ngw_get_lidar(ngw_handle* h, void* out_host /* [n_envs] rows of the current format */);
+/* With the observation fused (ngw_lidar_fuse): rows_host != NULL - a page-locked buffer (ngw_host_alloc) of [n_envs] rows of the current
+ * format - makes every following ngw_step_host_packed deliver the rows of the state it produced into that buffer as part of the call
+ * (pipelined with the step's slices on big batches: what LidarInFront(VecNovelGridworld).step() returns needs no second call and no
+ * second synchronisation); NULL switches it off.  ngw_lidar_set_output / ngw_lidar_configure switch it off too (the row size changed). */
+int ngw_lidar_host_rows(ngw_handle* h, void* rows_host);
 int ngw_lidar_device_ptr(ngw_handle* h, void** out);
 
 /* AgentMap (observation_wrappers.py:83-129): ngw_agent_view() gathers, for every env, the (2*view_size+1)^2 window of the
