@@ -385,6 +385,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     if (const char* v = getenv("NGW_HOST_DELTA")) h->host_delta = atoi(v) != 0;
     if (const char* v = getenv("NGW_ZC_BYTES")) { h->zc_bytes = (size_t)atoll(v); if (!h->zc_bytes) h->zc_bytes = 1; }
     if (const char* v = getenv("NGW_API_SLICES")) h->api_slices = atoi(v);
+    if (const char* v = getenv("NGW_SOLO")) h->solo_enabled = atoi(v) != 0;
     {
         // Which per-launch step kernel: the one that reads the <= 14 cells a step needs straight from HBM, at EVERY map size.  Up to
         // round 3 the 10 x 10 (and 6 x 6) maps - whose 64 rows arrive in one round of loads and land in LDS as they are - kept the
@@ -586,6 +587,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
 int ngw_destroy(ngw_handle* h) {
     if (!h) return NGW_OK;
     (void)hipSetDevice(h->device);
+    if (h->solo_running) (void)solo_stop(h);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) (void)hipFree(p);
     for (void* p : h->host_allocs) (void)hipHostFree(p);
@@ -637,6 +639,7 @@ int ngw_stream_order(ngw_handle* h, void* other_stream, int handle_waits) {
 int ngw_sync(ngw_handle* h) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->solo_running) { if (int rc = solo_stop(h)) return rc; }
     HIP_TRY(hipStreamSynchronize(h->stream));
     return NGW_OK;
 }
@@ -673,6 +676,7 @@ int ngw_out_device_ptrs(ngw_handle* h, void** reward, void** done, void** info) 
 int ngw_error_flags(ngw_handle* h, uint32_t* flags) {
     if (!h || !flags) return fail(NGW_E_INVALID_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->solo_running) { if (int rc = solo_stop(h)) return rc; }
     HIP_TRY(hipMemcpyAsync(flags, h->b.flags, sizeof(uint32_t), hipMemcpyDefault, h->stream));
     HIP_TRY(hipMemsetAsync(h->b.flags, 0, sizeof(uint32_t), h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));

@@ -68,6 +68,7 @@ extern "C" {
 int ngw_get_obs(ngw_handle* h, int8_t* map, int32_t* loc, int32_t* facing, int32_t* inv) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->solo_running) { if (int rc = solo_stop(h)) return rc; }
     const size_t n = (size_t)h->n, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
     D2H(map, h->b.map, n * S2);
     D2H(loc, h->b.loc, n * 2 * sizeof(int32_t));
@@ -80,6 +81,7 @@ int ngw_get_obs(ngw_handle* h, int8_t* map, int32_t* loc, int32_t* facing, int32
 int ngw_get_step_out(ngw_handle* h, int32_t* reward, uint8_t* done, uint8_t* result, uint8_t* cost_code, uint16_t* msg_code, uint16_t* msg_arg) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->solo_running) { if (int rc = solo_stop(h)) return rc; }
     const size_t n = (size_t)h->n;
     D2H(reward, h->b.reward, n * sizeof(int32_t));
     D2H(done, h->b.done, n);
@@ -134,7 +136,18 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
                             {want_info ? (void*)h : nullptr, h->b.info, n * 4}};
     size_t total = 0;
     for (const Out& o : outs) if (o.host) total += (o.bytes + 255) & ~(size_t)255;
-    if (h->hostres) {
+    if (h->hostres && solo_ok(h)) {
+        // ONE env, reference semantics (the gym.Env adapter): the resident step loop (ngw_solo.inc) has speculated the outcome of every
+        // action from the committed state - this step is a look-up in its records plus a command posted for it to commit.  No launch, no
+        // wait (unless the caller steps faster than the device speculates).
+        if (int rc = solo_step(h, actions_host[0])) return rc;
+        const NgwMirror& m = h->mir;
+        const void* const mirrors[INFO] = {m.map, m.loc, m.facing, m.inv, m.reward, m.done, nullptr, m.selected, m.step_count};
+        for (int r = 0; r < INFO; r++)
+            if (outs[r].host && r != 6) memcpy(outs[r].host, mirrors[r], outs[r].bytes);
+        if (error_flags) *error_flags = *h->b.flags_host;
+        if (want_info) info_words = m.info;
+    } else if (h->hostres) {
         // Single-wavefront handle: ONE launch, no copy call, no stream synchronisation.  The action of a one-env handle travels
         // in the kernel's argument block (more envs: a page-locked array the kernel reads in place), the kernel steps the
         // state in HBM and copies the wave's rows into the host mirror, and the results are read there.
@@ -353,7 +366,9 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
     if (lrows) { NgwLaunch lq{}; lidar_format(h, lq); lrb = (size_t)lq.l_rb; }
     int nsl = 1;
     if (delta && h->nostage && (!h->lidar_fused || h->boards_on) && !h->hostres && !h->capturing) {
-        nsl = h->api_slices > 0 ? h->api_slices : (n >= 32768 ? 4 : (n >= 8192 ? 2 : 1));
+        // MEASURED AND NOT THE DEFAULT (profiles/r05_ab.md): at 65 536 envs one slice 64.8 us per call, two 84.4, four 100.0 - every slice costs
+        // two launches, an event record and a cross-stream wait (~10 us), more than the overlap returns.  NGW_API_SLICES=<n> still selects it.
+        nsl = h->api_slices > 0 ? h->api_slices : 1;
         if (nsl > 4) nsl = 4;
         while (nsl > 1 && n / (size_t)nsl < 1024) nsl >>= 1;
     }
@@ -541,6 +556,7 @@ int ngw_get_state(ngw_handle* h, int64_t first, int64_t count, int8_t* map, int3
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     if (first < 0 || count < 0 || first + count > h->n) return fail(NGW_E_INVALID_ARG, "env range [%lld, +%lld) out of bounds", (long long)first, (long long)count);
     HIP_TRY(hipSetDevice(h->device));
+    if (h->solo_running) { if (int rc = solo_stop(h)) return rc; }
     const size_t n = (size_t)count, f = (size_t)first, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
     D2H(map, h->b.map + f * S2, n * S2);
     D2H(loc, h->b.loc + f * 2, n * 2 * sizeof(int32_t));
@@ -588,6 +604,8 @@ int ngw_set_state(ngw_handle* h, int64_t first, int64_t count, const int8_t* map
         }
     }
     HIP_TRY(hipSetDevice(h->device));
+    if (h->solo_running) { if (int rc = solo_stop(h)) return rc; }
+    h->solo_mirror_valid = false;
     h->mirror_valid = false;
     if (map) h->brd_dirty = true;                    // (boards mode: the bit rows are rebuilt before the next step launch)
     H2D(h->b.map + f * S2, map, n * S2);

@@ -147,6 +147,8 @@ int launch_refill(ngw_handle* h) {
 }
 
 int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, const uint8_t* mask_dev, uint64_t action_seed, int64_t t0) {
+    if (h->solo_running) { if (int rc = solo_stop(h)) return rc; }
+    h->solo_mirror_valid = false;                     // (a per-launch step / reset refreshes the WHOLE mirror itself; the loop's host side starts from a copy)
     h->mirror_valid = false;                          // (ngw_step_host's delta path sets it again after its own launch)
     NgwLaunch a = h->proto;
     a.b = h->b;
@@ -227,6 +229,140 @@ int launch_step_slice(ngw_handle* h, const uint8_t* actions_u8_dev, int64_t firs
     q.stamps = nullptr; q.seq = 0; q.action0 = 0; q.use_action0 = 2;
     const unsigned grid = (unsigned)((count + NGW_EPB - 1) / NGW_EPB);
     HIP_TRY(ngw_launch(h->dspec, &q, h->map_mode, 8 | (h->ext ? 2 : 0) | (h->boards_on ? 1 : 0), grid, h->ns_lds, h->stream));
+    return NGW_OK;
+}
+
+// ---------------------------------------------------------------- the one-env handle's resident step loop (ngw_solo.inc)
+bool solo_ok(const ngw_handle* h) {
+    return h->solo_enabled && h->n == 1 && h->hostres && !h->autoreset && !h->lidar_fused && !h->term_on && !h->capturing && h->proto.S <= 46;
+}
+
+namespace {
+int solo_start(ngw_handle* h, int32_t commit0, uint32_t k0) {
+    const int S2 = h->proto.S2, K = h->proto.K;
+    if (!h->solo_mbox) {
+        void* q = nullptr;
+        HIP_TRY(hipHostMalloc(&q, 64, hipHostMallocMapped));
+        memset(q, 0, 64);
+        h->host_allocs.push_back(q);
+        h->solo_mbox = static_cast<uint32_t*>(q);
+        const size_t rec_dw = (size_t)((8 + K + 3) & ~3);
+        const size_t bytes = (NGW_SOLO_REC0 + NGW_MAX_ACTIONS * rec_dw) * 4;
+        HIP_TRY(hipHostMalloc(&q, bytes, hipHostMallocMapped));
+        memset(q, 0, bytes);
+        h->host_allocs.push_back(q);
+        h->solo_out = static_cast<uint32_t*>(q);
+        NgwSolo& p = h->solo_proto;
+        p = NgwSolo{};
+        p.mbox = h->solo_mbox; p.out = h->solo_out;
+        p.S = h->proto.S; p.S2 = S2; p.K = K; p.A = h->spec.n_actions; p.MSp = (S2 + 15) & ~15;
+        p.KP = K | 1; p.rec_dw = (int32_t)rec_dw;
+        p.timeout_ticks = 30000;                                      // 300 us without a command: the loop ends, the next step() starts a new one
+        if (const char* v = getenv("NGW_SOLO_TIMEOUT_US")) p.timeout_ticks = (uint32_t)atoi(v) * 100u;
+        uint32_t off = 0;
+        p.off_map = off; off += (uint32_t)(NGW_EPB * p.MSp / 4);
+        p.off_master = off; off += (uint32_t)(p.MSp / 4);
+        p.off_inv = off; off += (uint32_t)(NGW_EPB * p.KP);
+        p.off_invb = off; off += (uint32_t)(NGW_EPB * p.KP);
+        h->solo_lds = (size_t)off * 4;
+    }
+    if (!h->solo_mirror_valid) {
+        // the host applies every step's outcome to its mirror of the state: it has to start from what the device holds (anything else that
+        // ran on this handle since the last loop - resets, state injection, per-launch steps - may have left the mirror behind)
+        const NgwMirror& m = h->mir;
+        HIP_TRY(hipMemcpyAsync(m.map, h->b.map, (size_t)S2, hipMemcpyDefault, h->stream));
+        HIP_TRY(hipMemcpyAsync(m.loc, h->b.loc, 8, hipMemcpyDefault, h->stream));
+        HIP_TRY(hipMemcpyAsync(m.facing, h->b.facing, 4, hipMemcpyDefault, h->stream));
+        HIP_TRY(hipMemcpyAsync(m.inv, h->b.inv, (size_t)K * 4, hipMemcpyDefault, h->stream));
+        HIP_TRY(hipMemcpyAsync(m.selected, h->b.selected, 1, hipMemcpyDefault, h->stream));
+        HIP_TRY(hipMemcpyAsync(m.step_count, h->b.step_count, 4, hipMemcpyDefault, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->solo_mirror_valid = true;
+    }
+    NgwSolo p = h->solo_proto;
+    p.b = h->b; p.k0 = k0; p.commit0 = commit0;
+    ((volatile uint32_t*)h->solo_out)[0] = k0 - 1u;                  // (nothing speculated yet)
+    ((volatile uint32_t*)h->solo_out)[1] = 0u;
+    ((volatile uint32_t*)h->solo_mbox)[0] = k0;                      // (no command posted beyond the state the launch starts from ... or the one it commits first)
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    HIP_TRY(ngw_solo_launch(h->dspec, &p, h->ext, h->solo_lds, h->stream));
+    h->solo_running = true;
+    return NGW_OK;
+}
+inline void cpu_pause() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    __asm__ __volatile__("" ::: "memory");
+#endif
+}
+}  // namespace
+
+int solo_stop(ngw_handle* h) {
+    if (!h->solo_running) return NGW_OK;
+    volatile uint32_t* mb = h->solo_mbox; volatile uint32_t* out = h->solo_out;
+    mb[2] = 1u;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->solo_running = false;
+    if (out[0] != h->solo_seq) {
+        // the loop had ended (idle limit) before it saw the last command: a fresh launch commits it and, the quit word still up, leaves at once
+        if (out[0] + 1u != h->solo_seq) { mb[2] = 0u; return fail(NGW_E_HIP, "one-env step loop lost its place (device %u, host %u)", out[0], h->solo_seq); }
+        if (int rc = solo_start(h, h->solo_last_action, h->solo_seq - 1u)) { mb[2] = 0u; return rc; }
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->solo_running = false;
+    }
+    mb[2] = 0u;
+    return NGW_OK;
+}
+
+int solo_step(ngw_handle* h, int32_t action) {
+    volatile uint32_t* mb = h->solo_mbox; volatile uint32_t* out = h->solo_out;
+    if (!h->solo_running) { if (int rc = solo_start(h, -1, h->solo_seq)) return rc; mb = h->solo_mbox; out = h->solo_out; }
+    // the records of the committed state: usually there already (the device speculated while the caller was busy)
+    for (uint64_t spin = 0;; spin++) {
+        if (out[0] == h->solo_seq) break;
+        if (out[1]) {                                                // the loop ended (idle limit) ...
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            if (out[0] == h->solo_seq) break;                        // ... after it had speculated this state: the records stand
+            HIP_TRY(hipStreamSynchronize(h->stream));                // ... before it saw the last command: a fresh launch commits it first
+            h->solo_running = false;
+            if (out[0] + 1u != h->solo_seq) return fail(NGW_E_HIP, "one-env step loop lost its place (device %u, host %u)", out[0], h->solo_seq);
+            if (int rc = solo_start(h, h->solo_last_action, h->solo_seq - 1u)) return rc;
+            spin = 0;
+            continue;
+        }
+        if (spin > (1ull << 26)) return fail(NGW_E_HIP, "one-env step loop does not answer");
+        cpu_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    // ---- the outcome of `action`, applied to the host's mirror of the state (what the kernel's commit does to the state in HBM)
+    const NgwSolo& p = h->solo_proto;
+    const uint32_t* rec = h->solo_out + NGW_SOLO_REC0 + (size_t)action * (size_t)p.rec_dw;
+    const NgwMirror& m = h->mir;
+    const int S = p.S, K = p.K;
+    const uint32_t w2 = rec[2], w3 = rec[3];
+    const int nr = (int)((w2 >> 8) & 255u), nc = (int)((w2 >> 16) & 255u);
+    if ((w3 >> 8) & 1u) m.map[rec[5]] = (int8_t)((w3 >> 16) & 255u);
+    if (rec[6]) {
+        const int ac = nr * S + nc;
+        for (int k = 0; k < 9; k++) if ((rec[6] >> k) & 1u) m.map[ac + (k / 3 - 1) * S + (k % 3 - 1)] = 0;
+    }
+    for (int k = 0; k < K; k++) m.inv[k] = (int32_t)rec[8 + k];
+    m.loc[0] = nr; m.loc[1] = nc; m.facing[0] = (int32_t)(w2 >> 24); m.selected[0] = (uint8_t)(w3 & 255u); m.step_count[0] = (int32_t)rec[4];
+    m.reward[0] = (int32_t)rec[0]; m.done[0] = (uint8_t)(w2 & 1u); m.info[0] = rec[1];
+    if (rec[7]) *h->b.flags_host |= rec[7];
+    // ---- post the command: the loop commits it and speculates from the new state
+    h->solo_last_action = action;
+    h->solo_seq++;
+    if (out[1]) {                                                    // (the loop has ended meanwhile: start the next one with the commit)
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->solo_running = false;
+        return solo_start(h, action, h->solo_seq - 1u);
+    }
+    mb[1] = (uint32_t)action;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    mb[0] = h->solo_seq;
     return NGW_OK;
 }
 

@@ -352,4 +352,25 @@ extern "C"
 #endif
 hipError_t ngw_lidar_boards_launch(const NgwLaunch* a, unsigned grid, size_t lds_bytes, hipStream_t stream);
 
+/* The one-env handle's resident step loop (ngw_solo.inc): kernel arguments.  The kernel stays resident between the steps of a Python loop,
+ * speculates the outcome of every action from the committed state into host-visible records, and commits the action the host posts. */
+struct NgwSolo {
+    NgwBufs b;                   // env 0's rows (the handle's ordinary state arrays)
+    volatile uint32_t* mbox;     // host -> device, page-locked host memory: [0] command sequence number, [1] action, [2] quit
+    uint32_t* out;               // device -> host, page-locked host memory: [0] sequence of the speculated state, [1] exited, [NGW_SOLO_REC0 ..) records
+    int32_t S, S2, K, A, MSp;    // MSp = bytes per private map copy (S2 rounded up to 16)
+    uint32_t k0;                 // sequence number of the state the launch starts from
+    int32_t commit0;             // an action the host posted while the previous launch was exiting: committed first (-1 = none)
+    uint32_t timeout_ticks;      // idle time after which the loop ends (100 MHz ticks)
+    uint32_t off_map, off_master, off_inv, off_invb;   // LDS dword offsets: private maps [64][MSp] | master map | inventory rows [64][KP] | their backup
+    int32_t KP, rec_dw;          // LDS inventory row stride; dwords per record (8 + K, rounded up to 4)
+};
+#define NGW_SOLO_REC0 16         // records start at this dword of `out`
+// record dwords: [0] reward  [1] info  [2] done | r << 8 | c << 16 | f << 24  [3] selected | wcell << 8 | cell value << 16  [4] step_count
+//                [5] cell index of the write  [6] 3 x 3 pick-up mask around the new position  [7] -  [8 ..) the inventory row
+#ifdef __cplusplus
+extern "C"
+#endif
+hipError_t ngw_solo_launch(const NgwDevSpec* dspec, const struct NgwSolo* p, int ext, size_t lds_bytes, hipStream_t stream);
+
 #endif

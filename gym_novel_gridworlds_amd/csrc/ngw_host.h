@@ -80,10 +80,20 @@ struct ngw_handle {
     uint32_t step_seq = 0, launch_seq = 0;   // hostres: sequence number the next step launch reports (launch_seq: only while ngw_step_host issues it)
     int32_t launch_action0 = 0; bool launch_use_action0 = false;   // one-env handles: the action of the launch ngw_step_host is issuing
     // ngw_step_host_packed, pipelined: the batch steps in slices on the handle's stream while a second stream brings the finished slices'
-    // results across PCIe (api_slices: 0 = automatic - 4 slices from 32 768 envs, 2 from 8 192 -, NGW_API_SLICES=<n> fixes it, 1 = off)
+    // results across PCIe (api_slices: 0 / 1 = off - the default: measured slower, profiles/r05_ab.md -, NGW_API_SLICES=<n> selects n slices)
     hipStream_t stream2 = nullptr;
     hipEvent_t slice_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int api_slices = 0;
+    // The one-env handle's resident step loop (ngw_solo.inc; NGW_SOLO=0 switches it off): a kernel that stays on the stream between the steps
+    // of a host loop, speculates every action's outcome into `solo_out` and commits what the host posts into `solo_mbox`.
+    int solo_enabled = 1;
+    bool solo_running = false, solo_mirror_valid = false;
+    uint32_t* solo_mbox = nullptr;            // page-locked, GPU-addressable: [0] command sequence, [1] action, [2] quit
+    uint32_t* solo_out = nullptr;             // page-locked, GPU-addressable: [0] speculated sequence, [1] exited, records from dword NGW_SOLO_REC0
+    uint32_t solo_seq = 0;                    // sequence number of the committed state as the host counts it
+    int32_t solo_last_action = -1;            // the last action posted (re-posted to a fresh launch if the loop ended before it took it)
+    NgwSolo solo_proto{};
+    size_t solo_lds = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing pair
     hipEvent_t order_ev = nullptr;             // ngw_stream_order
     bool ev_marked = false;                    // ngw_timing_mark recorded the closing event already
@@ -166,6 +176,9 @@ void layout_reset_fast(ngw_handle* h);
 // ngw_abi_launch.cpp
 int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, const uint8_t* mask_dev, uint64_t action_seed, int64_t t0);
 int launch_refill(ngw_handle* h);
+int solo_stop(ngw_handle* h);                       // ends the one-env handle's resident step loop (no-op when it is not running); every other entry point calls it first
+int solo_step(ngw_handle* h, int32_t action);      // one step() through the loop: the host mirror (h->mir) holds the new state afterwards
+bool solo_ok(const ngw_handle* h);
 int launch_step_slice(ngw_handle* h, const uint8_t* actions_u8_dev, int64_t first, int64_t count);   // one slice of a batched step (byte actions), on the handle's stream
 int step_slices_done(ngw_handle* h);                // the bookkeeping of ONE batched step (refill cadence) once its slices are out
 int publish_nx(ngw_handle* h, bool on);

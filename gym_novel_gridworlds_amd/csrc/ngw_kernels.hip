@@ -1146,6 +1146,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
 
 #include "ngw_boards.inc"
 #include "ngw_lean.inc"
+#include "ngw_solo.inc"
 #include "ngw_reset.inc"
 
 // ---------------------------------------------------------------- LidarInFront observation kernel (stand-alone launch)
@@ -1411,6 +1412,15 @@ __global__ void ngw_nop_kernel(const NgwDevSpec* dspec, const NgwLaunch a) {}
 }  // namespace
 
 #if NGW_HAS(5)
+extern "C" hipError_t ngw_solo_launch(const NgwDevSpec* dspec, const NgwSolo* p, int ext, size_t lds_bytes, hipStream_t stream) {
+    const void* fn = ext ? reinterpret_cast<const void*>(ngw_solo_kernel<true>) : reinterpret_cast<const void*>(ngw_solo_kernel<false>);
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    void* args[] = {const_cast<NgwDevSpec**>(&dspec), const_cast<NgwSolo*>(p)};
+    return hipLaunchKernel(fn, dim3(1), dim3(NGW_EPB), args, lds_bytes, stream);
+}
 extern "C" hipError_t ngw_reset_fast_launch(const NgwDevSpec* dspec, const NgwResetFast* a, int nw, int subset, unsigned grid, size_t lds_bytes,
                                             hipStream_t stream) {
     const void* fn = nullptr;

@@ -851,13 +851,13 @@ def test_big_batch_host_step_uses_one_block_and_matches_oracle():
 
 
 @pytest.mark.parametrize('cfg,n,horizon,slices', [('pogo10', 40000, 9, ''), ('axe10', 20000, 40, ''), ('add32', 4096, 15, '4'), ('pogo13', 30000, 11, '3'), ('crate10m', 20000, 25, '1'),
-                                                  ('fire10h', 9000, 30, '2'), ('bow20', 70000, 13, '')])
+                                                  ('fire10h', 9000, 30, '2'), ('bow20', 70000, 13, '4')])
 def test_host_step_delta_refresh_matches_oracle(cfg, n, horizon, slices, monkeypatch):
     """ngw_step_host on a big batch moves only what changed (include/ngw.h ngw_host_step_layout): the host observation equals
     the oracle's after EVERY step - through in-step resets, entity pick-ups and crates, odd row sizes - and after everything
     that invalidates the mirror in between (explicit resets, device steps, a fused rollout, state injection, refresh_host).
     `slices`: the pipelined form of the packed host step (the batch steps in slices while a second stream brings finished slices across
-    PCIe) - '' = the library's choice (4 slices from 32 768 envs, 2 from 8 192), a number fixes it (1 = off; a slice is a multiple of 64 envs,
+    PCIe) - '' = the library's default (one slice: the pipelined form measured slower), a number selects it (a slice is a multiple of 64 envs,
     so batch sizes that are no multiple of 64 x slices end in a short last slice)."""
     import torch
     if slices:
