@@ -453,7 +453,7 @@ uint32_t ngwo_step_batch(const ngw_spec* sp, int64_t n, int8_t* map, int32_t* lo
                          int64_t env_index_base) {
     const int S2 = sp->map_size * sp->map_size, K = sp->n_items;
     uint32_t flags = 0;
-#pragma omp parallel for schedule(static) reduction(| : flags)
+#pragma omp parallel for schedule(static) reduction(| : flags) if (n >= 512)
     for (int64_t i = 0; i < n; i++)
         flags |= step_one(sp, i, map + i * S2, loc + 2 * i, facing + i, inv + i * K, selected + i, step_count + i,
                           episode + i, actions[i], reward + i, done + i, info + i, autoreset, horizon, seed, env_index_base);
@@ -465,7 +465,7 @@ uint32_t ngwo_reset_batch(const ngw_spec* sp, int64_t n, const uint8_t* mask, in
                           int64_t env_index_base) {
     const int S2 = sp->map_size * sp->map_size, K = sp->n_items;
     uint32_t flags = 0;
-#pragma omp parallel for schedule(static) reduction(| : flags)
+#pragma omp parallel for schedule(static) reduction(| : flags) if (n >= 512)
     for (int64_t i = 0; i < n; i++) {
         if (mask && !mask[i]) continue;
         episode[i] += 1;
@@ -483,7 +483,7 @@ uint32_t ngwo_rollout_batch(const ngw_spec* sp, int64_t n, int32_t n_steps, int6
                             uint64_t seed, int64_t env_index_base) {
     const int S2 = sp->map_size * sp->map_size, K = sp->n_items;
     uint32_t flags = 0;
-#pragma omp parallel for schedule(static) reduction(| : flags)
+#pragma omp parallel for schedule(static) reduction(| : flags) if (n >= 512)
     for (int64_t i = 0; i < n; i++)
         for (int32_t t = 0; t < n_steps; t++) {
             int32_t a = (int32_t)ngwo_rollout_action(action_seed, (uint64_t)(env_index_base + i), (uint64_t)(t0 + t),
