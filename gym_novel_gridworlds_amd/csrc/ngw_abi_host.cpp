@@ -41,12 +41,12 @@ bool one_block(const ngw_handle* h, const void* map, const void* loc, const void
     return true;
 }
 
-void host_step_layout_packed(const ngw_handle* h, uint64_t off[9]) {
+void host_step_layout_packed(const ngw_handle* h, uint64_t off[8]) {
     const uint64_t n = (uint64_t)h->n, S2 = (uint64_t)h->proto.S2, K = (uint64_t)h->proto.K;
-    const uint64_t bytes[8] = {n * S2, n * K * 4, n * 4, n * 2, n, n * 4, 4, n * 4};   // (the last one - reward as int32 - is filled on the host, not by the device)
+    const uint64_t bytes[7] = {n * S2, n * K * 4, n * 4, n * 4, n, n * 4, 4};
     uint64_t o = 0;
-    for (int i = 0; i < 8; i++) { off[i] = o; o += (bytes[i] + 255) & ~(uint64_t)255; }
-    off[8] = o;
+    for (int i = 0; i < 7; i++) { off[i] = o; o += (bytes[i] + 255) & ~(uint64_t)255; }
+    off[7] = o;
 }
 
 /* Payload of the multi-GPU observation gather: the seven SoA arrays back to back, each section padded to 16 bytes. */
@@ -308,23 +308,19 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
 
 /* ---- the host step in its narrow wire format (big batches)
  * Block sections (index: 0 map int8 [n][S*S], 1 inventory int32 [n][K], 2 pose uint32 [n] = r | c << 8 | facing << 16 | selected << 24,
- * 3 reward int16 [n], 4 done uint8 [n], 5 info uint32 [n] (NGW_INFO_*), 6 error flags uint32), each padded to 256 bytes; offsets7[7] =
- * the block's size.  Sections 0-1 are refreshed by deltas (only the 16-byte pieces a step changed cross PCIe), 2-6 are dense and
- * come back with ONE copy: 11 B per env against the 26 B of the int32 SoA arrays of ngw_step_host. */
-int ngw_host_step_layout_packed(ngw_handle* h, uint64_t* offsets9) {
-    if (!h || !offsets9) return fail(NGW_E_INVALID_ARG, "NULL argument");
-    host_step_layout_packed(h, offsets9);
+ * 3 reward int32 [n] (ABI 3; int16 before: widening it on the host meant reading 128 KB the device had just written - ~12 us of cache
+ * misses per call at 65 536 envs - where two more bytes per env on the wire cost ~2), 4 done uint8 [n], 5 info uint32 [n] (NGW_INFO_*),
+ * 6 error flags uint32), each padded to 256 bytes; offsets8[7] = the block's size.  Sections 0-1 are refreshed by deltas (only the 16-byte
+ * pieces a step changed cross PCIe), 2-6 are dense: 13 B per env against the 26 B of the int32 SoA arrays of ngw_step_host. */
+int ngw_host_step_layout_packed(ngw_handle* h, uint64_t* offsets8) {
+    if (!h || !offsets8) return fail(NGW_E_INVALID_ARG, "NULL argument");
+    host_step_layout_packed(h, offsets8);
     return NGW_OK;
 }
 
 int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block, int with_map) {
     if (!h || !actions_host || !block) return fail(NGW_E_INVALID_ARG, "NULL argument");
     const ngw_spec& sp = h->spec;
-    {   // rewards travel as int16 here
-        const int rw[5] = {sp.reward_step, sp.reward_done, sp.fire_reward, sp.place_reward, sp.ext_reward};
-        for (int v : rw) if (v < -32768 || v > 32767) return fail(NGW_E_INVALID_ARG, "a reward of %d does not fit the narrow wire format (int16): use ngw_step_host", v);
-        for (int i = 0; i < sp.n_items; i++) if (sp.break_reward[i] < -32768 || sp.break_reward[i] > 32767) return fail(NGW_E_INVALID_ARG, "break_reward does not fit int16: use ngw_step_host");
-    }
     const size_t n = (size_t)h->n, S2 = (size_t)h->proto.S2, K = (size_t)h->proto.K;
     if (h->proto.S > 255) return fail(NGW_E_INVALID_ARG, "map_size beyond the pose bytes");
     HIP_TRY(hipSetDevice(h->device));
@@ -352,7 +348,7 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
 #endif
     HIP_TRY(hipEventSynchronize(h->act_ev[slot]));
     uint8_t* const a8 = h->act_pin + (size_t)slot * cap;
-    uint64_t off[9];
+    uint64_t off[8];
     host_step_layout_packed(h, off);
     if (!h->wire_stage) { if (int rc = dev_alloc(h, &h->wire_stage, (size_t)(off[7] - off[2]))) return rc; }
     const bool delta = h->host_delta && h->mirror_valid && h->mirror_block == block;
@@ -405,7 +401,7 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
             w.loc = h->b.loc + 2 * first; w.facing = h->b.facing + first; w.selected = h->b.selected + first; w.reward = h->b.reward + first;
             w.done = h->b.done + first; w.info = h->b.info + first; w.flags = h->b.flags;
             uint8_t* const st = h->mirror_dev;
-            w.pose = reinterpret_cast<uint32_t*>(st + off[2]) + first; w.reward16 = reinterpret_cast<int16_t*>(st + off[3]) + first; w.done8 = st + off[4] + first;
+            w.pose = reinterpret_cast<uint32_t*>(st + off[2]) + first; w.reward32 = reinterpret_cast<int32_t*>(st + off[3]) + first; w.done8 = st + off[4] + first;
             w.info32 = reinterpret_cast<uint32_t*>(st + off[5]) + first; w.flags_out = reinterpret_cast<uint32_t*>(st + off[6]);
             w.n = (int64_t)count;
             HIP_TRY(ngw_diff_wire_launch(&d, &w, h->stream2));
@@ -414,11 +410,6 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
         if (int rc = step_slices_done(h)) return rc;
         HIP_TRY(hipEventRecord(h->act_ev[slot], h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream2));                     // every slice's results are in the block (each waited for its step kernel)
-        {
-            const int16_t* r16 = reinterpret_cast<const int16_t*>(blk + off[3]);
-            int32_t* r32 = reinterpret_cast<int32_t*>(blk + off[7]);
-            for (size_t i = 0; i < n; i++) r32[i] = r16[i];
-        }
         h->mirror_valid = h->host_delta && h->mirror_block == block;
         return NGW_OK;
     }
@@ -472,7 +463,7 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
     // info straight into it across PCIe, like the delta kernel before it - no staging, no copy operation behind the kernels.
     const bool direct = delta;
     uint8_t* const st = direct ? h->mirror_dev : h->wire_stage - off[2];   // (staging holds sections 2 .. 6 at their block offsets)
-    w.pose = reinterpret_cast<uint32_t*>(st + off[2]); w.reward16 = reinterpret_cast<int16_t*>(st + off[3]); w.done8 = st + off[4];
+    w.pose = reinterpret_cast<uint32_t*>(st + off[2]); w.reward32 = reinterpret_cast<int32_t*>(st + off[3]); w.done8 = st + off[4];
     w.info32 = reinterpret_cast<uint32_t*>(st + off[5]); w.flags_out = reinterpret_cast<uint32_t*>(st + off[6]);
     w.n = (int64_t)n;
     if (merged) HIP_TRY(ngw_diff_wire_launch(&d, &w, h->stream));
@@ -494,11 +485,6 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
         }
     }
 #endif
-    {   // reward: int16 on the wire, int32 for the caller (section 7; plain loop: the compiler vectorises the sign extension)
-        const int16_t* r16 = reinterpret_cast<const int16_t*>(blk + off[3]);
-        int32_t* r32 = reinterpret_cast<int32_t*>(blk + off[7]);
-        for (size_t i = 0; i < n; i++) r32[i] = r16[i];
-    }
     // (a delta step that skipped the map leaves the map's shadow describing what the block holds: the next step that wants the map
     //  brings every change since across)
     h->mirror_valid = h->host_delta && h->mirror_block == block;

@@ -318,7 +318,7 @@ hipError_t ngw_diff_launch(const struct NgwDiff* p, hipStream_t stream);
 struct NgwWire {
     const int32_t* loc; const int32_t* facing; const uint8_t* selected; const int32_t* reward; const uint8_t* done; const uint32_t* info;
     const uint32_t* flags;
-    uint32_t* pose; int16_t* reward16; uint8_t* done8; uint32_t* info32; uint32_t* flags_out;
+    uint32_t* pose; int32_t* reward32; uint8_t* done8; uint32_t* info32; uint32_t* flags_out;
     int64_t n;
 };
 #ifdef __cplusplus

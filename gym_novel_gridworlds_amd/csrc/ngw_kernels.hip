@@ -1216,8 +1216,7 @@ __global__ __launch_bounds__(256) void ngw_diff_kernel(const NgwDiff p) {
 }
 
 // Narrow wire format of the host step (NgwWire, ngw_step_host_packed): one lane per env narrows pose / reward / done / info into
-// four dense arrays of a staging payload (reads 22 B, writes 11 B per env; coalesced both ways).  Rewards are small integers
-// (-25 .. 50 in the reference); a spec with a reward beyond int16 is refused by the host before this format is used.
+// four dense arrays of a staging payload (reads 22 B, writes 13 B per env; coalesced both ways).
 __global__ __launch_bounds__(256) void ngw_wire_kernel(const NgwWire p) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e == 0) *p.flags_out = *p.flags;
@@ -1225,7 +1224,7 @@ __global__ __launch_bounds__(256) void ngw_wire_kernel(const NgwWire p) {
     const int r = p.loc[2 * e], c = p.loc[2 * e + 1], f = p.facing[e];
     const uint32_t sel = p.selected[e];
     p.pose[e] = (uint32_t)(r & 255) | ((uint32_t)(c & 255) << 8) | ((uint32_t)(f & 255) << 16) | (sel << 24);
-    p.reward16[e] = (int16_t)p.reward[e];
+    p.reward32[e] = p.reward[e];
     p.done8[e] = p.done[e];
     p.info32[e] = p.info[e];
 }
@@ -1241,7 +1240,7 @@ __global__ __launch_bounds__(256) void ngw_diff_wire_kernel(const NgwDiff p, con
             const int rr = w.loc[2 * e], c = w.loc[2 * e + 1], f = w.facing[e];
             const uint32_t sel = w.selected[e];
             w.pose[e] = (uint32_t)(rr & 255) | ((uint32_t)(c & 255) << 8) | ((uint32_t)(f & 255) << 16) | (sel << 24);
-            w.reward16[e] = (int16_t)w.reward[e];
+            w.reward32[e] = w.reward[e];
             w.done8[e] = w.done[e];
             w.info32[e] = w.info[e];
         }

@@ -194,7 +194,7 @@ class VecNovelGridworld:
         and leaves the env as it was - the reference, too, asserts before it changes anything.  The state is undefined until the
         next reset(), as after construction."""
         old_h, old_attrs = self._h, dict(self.__dict__)
-        for name in VecNovelGridworld._HOST_ATTRS + ('_host', '_step_args', '_step1_args', '_step1_fn', '_step1_mv', '_state1_mv', '_reset1_args', '_last_state_views', '_lidar_host', '_view_host', '_last_actions', '_packed_block', '_steps_stale', '_reward_wire'):
+        for name in VecNovelGridworld._HOST_ATTRS + ('_host', '_step_args', '_step1_args', '_step1_fn', '_step1_mv', '_state1_mv', '_reset1_args', '_last_state_views', '_lidar_host', '_view_host', '_last_actions', '_packed_block', '_steps_stale'):
             self.__dict__.pop(name, None)
         self._h = C.c_void_p()
         try:
@@ -209,7 +209,7 @@ class VecNovelGridworld:
             _cabi.lib().ngw_destroy(old_h)
         return self
 
-    _HOST_ATTRS = ('_obs', '_reward', '_reward_wire', '_done', '_act_pinned', '_sel_host', '_steps_host', '_result', '_cost', '_msg', '_arg', '_flags_np', '_info_words')
+    _HOST_ATTRS = ('_obs', '_reward', '_done', '_act_pinned', '_sel_host', '_steps_host', '_result', '_cost', '_msg', '_arg', '_flags_np', '_info_words')
 
     def __getattr__(self, name):
         # The host mirrors (10 MB page-locked at 65 536 envs, 157 B per env) exist only for the host API; a handle that is
@@ -217,7 +217,7 @@ class VecNovelGridworld:
         if name in VecNovelGridworld._HOST_ATTRS:
             if self.__dict__.get('_host') is None:
                 N, S, K = self.num_envs, self.map_size, self.n_items
-                if self._one_block_path() and self._rewards_fit_int16():   # (a spec with a bigger reward keeps the int32 one-block path)
+                if self._one_block_path():
                     self._make_packed_host()
                     return self.__dict__[name]
                 # ONE page-locked block laid out as ngw_host_step_layout says: a big batch's step() then comes back with a single
@@ -234,7 +234,7 @@ class VecNovelGridworld:
                           'agent_facing_id': sec(2, (N,), np.int32), 'inventory_items_quantity': sec(3, (N, K), np.int32)},
                     _reward=sec(4, (N,), np.int32), _done=sec(5, (N,), np.uint8), _flags_np=sec(7, (1,), np.uint32),
                     # the packed info words of the last step(): big batches (the one-block path of ngw_step_host) decode them lazily
-                    _info_words=sec(6, (N,), np.uint32) if self._one_block_path() else None, _reward_wire=None,
+                    _info_words=sec(6, (N,), np.uint32) if self._one_block_path() else None,
                     _sel_host=sec(8, (N,), np.uint8), _steps_host=sec(9, (N,), np.int32),     # selected item / step_count after the last step()
                     _act_pinned=_cabi.pinned_array((N,), np.int32),
                     _result=np.zeros(N, np.uint8), _cost=np.zeros(N, np.uint8), _msg=np.zeros(N, np.uint16), _arg=np.zeros(N, np.uint16))
@@ -244,11 +244,11 @@ class VecNovelGridworld:
 
     def _make_packed_host(self):
         """Host mirrors of a big batch: ONE page-locked block in the narrow wire format (include/ngw.h ngw_host_step_layout_packed) -
-        map and inventory refreshed by deltas, pose as four bytes per env, reward int16, done uint8, packed info words."""
+        map and inventory refreshed by deltas, pose as four bytes per env, reward int32, done uint8, packed info words."""
         N, S, K = self.num_envs, self.map_size, self.n_items
-        offs = (C.c_uint64 * 9)()
+        offs = (C.c_uint64 * 8)()
         _cabi.check(_cabi.lib().ngw_host_step_layout_packed(self._h, offs))
-        block = _cabi.pinned_array((int(offs[8]),), np.uint8)
+        block = _cabi.pinned_array((int(offs[7]),), np.uint8)
 
         def sec(i, shape, dt):
             nb = int(np.prod(shape)) * np.dtype(dt).itemsize
@@ -257,10 +257,8 @@ class VecNovelGridworld:
         obs = LazyObs({'map': sec(0, (N, S, S), np.int8), 'agent_location': np.zeros((N, 2), np.int32),
                        'agent_facing_id': np.zeros(N, np.int32), 'inventory_items_quantity': sec(1, (N, K), np.int32)})
         obs._pose, obs._dirty = pose, False
-        # reward: the wire carries int16 (section 3); the C call widens it into the block's int32 section 7, so the dtype step() returns
-        # does not depend on the batch size (in-dtype arithmetic on an int16 view would overflow at reward * 1000)
         self.__dict__['_host'] = dict(
-            _obs=obs, _reward=sec(7, (N,), np.int32), _reward_wire=sec(3, (N,), np.int16), _done=sec(4, (N,), np.uint8), _info_words=sec(5, (N,), np.uint32), _flags_np=sec(6, (1,), np.uint32),
+            _obs=obs, _reward=sec(3, (N,), np.int32), _done=sec(4, (N,), np.uint8), _info_words=sec(5, (N,), np.uint32), _flags_np=sec(6, (1,), np.uint32),
             _sel_host=pose[:, 3], _steps_host=np.zeros(N, np.int32), _act_pinned=np.zeros(N, np.int32),
             _result=np.zeros(N, np.uint8), _cost=np.zeros(N, np.uint8), _msg=np.zeros(N, np.uint16), _arg=np.zeros(N, np.uint16))
         self.__dict__.update(self.__dict__['_host'])
@@ -409,14 +407,6 @@ class VecNovelGridworld:
         _cabi.check(_cabi.lib().ngw_get_terminal_obs(self._h, _cabi._ptr(out['map'], np.int8), _cabi._ptr(out['agent_location'], np.int32),
                                                      _cabi._ptr(out['agent_facing_id'], np.int32), _cabi._ptr(out['inventory_items_quantity'], np.int32)))
         return out
-
-    def _rewards_fit_int16(self):
-        """The narrow wire format carries rewards as int16 (ngw_step_host_packed refuses a spec with a bigger one): such a spec keeps
-        the int32 one-block path of ngw_step_host."""
-        c = self.cspec
-        vals = [c.reward_step, c.reward_done, c.fire_reward, c.place_reward, c.ext_reward, c.chop_reward, c.axe_reward]
-        vals += list(c.break_reward[:self.n_items]) + list(c.recipe_reward[:c.n_recipes])
-        return all(-32768 <= int(x) <= 32767 for x in vals)
 
     def _one_block_path(self):
         """Does ngw_step_host take its one-block path (pack + one copy, delta refresh) for this env's full step()?  The rule of

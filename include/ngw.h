@@ -358,16 +358,16 @@ int ngw_unpack_obs(ngw_handle* h, const void* payloads_dev, int32_t world, int8_
 
 /* The host step in its NARROW WIRE FORMAT (big batches; what VecNovelGridworld.step() uses from a few thousand envs on).  One
  * page-locked block holds everything a step returns; ngw_host_step_layout_packed gives its section offsets (index: 0 map int8
- * [n][S*S], 1 inventory int32 [n][K], 2 pose uint32 [n] = r | c << 8 | facing << 16 | selected << 24, 3 reward int16 [n], 4 done
- * uint8 [n], 5 info uint32 [n] (NGW_INFO_*), 6 error flags uint32, 7 reward int32 [n] - host side only: widened from section 3 by the call itself once the device is
- * done, so that what a caller reads has the same type whatever the batch size; sections padded to 256 bytes, offsets9[8] = the block's size).
+ * [n][S*S], 1 inventory int32 [n][K], 2 pose uint32 [n] = r | c << 8 | facing << 16 | selected << 24, 3 reward int32 [n] (ABI 3: the
+ * type ngw_step_host returns whatever the batch size; int16 before), 4 done uint8 [n], 5 info uint32 [n] (NGW_INFO_*), 6 error flags
+ * uint32; sections padded to 256 bytes, offsets8[7] = the block's size).
  * ngw_step_host_packed(h, actions, block, with_map): int32 actions from host memory are validated and narrowed to bytes on the way
  * into a buffer the step kernel reads in place (no copy call); map and inventory are refreshed by deltas as in ngw_step_host (the block
- * is a mirror the caller hands in call after call; with_map = 0 skips the map's delta for this call); the dense sections 2-6 - 11 B per
- * env instead of the 26 B of the int32 arrays - are stored straight into the block by the narrowing kernel once the block is a mirror (mapped
- * into the GPU's address space; the first call on a block, and a block that cannot be mapped, bring them across with one copy).  Widening (pose bytes -> int32 arrays) is the caller's, when
- * he needs it.  Rewards travel as int16: a spec with a larger reward is refused (NGW_E_INVALID_ARG; use ngw_step_host). */
-int ngw_host_step_layout_packed(ngw_handle* h, uint64_t* offsets9);
+ * is a mirror the caller hands in call after call; with_map = 0 skips the map's delta for this call); the dense sections 2-6 - 13 B per
+ * env instead of the 26 B of the int32 arrays - are stored straight into the block by the device once the block is a mirror (mapped
+ * into the GPU's address space; the first call on a block, and a block that cannot be mapped, bring them across with one copy).
+ * Widening (pose bytes -> int32 arrays) is the caller's, when he needs it. */
+int ngw_host_step_layout_packed(ngw_handle* h, uint64_t* offsets8);
 int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block, int with_map);
 
 /* Terminal observations under same-step autoreset.  A step that ends an env's episode (done, or the horizon) returns the NEXT

@@ -559,6 +559,62 @@ def test_single_env_adapter_on_hip_backend(cfg):
     assert T.replay_adapter(cfg, 'hip', max_steps=250, n_single=150) > 300
 
 
+@pytest.mark.parametrize('cfg,timeout_us', [('pogo10', ''), ('axe10', '20'), ('bow20', '5'), ('fire10h', '2000'), ('add12m', '0')])
+def test_resident_step_loop_of_one_env_handles(cfg, timeout_us, monkeypatch):
+    """The one-env handle's resident step loop (csrc/ngw_solo.inc): every step's outcome is looked up in the records the device speculated
+    and the posted action committed behind the caller's back.  Held to the oracle step by step through what can go wrong around it: the
+    loop ending on its idle limit at any point of the exchange (limits of 0 - 20 us make it end between, during and right after steps;
+    the caller also pauses now and then), other calls on the handle in between (state reads and writes, resets, device-side launches),
+    episodes that end (`done` is sticky under the reference semantics), invalid actions."""
+    import time
+    import gym_novel_gridworlds_amd as G
+    from oracle.ngw_oracle import Oracle
+    if timeout_us:
+        monkeypatch.setenv('NGW_SOLO_TIMEOUT_US', timeout_us)
+    spec = T.build_spec(cfg)
+    A, S, K = len(spec.actions_id), spec.map_size, len(spec.items_id)
+    v = G.VecNovelGridworld(spec=spec, num_envs=1, seed=3)
+    o = Oracle(spec.compile(), 1, seed=3)
+    v.reset1(); o.reset()
+    rs = np.random.RandomState(11)
+
+    def same_state(where):
+        mb, r, c, f, ib, sel, steps = v.last_state1()
+        assert (np.frombuffer(mb, np.int8) == o.st.map[0]).all() and (r, c, f) == (o.st.loc[0][0], o.st.loc[0][1], o.st.facing[0]), where
+        assert (np.frombuffer(ib, np.int32) == o.st.inv[0]).all() and sel == o.st.selected[0] and steps == o.st.step_count[0], where
+
+    for t in range(1500):
+        a = int(rs.randint(0, A))
+        got = v.step1(a); o.step(np.array([a], np.int32))
+        exp = (int(o.reward[0]), bool(o.done[0]), bool(o.result[0]), int(o.cost_code[0]), int(o.msg_code[0]), int(o.msg_arg[0]))
+        assert got == exp, (t, a, got, exp)
+        same_state(t)
+        k = rs.randint(0, 60)
+        if k == 0:
+            time.sleep(0.002)                                           # well past any idle limit
+        elif k == 1:                                                    # a state read of the device's copy: the loop is stopped first
+            st = v.get_state()
+            assert (st['map'] == o.st.map).all() and (st['inv'] == o.st.inv).all() and (st['step_count'] == o.st.step_count).all(), t
+        elif k == 2:
+            v.reset1(); o.reset()
+        elif k == 3:                                                    # state injection between steps
+            inv = rs.randint(0, 9, (1, K)).astype(np.int32)
+            v.set_state(0, inv=inv); o.st.inv[:] = inv
+        elif k == 4:                                                    # a per-launch device-side step on the same handle
+            import torch
+            b = rs.randint(0, A, 1).astype(np.int32)
+            bd = torch.from_numpy(b).cuda()
+            torch.cuda.synchronize()
+            v.step_device(bd.data_ptr()); v.sync(); o.step(b)
+        elif k == 5:
+            with pytest.raises(ValueError, match='%d is not in list' % A):
+                v.step1(A)
+        if o.done[0] and k % 3 == 0:
+            v.reset1(); o.reset()
+    assert v.error_flags() == 0
+    v.close()
+
+
 def test_single_env_random_action_loop_shape():
     """tests/random_action.py:51-64 loop shape on the adapter: 50 steps, map_size change + reset every 10."""
     import gym_novel_gridworlds_amd as G
@@ -897,7 +953,7 @@ def test_host_step_delta_refresh_matches_oracle(cfg, n, horizon, slices, monkeyp
             v.refresh_host()                                            # ... and says so
         a = rs.randint(0, A, size=n).astype(np.int32)
         obs, reward, done, info = v.step(a); o.step(a)
-        assert reward.dtype == np.int32                                 # (whatever the batch size: the narrow wire format's int16 is widened)
+        assert reward.dtype == np.int32                                 # (whatever the batch size)
         assert (reward == o.reward).all() and (done == o.done.astype(bool)).all(), t
         assert (info['message_code'] == o.msg_code).all() and (info['message_arg'] == o.msg_arg).all(), t
         host_equals_oracle(obs, '%s step %d' % (cfg, t))
