@@ -383,6 +383,7 @@ int ngw_create(const ngw_spec* spec, int64_t n_envs, int device, uint64_t seed, 
     if (const char* v = getenv("NGW_FAST_RESET")) h->fast_reset = atoi(v);
     if (const char* v = getenv("NGW_ADAPT_PREFETCH")) h->adapt = atoi(v) != 0;
     if (const char* v = getenv("NGW_HOST_DELTA")) h->host_delta = atoi(v) != 0;
+    if (const char* v = getenv("NGW_HOST_WRITE_THROUGH")) h->wt_enabled = atoi(v) != 0;
     if (const char* v = getenv("NGW_ZC_BYTES")) { h->zc_bytes = (size_t)atoll(v); if (!h->zc_bytes) h->zc_bytes = 1; }
     if (const char* v = getenv("NGW_API_SLICES")) h->api_slices = atoi(v);
     if (const char* v = getenv("NGW_SOLO")) h->solo_enabled = atoi(v) != 0;

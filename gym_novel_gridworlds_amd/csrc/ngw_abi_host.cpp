@@ -49,6 +49,44 @@ void host_step_layout_packed(const ngw_handle* h, uint64_t off[8]) {
     off[7] = o;
 }
 
+// Actions: int32 ids from the caller's array, validated (the reference raises for a bad id before it touches any state: pogostick_v1_env.py:236)
+// and narrowed to one byte per env in ONE pass into the page-locked buffer the step kernel reads in place.  Returns nonzero when an id lies
+// outside [0, A).  AVX2 where the CPU has it (32 ids per round: 2.5 us per 65 536 against the 7 us of the compiler's own vectorisation).
+#if (defined(__x86_64__) || defined(__i386__)) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) uint32_t narrow_actions_avx2(const int32_t* a, uint8_t* o, size_t n, int A) {
+    const __m256i top = _mm256_set1_epi32(A - 1), idx = _mm256_setr_epi32(0, 4, 1, 5, 2, 6, 3, 7);
+    __m256i bad = _mm256_setzero_si256();                              // sign bits of a and of (A - 1 - a): set for a < 0 or a >= A
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        const __m256i x0 = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(a + i)), x1 = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(a + i + 8));
+        const __m256i x2 = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(a + i + 16)), x3 = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(a + i + 24));
+        bad = _mm256_or_si256(bad, _mm256_or_si256(_mm256_or_si256(x0, x1), _mm256_or_si256(x2, x3)));
+        bad = _mm256_or_si256(bad, _mm256_or_si256(_mm256_or_si256(_mm256_sub_epi32(top, x0), _mm256_sub_epi32(top, x1)),
+                                                   _mm256_or_si256(_mm256_sub_epi32(top, x2), _mm256_sub_epi32(top, x3))));
+        const __m256i p = _mm256_packus_epi16(_mm256_packs_epi32(x0, x1), _mm256_packs_epi32(x2, x3));   // (bytes of valid ids survive both saturations)
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(o + i), _mm256_permutevar8x32_epi32(p, idx));
+    }
+    uint32_t b = (uint32_t)_mm256_movemask_ps(_mm256_castsi256_ps(bad));
+    for (; i < n; i++) { const uint32_t v = (uint32_t)a[i]; b |= v >= (uint32_t)A ? 1u : 0u; o[i] = (uint8_t)v; }
+    return b;
+}
+#define NGW_HAVE_AVX2_NARROW 1
+#endif
+uint32_t narrow_actions(const int32_t* a, uint8_t* o, size_t n, int A) {
+#ifdef NGW_HAVE_AVX2_NARROW
+    static const bool avx2 = __builtin_cpu_supports("avx2") != 0;
+    if (avx2 && A >= 1) return narrow_actions_avx2(a, o, n, A);      // (A - 1 - a cannot wrap for a >= 0: A <= 64)
+#endif
+    uint32_t bad = 0;
+    for (size_t i = 0; i < n; i++) {                                  // (branch-free: vectorises)
+        const uint32_t v = (uint32_t)a[i];
+        bad |= v >= (uint32_t)A ? 1u : 0u;
+        o[i] = (uint8_t)v;
+    }
+    return bad;
+}
+
 /* Payload of the multi-GPU observation gather: the seven SoA arrays back to back, each section padded to 16 bytes. */
 struct PackSection { const void* dev; uint64_t bytes; };
 int pack_sections(const ngw_handle* h, PackSection sec[7], uint64_t offs[8]) {
@@ -216,7 +254,7 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
         uint64_t off[11];
         host_step_layout(h, off);
         if (!h->step_stage) { if (int rc = dev_alloc(h, &h->step_stage, (size_t)off[10])) return rc; }
-        const bool delta = h->host_delta && h->mirror_valid && h->mirror_block == map;
+        const bool delta = h->host_delta && h->mirror_valid && h->mirror_block == map && !h->shadow_stale;
         HIP_TRY(hipMemcpyAsync(h->actions_dev, actions_host, n * sizeof(int32_t), hipMemcpyDefault, h->stream));
         if (int rc = launch(h, NGW_MODE_STEP, 1, h->actions_dev, nullptr, 0, 0)) return rc;
         const void* const srcs[10] = {h->b.map, h->b.loc, h->b.facing, h->b.inv, h->b.reward, h->b.done, h->b.info, h->b.flags, h->b.selected, h->b.step_count};
@@ -252,6 +290,7 @@ int ngw_step_host(ngw_handle* h, const int32_t* actions_host, int8_t* map, int32
                     if (ok) HIP_TRY(hipMemcpyAsync(h->shadow[k], srcs[r], (size_t)nb[r], hipMemcpyDeviceToDevice, h->stream));
                 }
                 h->mirror_block = ok ? map : nullptr; h->mirror_dev = static_cast<uint8_t*>(dev);
+                h->shadow_stale = false;
             }
         }
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -351,15 +390,77 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
     uint64_t off[8];
     host_step_layout_packed(h, off);
     if (!h->wire_stage) { if (int rc = dev_alloc(h, &h->wire_stage, (size_t)(off[7] - off[2]))) return rc; }
-    const bool delta = h->host_delta && h->mirror_valid && h->mirror_block == block;
-    // Pipelined form (steady state of a big batch on the in-place step kernel): the batch steps in 2 - 4 slices on the handle's stream, and as
-    // soon as a slice's step kernel is done a second stream refreshes that slice's part of the caller's block across PCIe - while the next
-    // slice's actions are still being narrowed on the host and its step kernel runs.  The reference raises for a bad action id BEFORE it
-    // touches any state (pogostick_v1_env.py:236), so every id is checked first (read-only pass); narrowing then goes slice by slice.
     // the fused lidar observation's rows ride along when the caller registered a buffer for them (ngw_lidar_host_rows)
     const bool lrows = h->lidar_host_rows && h->lidar_fused && h->lidar_len;
     size_t lrb = 0;
     if (lrows) { NgwLaunch lq{}; lidar_format(h, lq); lrb = (size_t)lq.l_rb; }
+    const bool mirrored = h->host_delta && h->mirror_valid && h->mirror_block == block;
+    // Steady state on the in-place step kernel: ONE launch.  The block is a mirror of the state and mapped into the GPU's address space; the
+    // step kernel's write-through form (NgwWT, ngw_lean.inc) stores what the step changes straight into it - cells, inventory slots, whole rows of
+    // the envs that start an episode, pose / reward / done / info of every env - and its last block publishes the error flags and this call's
+    // sequence number behind section 6's flags word, which is polled here: no delta kernel, no stream synchronisation (a refill launch that
+    // follows the step on the stream runs while the caller already works on the results).  The delta kernel's shadows go stale meanwhile.
+    if (mirrored && h->wt_enabled && h->api_slices <= 1 && h->nostage && (!h->lidar_fused || h->boards_on) && !h->hostres && !h->capturing && !h->proto.stamps) {
+        const uint32_t bad = narrow_actions(actions_host, a8, n, A);
+        if (bad) {
+            h->act_next ^= 1;
+            for (size_t i = 0; i < n; i++)
+                if (actions_host[i] < 0 || actions_host[i] >= A) return fail(NGW_E_INVALID_ACTION, "%d is not in list", (int)actions_host[i]);   // pogostick_v1_env.py:236
+        }
+        uint8_t* const blk = static_cast<uint8_t*>(block);
+        if (h->wt_block != block) {
+            if (!h->wt_count) {
+                if (int rc = dev_alloc(h, &h->wt_count, 64)) return rc;
+                HIP_TRY(hipMemsetAsync(h->wt_count, 0, 64, h->stream));
+            }
+            uint8_t* const st = h->mirror_dev;
+            NgwWT w;
+            w.map = reinterpret_cast<int8_t*>(st + off[0]); w.inv = reinterpret_cast<int32_t*>(st + off[1]); w.pose = reinterpret_cast<uint32_t*>(st + off[2]);
+            w.reward = reinterpret_cast<int32_t*>(st + off[3]); w.done = st + off[4]; w.info = reinterpret_cast<uint32_t*>(st + off[5]);
+            w.flags = reinterpret_cast<uint32_t*>(st + off[6]); w.count = h->wt_count;
+            w.rows = nullptr;                                         // the observation rows go the same way when the buffer is mapped and whole blocks fit it
+            h->wt_rows = false;
+            if (lrows && h->n == h->n_pad) {
+                void* rd = nullptr;
+                if (hipHostGetDevicePointer(&rd, h->lidar_host_rows, 0) == hipSuccess && rd) { w.rows = static_cast<uint8_t*>(rd); h->wt_rows = true; }
+                else (void)hipGetLastError();
+            }
+            HIP_TRY(hipMemcpyAsync(&h->dspec->wt, &w, sizeof(w), hipMemcpyDefault, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));                 // (`w` is on this frame)
+            h->wt_block = block;
+        }
+        h->wt_seq = h->wt_seq + 1u ? h->wt_seq + 1u : 1u;
+        volatile uint32_t* const sw = reinterpret_cast<volatile uint32_t*>(blk + off[6]) + 1;
+        *sw = 0u;                                                       // (whatever the block held there)
+        h->launch_use_action0 = false; h->launch_act_u8 = true; h->launch_wire = true;
+        const int lrc = launch(h, NGW_MODE_STEP, 1, reinterpret_cast<const int32_t*>(h->act_pin_dev + (size_t)slot * cap), nullptr, 0, 0);
+        h->launch_act_u8 = false; h->launch_wire = false;
+        if (lrc) return lrc;
+        HIP_TRY(hipEventRecord(h->act_ev[slot], h->stream));
+        if (lrows && !h->wt_rows) {
+            HIP_TRY(hipMemcpyAsync(h->lidar_host_rows, h->lidar_out, n * lrb, hipMemcpyDefault, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        } else {
+            bool seen = false;
+            for (uint32_t spin = 0; spin < (1u << 22); spin++) {          // (bounded: ~100 ms, then the stream is synchronised the usual way)
+                if (*sw == h->wt_seq) { seen = true; break; }
+#if defined(__x86_64__) || defined(__i386__)
+                __builtin_ia32_pause();
+#else
+                __asm__ __volatile__("" ::: "memory");
+#endif
+            }
+            if (!seen) HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);                       // the block's reads stay behind the poll
+        h->mirror_valid = true; h->shadow_stale = true;
+        return NGW_OK;
+    }
+    const bool delta = mirrored && !h->shadow_stale;
+    // Pipelined form (steady state of a big batch on the in-place step kernel): the batch steps in 2 - 4 slices on the handle's stream, and as
+    // soon as a slice's step kernel is done a second stream refreshes that slice's part of the caller's block across PCIe - while the next
+    // slice's actions are still being narrowed on the host and its step kernel runs.  The reference raises for a bad action id BEFORE it
+    // touches any state (pogostick_v1_env.py:236), so every id is checked first (read-only pass); narrowing then goes slice by slice.
     int nsl = 1;
     if (delta && h->nostage && (!h->lidar_fused || h->boards_on) && !h->hostres && !h->capturing) {
         // MEASURED AND NOT THE DEFAULT (profiles/r05_ab.md): at 65 536 envs one slice 64.8 us per call, two 84.4, four 100.0 - every slice costs
@@ -380,7 +481,6 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
             HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
             for (hipEvent_t& e : h->slice_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
-        uint8_t* const blk = static_cast<uint8_t*>(block);
         const size_t per = (n / (size_t)nsl + 63) / 64 * 64;
         int s_i = 0;
         for (size_t first = 0; first < n; first += per, s_i++) {
@@ -413,12 +513,7 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
         h->mirror_valid = h->host_delta && h->mirror_block == block;
         return NGW_OK;
     }
-    uint32_t bad = 0;
-    for (size_t i = 0; i < n; i++) {                                  // (branch-free: vectorises)
-        const uint32_t a = (uint32_t)actions_host[i];
-        bad |= a >= (uint32_t)A ? 1u : 0u;
-        a8[i] = (uint8_t)a;
-    }
+    const uint32_t bad = narrow_actions(actions_host, a8, n, A);
     if (bad) {
         h->act_next ^= 1;
         for (size_t i = 0; i < n; i++)
@@ -455,6 +550,7 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
                 if (ok) HIP_TRY(hipMemcpyAsync(h->shadow[r], srcs[r], (size_t)nb[r], hipMemcpyDeviceToDevice, h->stream));
             }
             h->mirror_block = ok ? block : nullptr; h->mirror_dev = static_cast<uint8_t*>(dev);
+            h->shadow_stale = false;
         }
     }
     NgwWire w = {};

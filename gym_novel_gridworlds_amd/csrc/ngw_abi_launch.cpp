@@ -177,8 +177,8 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
     if (!taken && mode == NGW_MODE_STEP && h->nostage && (!h->lidar_fused || boards)) {   // maps read in place: no-stage step kernel
         NgwLaunch q = h->ns_proto;
         q.b = h->b; q.mode = mode; q.n_steps = 1; q.actions = actions_dev; q.autoreset = h->autoreset; q.horizon = h->horizon; q.stamps = h->proto.stamps;
-        q.seq = h->launch_seq; q.action0 = h->launch_action0; q.use_action0 = h->launch_use_action0 ? 1 : (h->launch_act_u8 ? 2 : 0);
-        HIP_TRY(ngw_launch(h->dspec, &q, h->map_mode, 8 | (h->ext ? 2 : 0) | (boards ? 1 : 0), grid, h->ns_lds, h->stream));
+        q.seq = h->launch_wire ? h->wt_seq : h->launch_seq; q.action0 = h->launch_action0; q.use_action0 = h->launch_use_action0 ? 1 : (h->launch_act_u8 ? 2 : 0);
+        HIP_TRY(ngw_launch(h->dspec, &q, h->map_mode, 8 | (h->ext ? 2 : 0) | (boards ? 1 : 0) | (h->launch_wire ? 16 : 0), grid, h->ns_lds, h->stream));
         taken = true;
     }
     if (!taken) {

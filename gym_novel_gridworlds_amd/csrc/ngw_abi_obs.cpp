@@ -142,6 +142,7 @@ int ngw_lidar_configure(ngw_handle* h, const ngw_lidar_cfg* cfg) {
     }
     h->lidar_len = L; h->lidar_world = world;
     h->lidar_host_rows = nullptr;
+    h->wt_block = nullptr;
     h->lidar_range = cfg->max_range; h->lidar_beams = cfg->num_beams; h->lidar_chan = cfg->n_chan; h->lidar_ninv = cfg->n_inv;
     if (h->lidar_fused) { if (int rc = layout_lds(h)) { h->lidar_fused = 0; layout_lds(h); boards_mode_update(h); upload_reset_u(h); return rc; } }
     const bool was = boards_mode_update(h);
@@ -160,6 +161,7 @@ int ngw_lidar_set_output(ngw_handle* h, int bits) {
     drop_graph(h);                                   // captured launches bake the format in
     h->lidar_bits = bits;
     h->lidar_host_rows = nullptr;                    // (the row size changed: the caller registers a buffer of the new size)
+    h->wt_block = nullptr;
     if (h->lidar_len) {
         if (h->lidar_fused) { if (int rc = layout_lds(h)) return rc; }
         const bool was = boards_mode_update(h);
@@ -191,6 +193,7 @@ int ngw_lidar_fuse(ngw_handle* h, int enable) {
     if (enable && !h->general_ok) return fail(NGW_E_INVALID_ARG, "map_size %d: the fused lidar epilogue keeps a wavefront's 64 maps in LDS (> 160 KiB)", h->proto.S);
     const int before = h->lidar_fused;
     h->lidar_fused = enable ? 1 : 0;
+    h->wt_block = nullptr;
     if (int rc = layout_lds(h)) { h->lidar_fused = before; layout_lds(h); upload_reset_u(h); return rc; }
     const bool was = boards_mode_update(h);
     if (int rc = upload_reset_u(h)) return rc;
@@ -226,6 +229,7 @@ int ngw_lidar_host_rows(ngw_handle* h, void* rows_host) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->lidar_host_rows = static_cast<uint8_t*>(rows_host);
+    h->wt_block = nullptr;                           // (the step kernel's write-through targets are set up again)
     return NGW_OK;
 }
 

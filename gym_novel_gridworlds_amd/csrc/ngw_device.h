@@ -189,6 +189,23 @@ struct NgwTerm {
     int32_t* inv;         /* [n_pad][K]   */
 };
 
+/* Host write-through of the step kernel (ngw_step_host_packed's steady state on the in-place kernel): the caller's page-locked block is a
+ * mirror of the state and is mapped into the GPU's address space - the step kernel itself stores what the step changes into it across
+ * PCIe (the map cells and inventory slots it writes, whole rows of the envs that start a new episode, pose / reward / done / info of every
+ * env), counts its finished blocks and the last one publishes the error flags and the launch's sequence number, which the host polls:
+ * one launch per host step, no delta kernel behind it, no stream synchronisation.  All null = off. */
+struct NgwWT {
+    int8_t* map;          /* [n][S*S]  section 0 of the block (device address of the mapped host memory) */
+    int32_t* inv;         /* [n][K]    section 1 */
+    uint32_t* pose;       /* [n]       section 2: r | c << 8 | facing << 16 | selected << 24 */
+    int32_t* reward;      /* [n]       section 3 */
+    uint8_t* done;        /* [n]       section 4 */
+    uint32_t* info;       /* [n]       section 5 */
+    uint32_t* flags;      /* section 6: [0] error flags, [1] sequence number of the last finished step */
+    uint32_t* count;      /* device memory: blocks of the current launch that have finished */
+    uint8_t* rows;        /* fused LidarInFront observation: the caller's row buffer ([n_pad] rows, ngw_lidar_host_rows), or null */
+};
+
 struct NgwDevSpec {
     NgwStepU u;
     uint8_t place_seq[NGW_MAX_PLACE];   /* item id of the n-th placement of a reset (items_quantity flattened in order): the reset paths copy it to LDS */
@@ -202,6 +219,7 @@ struct NgwDevSpec {
     NgwResetU ru;
     NgwMirror mir;
     NgwTerm term;
+    NgwWT wt;
     double pctq[NGW_MAX_PASSES][64];   /* per reset pass: pct / 100.0 for pct in [pct_lo, pct_hi) as the host's IEEE double */
 };
 

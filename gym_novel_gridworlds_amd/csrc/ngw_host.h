@@ -62,6 +62,12 @@ struct ngw_handle {
     const void* mirror_block = nullptr;
     uint8_t* mirror_dev = nullptr;
     bool mirror_valid = false;
+    int wt_enabled = 1;                   // NGW_HOST_WRITE_THROUGH=0: the delta kernel behind every step instead of the step kernel's own stores into the block (A/B)
+    bool shadow_stale = false;            // write-through steps ran since the shadows were seeded: the delta kernel needs them seeded again
+    void* wt_block = nullptr;             // the block NgwDevSpec::wt points into
+    uint32_t* wt_count = nullptr;         // device counter of finished blocks
+    uint32_t wt_seq = 0;
+    bool wt_rows = false;                 // NgwDevSpec::wt also points at the caller's lidar row buffer
     int host_delta = 1;                   // NGW_HOST_DELTA=0: every ngw_step_host copies the whole observation (A/B)
     size_t zc_bytes = (size_t)256 << 10;  // NGW_ZC_BYTES: largest ngw_step_host result written straight into mapped host memory (read at ngw_create)
     std::vector<void*> allocs;
@@ -71,6 +77,7 @@ struct ngw_handle {
     hipEvent_t mask_ev[2] = {nullptr, nullptr};
     int mask_next = 0;
     uint8_t* act_pin_dev = nullptr;            // ... the same buffer as the GPU addresses it (ngw_step_host_packed: the kernel reads the actions in place)
+    bool launch_wire = false;                  // the launch being issued is the host write-through form (feat 16), its sequence number wt_seq
     bool launch_act_u8 = false;                // the launch being issued reads one byte per env from `actions`
     uint8_t* wire_stage = nullptr;             // ngw_step_host_packed: device staging of the dense sections
     uint8_t* act_pin = nullptr;                // ngw_step's actions: two page-locked halves feeding the asynchronous copy

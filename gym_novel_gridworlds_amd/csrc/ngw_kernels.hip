@@ -27,7 +27,7 @@
 #include "../../include/ngw.h"
 #include "ngw_device.h"
 
-// The library is built from this file EIGHT times, in parallel (Makefile): -DNGW_PART=n keeps the launchers - and with them the
+// The library is built from this file ELEVEN times, in parallel (Makefile): -DNGW_PART=n keeps the launchers - and with them the
 // kernel instantiations - of one part; without NGW_PART (make asm) everything is in one unit.
 //   0: ngw_launch + the general kernel   1 / 6 / 7: step kernels per map addressing mode (1 also holds the in-place ones)
 //   2 / 3 / 4: rollout kernels per map addressing mode   5: new-episode (reset_fast), lidar, diff / wire / pack / agent-view kernels
@@ -1436,7 +1436,7 @@ extern "C" hipError_t ngw_reset_fast_launch(const NgwDevSpec* dspec, const NgwRe
 }
 #endif  // NGW_HAS(5)
 
-// feat: 1 = fused LidarInFront epilogue, 2 = wrapper predicates (EXT), 8 = no-stage step (maps read in place)
+// feat: 1 = fused LidarInFront epilogue, 2 = wrapper predicates (EXT), 8 = no-stage step (maps read in place), 16 = host write-through (with 8)
 extern "C" hipError_t ngw_part_step(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int feat, unsigned grid, size_t lds_bytes,
                                     hipStream_t stream);
 extern "C" hipError_t ngw_part_rollout_straight(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
@@ -1456,6 +1456,28 @@ extern "C" hipError_t ngw_part_step_straight(const NgwDevSpec* dspec, const NgwL
 extern "C" hipError_t ngw_part_step_dword(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
 extern "C" hipError_t ngw_part_step_byte(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
 extern "C" hipError_t ngw_part_step_boards(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t ngw_part_step_wire(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t ngw_part_step_wire_boards(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream);
+#if NGW_HAS(9)
+// in-place step with the host write-through (NgwWT: ngw_step_host_packed's steady state)
+extern "C" hipError_t ngw_part_step_wire(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream) {
+    if (feat & 1) return ngw_part_step_wire_boards(dspec, a, feat, grid, lds_bytes, stream);
+    return (feat & 2) ? launch_lean<NGW_MAP_STRAIGHT, false, true, false, 0, true>(dspec, a, grid, lds_bytes, stream)
+                      : launch_lean<NGW_MAP_STRAIGHT, false, false, false, 0, true>(dspec, a, grid, lds_bytes, stream);
+}
+#endif  // NGW_HAS(9)
+#if NGW_HAS(10)
+extern "C" hipError_t ngw_part_step_wire_boards(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream) {
+    const bool ext = (feat & 2) != 0;
+    if (!a->l_boards || a->BS < 4 || a->BS > 32) return hipErrorInvalidValue;
+    if (a->BS <= 12) return ext ? launch_lean<NGW_MAP_STRAIGHT, false, true, true, 12, true>(dspec, a, grid, lds_bytes, stream)
+                                : launch_lean<NGW_MAP_STRAIGHT, false, false, true, 12, true>(dspec, a, grid, lds_bytes, stream);
+    if (a->BS <= 20) return ext ? launch_lean<NGW_MAP_STRAIGHT, false, true, true, 20, true>(dspec, a, grid, lds_bytes, stream)
+                                : launch_lean<NGW_MAP_STRAIGHT, false, false, true, 20, true>(dspec, a, grid, lds_bytes, stream);
+    return ext ? launch_lean<NGW_MAP_STRAIGHT, false, true, true, 32, true>(dspec, a, grid, lds_bytes, stream)
+               : launch_lean<NGW_MAP_STRAIGHT, false, false, true, 32, true>(dspec, a, grid, lds_bytes, stream);
+}
+#endif  // NGW_HAS(10)
 #if NGW_HAS(8)
 // in-place step + the LidarInFront observation from the occupancy bit rows (ngw_boards.inc): NR = 12 / 20 / 32 register rows
 extern "C" hipError_t ngw_part_step_boards(const NgwDevSpec* dspec, const NgwLaunch* a, int feat, unsigned grid, size_t lds_bytes, hipStream_t stream) {
@@ -1491,6 +1513,7 @@ NGW_STEP_PART(ngw_part_step_straight, NGW_MAP_STRAIGHT)
 extern "C" hipError_t ngw_part_step(const NgwDevSpec* dspec, const NgwLaunch* a, int map_mode, int feat, unsigned grid, size_t lds_bytes,
                                     hipStream_t stream) {
     if (feat & 8) {                                                     // no-stage: with the lidar observation, the one on the occupancy bit rows
+        if (feat & 16) return ngw_part_step_wire(dspec, a, feat, grid, lds_bytes, stream);   // ... with the host write-through
         if (feat & 1) return ngw_part_step_boards(dspec, a, feat, grid, lds_bytes, stream);
         return (feat & 2) ? launch_lean<NGW_MAP_STRAIGHT, false, true, false>(dspec, a, grid, lds_bytes, stream)
                           : launch_lean<NGW_MAP_STRAIGHT, false, false, false>(dspec, a, grid, lds_bytes, stream);

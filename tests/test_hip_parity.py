@@ -907,20 +907,31 @@ def test_big_batch_host_step_uses_one_block_and_matches_oracle():
 
 
 @pytest.mark.parametrize('cfg,n,horizon,slices', [('pogo10', 40000, 9, ''), ('axe10', 20000, 40, ''), ('add32', 4096, 15, '4'), ('pogo13', 30000, 11, '3'), ('crate10m', 20000, 25, '1'),
-                                                  ('fire10h', 9000, 30, '2'), ('bow20', 70000, 13, '4')])
+                                                  ('fire10h', 9000, 30, '2'), ('bow20', 70000, 13, '4'), ('pogo13', 30000, 11, ''), ('add32', 4100, 15, ''), ('crate10m', 20000, 25, ''),
+                                                  ('fire10h', 9000, 30, ''), ('bow20', 70000, 13, ''), ('fencer12h', 8000, 12, ''), ('pogo10', 40000, 9, 'delta'), ('add32', 4096, 15, 'delta'),
+                                                  ('axe10', 20001, 14, 'inline'), ('add29h', 5000, 10, 'inline'), ('axe10', 20000, 21, 'terminal')])
 def test_host_step_delta_refresh_matches_oracle(cfg, n, horizon, slices, monkeypatch):
     """ngw_step_host on a big batch moves only what changed (include/ngw.h ngw_host_step_layout): the host observation equals
     the oracle's after EVERY step - through in-step resets, entity pick-ups and crates, odd row sizes - and after everything
     that invalidates the mirror in between (explicit resets, device steps, a fused rollout, state injection, refresh_host).
-    `slices`: the pipelined form of the packed host step (the batch steps in slices while a second stream brings finished slices across
-    PCIe) - '' = the library's default (one slice: the pipelined form measured slower), a number selects it (a slice is a multiple of 64 envs,
-    so batch sizes that are no multiple of 64 x slices end in a short last slice)."""
+    `slices`: '' = the library's default, the step kernel's HOST WRITE-THROUGH form (one launch: the kernel stores what the step changes
+    into the caller's block itself and its last block publishes a sequence number the call polls); 'delta' = NGW_HOST_WRITE_THROUGH=0, the delta
+    kernel behind every step; a number = the pipelined form of that (the batch steps in slices while a second stream brings finished slices
+    across PCIe; a slice is a multiple of 64 envs, so batch sizes that are no multiple of 64 x slices end in a short last slice); 'inline' =
+    write-through without prepared episodes (the cold tail places the new episode inline); 'terminal' = with terminal-observation capture."""
     import torch
-    if slices:
+    kw = {}
+    if slices == 'delta':
+        monkeypatch.setenv('NGW_HOST_WRITE_THROUGH', '0')
+    elif slices == 'inline':
+        kw['reset_prefetch'] = 0
+    elif slices == 'terminal':
+        kw['terminal_capture'] = True
+    elif slices:
         monkeypatch.setenv('NGW_API_SLICES', slices)
     spec = T.build_spec(cfg)
     A = len(spec.actions_id)
-    v = VecNovelGridworld(spec=spec, num_envs=n, seed=16, autoreset=True, horizon=horizon)
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=16, autoreset=True, horizon=horizon, **kw)
     o = Oracle(spec.compile(), n, seed=16, autoreset=True, horizon=horizon)
     v.reset(); o.reset()
     stag = (np.arange(n) * 7919 % horizon).astype(np.int32)
