@@ -436,7 +436,7 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
         const int lrc = launch(h, NGW_MODE_STEP, 1, reinterpret_cast<const int32_t*>(h->act_pin_dev + (size_t)slot * cap), nullptr, 0, 0);
         h->launch_act_u8 = false; h->launch_wire = false;
         if (lrc) return lrc;
-        HIP_TRY(hipEventRecord(h->act_ev[slot], h->stream));
+        // (no event for the action buffer's slot: this call returns only after the kernel has published its sequence number)
         if (lrows && !h->wt_rows) {
             HIP_TRY(hipMemcpyAsync(h->lidar_host_rows, h->lidar_out, n * lrb, hipMemcpyDefault, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
