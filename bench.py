@@ -453,12 +453,12 @@ def main():
             _cabi.check(fl(v._h, int(kfl), 1, C.byref(us_g)))            # replayed from a graph: the device-side boundary between dependent launches
             _cabi.check(fl(v._h, int(kfl), 0, C.byref(us_e)))            # issued eagerly: what the HOST can sustain (a region below 100 steps is launched this way)
             wl = pmc.get('%s_wave_life' % args.workload, pmc.get('C2_wave_life', {}))
-            life_us = wl.get('median_us')
+            life_us = wl.get('median_us_net_of_stamps', wl.get('median_us'))   # (net of what the eight clock stamps themselves cost a wave)
             # the device needs the boundary + a wave's life per launch; an eager loop cannot go faster than the host issues launches
             floor_us = max(us_g.value + (life_us or 0.0), 0.0 if use_graph else us_e.value)
             roofline['floor'] = {'empty_kernel_launch_period_us': {'hipGraph replay': round(us_g.value, 4), 'eager': round(us_e.value, 4)},
                                  'launch_form_of_this_region': 'hipGraph replay' if use_graph else 'eager',
-                                 'launches': int(kfl), 'stamped_wave_life_us': life_us, 'wave_life_source': wl.get('source'),
+                                 'launches': int(kfl), 'stamped_wave_life_us': life_us, 'stamped_wave_life_us_with_stamp_cost': wl.get('median_us'), 'wave_life_source': wl.get('source'),
                                  'floor_us': round(floor_us, 4),
                                  'what': 'floor = max(empty-kernel launch period replayed from a graph + the median life of a wave of the step kernel (in-kernel clock '
                                          'stamps, profiles/), and - for an eagerly launched region - the empty-kernel launch period of the host loop): EMPTY kernels '

@@ -243,39 +243,44 @@ open(os.path.join(DST, ROUND + '_pmc.md'), 'w').write('\n'.join(pm) + '\n')
 # ---------------------------------------------------------------- the fused LidarInFront step
 ld = ['# The step with the fused LidarInFront observation (%s)\n' % ROUND,
       'Reference: `gym_novel_gridworlds/observation_wrappers.py:10-80` - the observation every reference training / evaluation script wraps the env in.  '
-      'Kernel `ngw_step_lean<0, true, false, true>`: the batched step of C2 (Pogostick-v1 10x10, 65 536 envs) with the observation rows (8 beams x 7 lidar '
-      'items + 7 inventory entries = 63 values per env) built in the same launch.  Commands: `python3 bench.py --no-cpu-baseline --no-side --lidar <format> ...` '
-      '(`tools/profile_round.sh`, section 5); the default bench line reports the same three formats untraced under `lidar`.\n']
-ld.append('## Kernel trace per row format (400 timed steps, hipGraph replay)\n')
-ld.append('| rows | bytes per env | bench line while traced: us per batched step | `ngw_step_lean<..., true>` launches | average ns (kernel_stats.csv) | median us (kernel trace) |')
-ld.append('|---|---|---|---|---|---|')
-for F in ('int32', 'int16', 'packed'):
-    f = first('stats_lidar_%s/**/*kernel_stats.csv' % F)
-    ln = bench_line('stats_lidar_%s.log' % F)
+      'Kernel `ngw_step_lean<0, false, EXT, true, NR>` (round 5): the IN-PLACE step kernel with the observation built from the occupancy bit rows '
+      '(`csrc/ngw_boards.inc`: the first hit of each of the 8 rays is a count-leading / trailing-zeros on the agent\'s row, column and two diagonals; NR = 12 / 20 / 32 '
+      'register rows for maps up to 12 / 20 / 32 cells), the rows (8 beams x 7 lidar items + the inventory tail) written in the same launch.  Commands: '
+      '`python3 bench.py --no-cpu-baseline --no-side [--workload W] --lidar <format> ...` (`tools/profile_round.sh`, section 5); the default bench line reports the three '
+      'formats at C2 untraced under `lidar`.\n']
+ld.append('## Kernel trace per workload and row format (400 timed steps, hipGraph replay)\n')
+ld.append('| workload | rows | bytes per env | bench line while traced: us per batched step | `ngw_step_lean<..., true, NR>` launches | average ns (kernel_stats.csv) | median us (kernel trace) |')
+ld.append('|---|---|---|---|---|---|---|')
+for W, F in (('C2', 'int32'), ('C2', 'int16'), ('C2', 'packed'), ('C3', 'packed'), ('C5', 'packed')):
+    tag = F if W == 'C2' else '%s_%s' % (W, F)
+    f = first('stats_lidar_%s/**/*kernel_stats.csv' % tag)
+    ln = bench_line('stats_lidar_%s.log' % tag)
     if not f or not ln:
         continue
     row = [r for r in csv.DictReader(open(f)) if 'step_lean' in r['Name']]
-    tr = first('stats_lidar_%s/**/*kernel_trace.csv' % F)
+    tr = first('stats_lidar_%s/**/*kernel_trace.csv' % tag)
     dur = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in csv.DictReader(open(tr)) if 'step_lean' in r['Kernel_Name']]
     if row:
-        ld.append('| %s | %d | %.2f | %s | %.1f | %.2f |' % (F, ln['config']['fused_lidar']['row_bytes'], ln['ms_per_step'] * 1e3, row[0]['Calls'], float(row[0]['AverageNs']),
-                                                       st.median(dur) if dur else float('nan')))
+        ld.append('| %s | %s | %d | %.2f | %s | %.1f | %.2f |' % (W, F, ln['config']['fused_lidar']['row_bytes'], ln['ms_per_step'] * 1e3, row[0]['Calls'], float(row[0]['AverageNs']),
+                                                            st.median(dur) if dur else float('nan')))
 ld.append('\n(As for the plain step kernel, a traced dispatch shows its whole un-overlapped launch; the untraced figures are the bench line\'s `lidar` key and `tools/lidar_rate.py`.)\n')
 ld.append('## HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes)\n')
-ld.append('| rows | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes per launch (corrected) | per env-step | of which observation rows |')
-ld.append('|---|---|---|---|---|---|')
-for F in ('int16', 'packed'):
-    f_by, w_by = counters('pmc_lidar_%s_FETCH_SIZE' % F), counters('pmc_lidar_%s_WRITE_SIZE' % F)
-    ln = bench_line('pmc_lidar_%s_FETCH_SIZE.log' % F)
+ld.append('| workload | rows | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes per launch (corrected) | per env-step | of which observation rows |')
+ld.append('|---|---|---|---|---|---|---|')
+for W, F in (('C2', 'int16'), ('C2', 'packed'), ('C3', 'packed'), ('C5', 'packed')):
+    tag = F if W == 'C2' else '%s_%s' % (W, F)
+    f_by, w_by = counters('pmc_lidar_%s_FETCH_SIZE' % tag), counters('pmc_lidar_%s_WRITE_SIZE' % tag)
+    ln = bench_line('pmc_lidar_%s_FETCH_SIZE.log' % tag)
     for (k, cn), v in f_by.items():
         if 'step_lean' not in k:
             continue
         fv, wv = st.median(v), st.median(w_by.get((k, 'WRITE_SIZE'), [0]))
         total = fv * 1024 * ff + wv * 1024 * wf
         rb = ln['config']['fused_lidar']['row_bytes'] if ln else 0
-        ld.append('| %s | %.1f | %.1f | %.0f | %.1f | %d |' % (F, fv, wv, total, total / 65536, rb))
-        traffic['C2_lidar_%s_step' % F] = {'hbm_bytes_per_launch': round(total), 'env_steps_per_launch': 65536, 'hbm_bytes_per_env_step': round(total / 65536, 1),
-                                           'source': 'profiles/%s_lidar.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)' % ROUND}
+        envs = ln['config']['envs_per_gpu'] if ln else 65536
+        ld.append('| %s | %s | %.1f | %.1f | %.0f | %.1f | %d |' % (W, F, fv, wv, total, total / envs, rb))
+        traffic['%s_lidar_%s_step' % (W, F)] = {'hbm_bytes_per_launch': round(total), 'env_steps_per_launch': envs, 'hbm_bytes_per_env_step': round(total / envs, 1),
+                                                'source': 'profiles/%s_lidar.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)' % ROUND}
 ld.append('\n## SQ counters (int16 rows)\n')
 vals = {}
 for d in ('sq_lidar_1', 'sq_lidar_2', 'sq_lidar_3'):
@@ -298,12 +303,13 @@ for F in ('int16', 'packed', 'int32'):                    # the stamped timeline
         ld.append('```')
         ld += [x.rstrip() for x in open(lg) if 'amdgpu.ids' not in x]
         ld.append('```\n')
-lr = os.path.join(ROOT, 'gpurun_out', ROUND, 'lidar_rate.log')
-if os.path.exists(lr):
-    ld.append('## Untraced rates (`tools/lidar_rate.py`: 64-step hipGraph replayed 16 times, default prepared-episode cadence)\n')
-    ld.append('```')
-    ld += [x.rstrip() for x in open(lr) if 'amdgpu.ids' not in x]
-    ld.append('```\n')
+for W in ('', '_C2', '_C3', '_C5'):
+    lr = os.path.join(ROOT, 'gpurun_out', ROUND, 'lidar_rate%s.log' % W)
+    if os.path.exists(lr):
+        ld.append('## Untraced rates%s (`tools/lidar_rate.py`: 64-step hipGraph replayed 16 times, default prepared-episode cadence)\n' % (W and ', ' + W[1:]))
+        ld.append('```')
+        ld += [x.rstrip() for x in open(lr) if 'amdgpu.ids' not in x]
+        ld.append('```\n')
 open(os.path.join(DST, ROUND + '_lidar.md'), 'w').write('\n'.join(ld) + '\n')
 
 
@@ -318,7 +324,23 @@ def _read(name):
 # empty-kernel launch period it measures itself
 wl_file = os.path.join(SRC, 'wave_life.json')
 if os.path.exists(wl_file):
+    lg0 = os.path.join(SRC, 'stamps_step.log')
+    gaps = {}                                             # (logs of a run whose JSON has no stamp cost yet: the per-stamp cost from the printed medians)
+    if os.path.exists(lg0):
+        cur = None
+        for line in open(lg0):
+            if line.startswith('== '):
+                cur = line[3:].split(':')[0].split(' ')[0]
+            elif '->' in line and cur and 'lidar' not in line:
+                try:
+                    gaps.setdefault(cur, []).append(float(line.split()[-2]))
+                except ValueError:
+                    pass
     for wl_name, rec in json.load(open(wl_file)).items():
+        if 'median_us_net_of_stamps' not in rec and gaps.get(wl_name):
+            g = gaps[wl_name][:7]
+            rec['stamp_cost_cycles'], rec['stamps_after_first'] = min(g), len(g)
+            rec['median_us_net_of_stamps'] = round((rec['median_cycles'] - len(g) * min(g)) / (rec['clock_ghz'] * 1e3), 3)
         rec['source'] = 'profiles/%s_kernel_stats.md (tools/stamp_timeline.py on the -DNGW_STAMPS build: s_memtime per wave, median over %d waves)' % (ROUND, rec.get('waves', 0))
         traffic['%s_wave_life' % wl_name] = rec
     ks_path = os.path.join(DST, ROUND + '_kernel_stats.md')

@@ -38,13 +38,20 @@ for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_reset_${W}_$c -- python3 tools/reset_pmc.py $W > $OUT/pmc_reset_${W}_$c.log 2>&1 || echo "pmc reset $W $c failed"
   done
 done
-# 5. the step with the FUSED LidarInFront observation (ngw_step_lean<., true, ., true>): kernel trace per row format, HBM traffic and SQ counters (int16 rows)
+# 5. the step with the FUSED LidarInFront observation (in-place step kernel + occupancy bit rows: ngw_step_lean<0, false, ., true, NR>): kernel trace per row format at C2 and
+#    with packed rows at C3 / C5, HBM traffic and SQ counters (int16 rows)
 for F in int32 int16 packed; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lidar_$F -- $B --lidar $F > $OUT/stats_lidar_$F.log 2>&1 || echo "stats lidar $F failed"
+done
+for W in C3 C5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lidar_${W}_packed -- $B --workload $W --lidar packed > $OUT/stats_lidar_${W}_packed.log 2>&1 || echo "stats lidar $W failed"
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   for F in int16 packed; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_lidar_${F}_$c -- $P --lidar $F > $OUT/pmc_lidar_${F}_$c.log 2>&1 || echo "pmc lidar $F $c failed"
+  done
+  for W in C3 C5; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_lidar_${W}_packed_$c -- $P --workload $W --lidar packed > $OUT/pmc_lidar_${W}_packed_$c.log 2>&1 || echo "pmc lidar $W $c failed"
   done
 done
 i=0
@@ -54,7 +61,12 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_
 done
 # 6. in-kernel clock stamps of the step kernel (diagnostics build): the median wave life that bench.py's roofline.floor adds to the empty-kernel launch period
 NGW_STAMP_JSON=$OUT/wave_life.json NGW_LIB=$PWD/gym_novel_gridworlds_amd/libngw_hip_stamps.so python3 tools/stamp_timeline.py C2 C3 C4 C5 > $OUT/stamps_step.log 2>&1 || echo "stamps failed"
-git rev-parse --short HEAD > $OUT/commit.txt 2>/dev/null || echo unknown > $OUT/commit.txt
+# 7. untraced rates of the fused lidar step, per workload
+mkdir -p gpurun_out/$ROUND
+for W in C2 C3 C5; do
+  NGW_LIDAR_SWEEP=0 python3 tools/lidar_rate.py 65536 $W > gpurun_out/$ROUND/lidar_rate_$W.log 2>&1 || echo "lidar_rate $W failed"
+done
+(git rev-parse --short HEAD 2>/dev/null || cat COMMIT 2>/dev/null || echo unknown) > $OUT/commit.txt
 date -u +%Y-%m-%dT%H:%MZ > $OUT/date.txt
 find $OUT -name "*.db" -delete 2>/dev/null
 du -sh $OUT

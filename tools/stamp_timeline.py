@@ -90,11 +90,16 @@ def main():
                 print('    %-20s -> %-22s %8.0f %8.0f' % (sn[a_], sn[b_], np.median(d), np.percentile(d, 90)))
         life = cy[:, last] - cy[:, 0]
         ghz = float(np.median(life / np.maximum((rt[:, last] - rt[:, 0]) * 10.0, 1.0)))
-        print('  wave life %.0f cycles median; clock ~%.2f GHz' % (np.median(life), ghz))
+        # what a stamp itself costs (two clock reads + the wait for them): the shortest median distance between two adjacent stamps - two of
+        # them sit back to back with nothing in between - times the stamps a wave passes after its first
+        stamp_cost = float(min(np.median(cy[:, i] - cy[:, i - 1]) for i in range(1, last + 1)))
+        net = float(np.median(life)) - last * stamp_cost
+        print('  wave life %.0f cycles median (%.0f net of the %d stamps behind the first, %.0f cycles each); clock ~%.2f GHz' % (np.median(life), net, last, stamp_cost, ghz))
         if os.environ.get('NGW_STAMP_JSON'):              # bench.py's roofline.floor reads the median wave life from profiles/pmc_traffic.json (tools/parse_round.py merges this file)
             import json
             life_us = (rt[:, last] - rt[:, 0]) * 0.01       # the chip-wide 100 MHz clock: 10 ns resolution per wave, the median over 1 024 waves is what counts
             rec = {'median_cycles': float(np.median(life)), 'clock_ghz': round(ghz, 3), 'median_us': round(float(np.median(life)) / (ghz * 1e3), 3),
+                   'stamp_cost_cycles': stamp_cost, 'stamps_after_first': int(last), 'median_us_net_of_stamps': round(net / (ghz * 1e3), 3),
                    'median_us_realtime_clock': round(float(np.median(life_us)), 3), 'last_wave_done_us': round(float((rt[:, last].max() - t0) * 0.01), 3),
                    'event_us_per_launch': round(ms / 40 * 1e3, 3), 'waves': int(grid)}
             path = os.environ['NGW_STAMP_JSON']
