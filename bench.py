@@ -281,6 +281,9 @@ def main():
     # 110 us eager), so regions shorter than 100 launches are issued eagerly, from one C-ABI call (tools/short_run.py).
     # (Tried: event-record nodes inside the graph to time a replay without its launch latency - two such nodes cost ~80 us per
     #  replay on this runtime, more than they explain.)
+    # (Round 5 re-measured: short graphs are now captured without a closing refill - ngw_graph_build's "open" graphs - and a 20-step replay after
+    #  the first costs 87-88 us against 92-99 us eager, but the first replay, which is the contract region, costs 121 us: driver-form lines
+    #  14.2 / 14.7 G with the graph against 14.2 G eager, contract region 12.6-12.8 G against 14 G.  The threshold stays.)
     use_graph = args.mode == 'step' and args.launch == 'graph' and steps >= 100
     ptrs = []
     if args.mode == 'step' or not args.no_side:

@@ -380,6 +380,7 @@ void drop_graph(ngw_handle* h) {
     h->graph_exec = nullptr;
     h->graph = nullptr;
     h->graph_steps = 0;
+    h->graph_open = false;
 }
 
 }  // namespace ngwh
@@ -470,6 +471,11 @@ int capture_graph(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride
         if (int rc = rebuild_boards(h, h->b.map, h->b.brd, h->n_pad)) return rc;
         h->brd_dirty = false;
     }
+    // A graph much shorter than the refill cadence is captured WITHOUT a refill: closing every replay of a 20-step graph with one (below) would
+    // run the ~21 us launch four times as often as the cadence asks for.  Such a graph is "open": ngw_graph_launch counts its steps and issues
+    // the refill between replays, eagerly, whenever the next replay would overrun the cadence.
+    const bool open = h->prefetch_every > 0 && n_steps * 2 <= h->cadence;
+    const int since0 = h->since_refill;
     h->since_refill = 0;                              // the captured refill cadence starts from a known phase
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     h->capturing = true;                              // (the depth and cadence the handle has adapted to so far are the ones captured)
@@ -477,10 +483,11 @@ int capture_graph(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride
     for (int i = 0; i < n_steps && !rc; i++) rc = launch(h, NGW_MODE_STEP, 1, actions_dev + (int64_t)i * step_stride, nullptr, 0, 0);
     // every replay must leave the refill cadence where it found it: a graph shorter than (or not a multiple of) the cadence
     // ends with one more refill, otherwise a replayed graph would never re-prepare the episodes its steps consume
-    if (!rc && h->prefetch_every > 0 && h->since_refill > 0) {
+    if (!rc && h->prefetch_every > 0 && h->since_refill > 0 && !open) {
         h->since_refill = h->prefetch_every;
         rc = launch_refill(h);
     }
+    if (open) h->since_refill = since0;               // (nothing ran: the steps since the last refill are what they were)
     h->capturing = false;
     hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
     if (rc) { drop_graph(h); return rc; }
@@ -490,6 +497,7 @@ int capture_graph(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride
     (void)hipGraphUpload(h->graph_exec, h->stream);   // pre-stage the graph so the first replay does not pay for it
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->graph_steps = n_steps; h->graph_actions = actions_dev; h->graph_stride = step_stride;
+    h->graph_open = open;
     h->adapted = false;
     return NGW_OK;
 }
@@ -774,6 +782,7 @@ int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stri
     if (!h || !actions_dev) return fail(NGW_E_INVALID_ARG, "NULL argument");
     if (n_steps < 1) return fail(NGW_E_INVALID_ARG, "n_steps must be >= 1");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->solo_running) { if (int rc = solo_stop(h)) return rc; }    // (a one-env handle's resident loop: its stream is busy until it ends)
     return capture_graph(h, actions_dev, step_stride, n_steps);
 }
 
@@ -781,6 +790,8 @@ int ngw_graph_launch(ngw_handle* h, int32_t reps) {
     if (!h) return fail(NGW_E_INVALID_ARG, "handle is NULL");
     if (!h->graph_exec) return fail(NGW_E_INVALID_ARG, "no graph: call ngw_graph_build first");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->solo_running) { if (int rc = solo_stop(h)) return rc; }
+    h->solo_mirror_valid = false;
     for (int i = 0; i < reps; i++) {
         // A captured graph holds the prepared-episode depth and the refill cadence it was captured with.  The refills inside it
         // keep reporting, so the host keeps adapting between replays (default setting only); when that changed something the
@@ -791,7 +802,11 @@ int ngw_graph_launch(ngw_handle* h, int32_t reps) {
             if (int rc = capture_graph(h, acts, stride, k)) return rc;
         }
         h->mirror_valid = false;
+        if (h->graph_open && h->prefetch_every > 0 && h->since_refill + h->graph_steps > h->cadence) {
+            if (int rc = launch_refill(h)) return rc;                               // (an open graph: the cadence is kept between its replays)
+        }
         HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
+        if (h->graph_open) h->since_refill += h->graph_steps;
     }
     return NGW_OK;
 }

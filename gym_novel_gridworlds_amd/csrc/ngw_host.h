@@ -157,6 +157,7 @@ struct ngw_handle {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_steps = 0;
+    bool graph_open = false;              // a SHORT graph (steps * 2 <= refill cadence) holds no refill: ngw_graph_launch keeps the cadence between its replays
     const int32_t* graph_actions = nullptr;   // what ngw_graph_build captured: an adaptation re-captures it
     int64_t graph_stride = 0;
 };
