@@ -139,11 +139,8 @@ int rebuild_boards(ngw_handle* h, const int8_t* map, uint32_t* brd, int64_t rows
 
 int launch_refill(ngw_handle* h) {
     bool fast = false;
-    if (int rc = refill_launches(h, &fast)) return rc;
-    // boards mode: the refill rewrote prepared maps - their bit rows follow.  The dedicated new-episode kernel writes them itself; behind the
-    // general kernel the rebuild launch does (every slot: the rows of untouched maps come out as they were)
-    if (h->boards_on && !fast) return rebuild_boards(h, h->nx.map, h->nx.brd, (int64_t)h->n_pad * h->depth);
-    return NGW_OK;
+    // (boards mode: both new-episode kernels write the bit rows of the maps they make - NgwBufs::brd of the slot)
+    return refill_launches(h, &fast);
 }
 
 int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, const uint8_t* mask_dev, uint64_t action_seed, int64_t t0) {
@@ -186,12 +183,14 @@ int launch(ngw_handle* h, int mode, int n_steps, const int32_t* actions_dev, con
             return fail(NGW_E_INVALID_ARG, "map_size %d: this call keeps a wavefront's 64 maps in LDS (fused rollouts, the fused lidar epilogue) "
                                            "and they need more than 160 KiB; per-launch steps and resets are available", h->proto.S);
         const bool march = h->lidar_fused && !(boards && mode == NGW_MODE_RESET);
+        if (!boards) a.b.brd = nullptr;                                // (the general kernel writes bit rows only while somebody reads them)
         HIP_TRY(ngw_launch(h->dspec, &a, h->map_mode, (march ? 1 : 0) | (h->ext ? 2 : 0), grid, h->lds_bytes, h->stream));
     }
     if (boards && mode == NGW_MODE_RESET) {
         // (the dedicated new-episode kernel wrote the bit rows of the maps it made or copied; a masked reset leaves the others as they were,
         //  which is only right if they were right before: a stale set is rebuilt whole)
-        if (!fast_took || h->brd_dirty) { if (int rc = rebuild_boards(h, h->b.map, h->b.brd, h->n_pad)) return rc; }
+        (void)fast_took;
+        if (h->brd_dirty) { if (int rc = rebuild_boards(h, h->b.map, h->b.brd, h->n_pad)) return rc; }
         h->brd_dirty = false;
         if (int rc = launch_lidar_boards(h)) return rc;
     }
@@ -427,6 +426,7 @@ int refill_launches(ngw_handle* h, bool* fast) {
         rf.b = NgwBufs{};
         rf.b.map = h->nx.map + slot * np * S2; rf.b.loc = h->nx.loc + slot * np * 2; rf.b.facing = h->nx.facing + slot * np;
         rf.b.inv = h->nx.inv + slot * np * K; rf.b.episode = h->nx.episode + slot * np;
+        rf.b.brd = h->boards_on && h->nx.brd ? h->nx.brd + slot * np * (size_t)h->proto.BS : nullptr;
         rf.b.flags = h->b.flags; rf.b.perm = h->b.perm;
         rf.mode = NGW_MODE_REFILL; rf.n_steps = 1;
         rf.actions = reinterpret_cast<const int32_t*>(h->b.episode);

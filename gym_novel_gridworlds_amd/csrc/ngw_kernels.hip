@@ -1092,6 +1092,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     }
     STAMP(3);
     bool do_reset = live && (MODE == NGW_MODE_RESET || MODE == NGW_MODE_REFILL) && action != 0;
+    bool renewed = false;                                                          // this lane's map in LDS is a new episode's
     if (do_reset) {                                                                // out of line: new_episode
         episode++;
         uint32_t rr = new_episode(dspec, (LDS_AS int8_t*)mp, (LDS_AS int32_t*)inv, (LDS_AS uint32_t*)cand, (const LDS_AS uint8_t*)(lds + a.off_act),
@@ -1099,6 +1100,7 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
                                   MODE != NGW_MODE_RESET);   // (an explicit reset that finds nothing prepared is not a miss)
         do_reset = !(rr & NGW_F_ROWS_STORED);                                      // from here on: "the wave must store its chunk"
         rr &= ~(uint32_t)NGW_F_ROWS_STORED;
+        renewed = !(MODE == NGW_MODE_REFILL && (rr & 0xFFu));
         if (MODE == NGW_MODE_REFILL && (rr & 0xFFu)) { rr &= ~0xFFu; episode = nx_old; }   // failed placement: leave the row
                                                                                    // stale, the real reset raises the flag
         flags |= rr & 0xFFu;
@@ -1128,6 +1130,19 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
             a.b.step_count[e] = steps;
         }
         a.b.episode[e] = episode;
+    }
+    // Boards mode (a.b.brd: the bit-row lidar is on): the occupancy bit rows of the maps this launch made, from the lane's map in LDS - one word per
+    // row, bit c = cell (r, c) holds a block.  (Behind this kernel the host used to rebuild the bit rows of EVERY map with another launch: with
+    // FireWall's refill every 18 steps over four prepared slots that was the larger part of a 35 us lidar step.)
+    if ((MODE == NGW_MODE_RESET || MODE == NGW_MODE_REFILL) && a.b.brd && renewed) {
+        GLOBAL_AS uint32_t* br = (GLOBAL_AS uint32_t*)a.b.brd + e * a.BS;
+        const LDS_AS uint8_t* m8 = (const LDS_AS uint8_t*)mp;
+        for (int rr_ = 0; rr_ < S; rr_++) {
+            uint32_t w = 0;
+            for (int cc = 0; cc < S; cc++) w |= (m8[rr_ * S + cc] != 0 ? 1u : 0u) << cc;
+            br[rr_] = w;
+        }
+        for (int rr_ = S; rr_ < a.BS; rr_++) br[rr_] = 0u;
     }
     if (LIDAR) lidar_epilogue(a, lds, tid, live, mp + r * S + c, f, inv);          // the observation of the state this reset produced
     if (flags) atomicOr(a.b.flags, flags);

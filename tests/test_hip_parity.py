@@ -909,7 +909,7 @@ def test_big_batch_host_step_uses_one_block_and_matches_oracle():
 @pytest.mark.parametrize('cfg,n,horizon,slices', [('pogo10', 40000, 9, ''), ('axe10', 20000, 40, ''), ('add32', 4096, 15, '4'), ('pogo13', 30000, 11, '3'), ('crate10m', 20000, 25, '1'),
                                                   ('fire10h', 9000, 30, '2'), ('bow20', 70000, 13, '4'), ('pogo13', 30000, 11, ''), ('add32', 4100, 15, ''), ('crate10m', 20000, 25, ''),
                                                   ('fire10h', 9000, 30, ''), ('bow20', 70000, 13, ''), ('fencer12h', 8000, 12, ''), ('pogo10', 40000, 9, 'delta'), ('add32', 4096, 15, 'delta'),
-                                                  ('axe10', 20001, 14, 'inline'), ('add29h', 5000, 10, 'inline'), ('axe10', 20000, 21, 'terminal')])
+                                                  ('axe10', 20001, 14, 'inline'), ('add29h', 5000, 10, 'inline'), ('axe10', 20000, 21, 'terminal'), ('axe10', 12000, 0, 'noauto'), ('fire10h', 12000, 0, 'noauto')])
 def test_host_step_delta_refresh_matches_oracle(cfg, n, horizon, slices, monkeypatch):
     """ngw_step_host on a big batch moves only what changed (include/ngw.h ngw_host_step_layout): the host observation equals
     the oracle's after EVERY step - through in-step resets, entity pick-ups and crates, odd row sizes - and after everything
@@ -918,7 +918,8 @@ def test_host_step_delta_refresh_matches_oracle(cfg, n, horizon, slices, monkeyp
     into the caller's block itself and its last block publishes a sequence number the call polls); 'delta' = NGW_HOST_WRITE_THROUGH=0, the delta
     kernel behind every step; a number = the pipelined form of that (the batch steps in slices while a second stream brings finished slices
     across PCIe; a slice is a multiple of 64 envs, so batch sizes that are no multiple of 64 x slices end in a short last slice); 'inline' =
-    write-through without prepared episodes (the cold tail places the new episode inline); 'terminal' = with terminal-observation capture."""
+    write-through without prepared episodes (the cold tail places the new episode inline); 'terminal' = with terminal-observation capture;
+    'noauto' = the reference's semantics (no autoreset: `done` is sticky until the explicit resets in between)."""
     import torch
     kw = {}
     if slices == 'delta':
@@ -931,11 +932,13 @@ def test_host_step_delta_refresh_matches_oracle(cfg, n, horizon, slices, monkeyp
         monkeypatch.setenv('NGW_API_SLICES', slices)
     spec = T.build_spec(cfg)
     A = len(spec.actions_id)
-    v = VecNovelGridworld(spec=spec, num_envs=n, seed=16, autoreset=True, horizon=horizon, **kw)
-    o = Oracle(spec.compile(), n, seed=16, autoreset=True, horizon=horizon)
+    auto = slices != 'noauto'
+    v = VecNovelGridworld(spec=spec, num_envs=n, seed=16, autoreset=auto, horizon=horizon, **kw)
+    o = Oracle(spec.compile(), n, seed=16, autoreset=auto, horizon=horizon)
     v.reset(); o.reset()
-    stag = (np.arange(n) * 7919 % horizon).astype(np.int32)
-    v.set_state(0, step_count=stag); o.st.step_count[:] = stag
+    if auto:
+        stag = (np.arange(n) * 7919 % horizon).astype(np.int32)
+        v.set_state(0, step_count=stag); o.st.step_count[:] = stag
     rs = np.random.RandomState(2)
 
     def host_equals_oracle(obs, where):
@@ -968,7 +971,7 @@ def test_host_step_delta_refresh_matches_oracle(cfg, n, horizon, slices, monkeyp
         assert (reward == o.reward).all() and (done == o.done.astype(bool)).all(), t
         assert (info['message_code'] == o.msg_code).all() and (info['message_arg'] == o.msg_arg).all(), t
         host_equals_oracle(obs, '%s step %d' % (cfg, t))
-    assert o.st.episode.min() >= 2 and v.error_flags() == 0
+    assert (not auto or o.st.episode.min() >= 2) and v.error_flags() == 0
     assert_state_equal(v, o, cfg + ' delta host steps')
 
 

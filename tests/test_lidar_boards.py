@@ -122,6 +122,16 @@ def test_bit_row_lidar_on_injected_maps(S):
     a = np.full(n, spec.actions_id['Left'], np.int32)                   # a turn: the observation of the injected maps from a new facing
     for t in range(4):
         v.step(a); o.step(a); check('injected, turn %d' % t)
+    # other items on the outer ring (every ray still ends there: the ring's bits are forced on, the item of the hit cell is read from the map)
+    m2 = o.st.map.reshape(n, S, S).copy()
+    m2[::3, 0, 1:-1] = spec.items_id['tree_log']; m2[1::3, 2:-2, S - 1] = spec.items_id['crafting_table']
+    v.set_state(0, map=m2.reshape(n, -1)); o.st.map[:] = m2.reshape(n, -1)
+    for t in range(4):
+        v.step(a); o.step(a); check('other items on the ring, turn %d' % t)
+    fw = np.full(n, spec.actions_id['Forward'], np.int32)               # (no Break: a block broken out of the ring would let the oracle's ray leave the map)
+    for t in range(6):
+        b = fw if t % 2 == 0 else a
+        v.step(b); o.step(b); check('other items on the ring, step %d' % t)
     v.close()
 
 

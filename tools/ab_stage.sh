@@ -10,7 +10,7 @@ for W in C2 C4 C2@16384 C2@4096 C2@64; do
     python - <<PY
 import json
 d = json.load(open('$OUT/ab_stage_${W}_$NS.json'))
-print('$W NGW_NOSTAGE=$NS: %s  value %.2f G  ms_per_step %.4f  device %.4f  repeats device median %.4f' % (d['roofline']['kernel'], d['value'] / 1e9, d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['repeats']['ms_per_step_device']['median']))
+print('$W NGW_NOSTAGE=$NS: %s  value %.2f G  ms_per_step %.4f  device %.4f  repeats device median %.4f' % (d['roofline']['kernel'], d['value'] / 1e9, d['ms_per_step'], d['roofline'].get('launch_period_ms_event_pair', d['roofline'].get('kernel_ms_avg', 0)), d['repeats']['ms_per_step_device']['median']))
 PY
   done
 done

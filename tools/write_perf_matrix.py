@@ -13,8 +13,10 @@ def trim(x):
     r = x['roofline']
     o = {'value_G': round(x['value'] / 1e9, 2), 'us_per_step': round(x['ms_per_step'] * 1e3, 2), 'n_gpus': x['n_gpus'], 'steps': x['steps'],
          'resets_in_timed_region': x['resets_in_timed_region'], 'roofline_frac': r['frac'], 'roofline_bytes_model': r.get('bytes_model'),
-         'kernel_us_avg': round(r['kernel_ms_avg'] * 1e3, 3), 'traffic_bytes': r.get('traffic'),
-         'frac_on_measured_traffic': r.get('frac_of_peak_on_measured_traffic'), 'prepared_episodes': x.get('prepared_episodes')}
+         'launch_period_us_event_pair': round(r.get('launch_period_ms_event_pair', r.get('kernel_ms_avg', 0)) * 1e3, 3), 'frac_event_pair': r.get('frac_event_pair'),
+         'traffic_bytes': r.get('traffic'), 'traffic_frac': r.get('traffic_frac', r.get('frac_of_peak_on_measured_traffic')),
+         'floor_us': (r.get('floor') or {}).get('floor_us'), 'frac_of_floor': r.get('frac_of_floor'), 'value_contract_G': round(x.get('value_contract', x['value']) / 1e9, 2),
+         'prepared_episodes': x.get('prepared_episodes')}
     o['kernel'] = r.get('kernel')
     if 'gather' in x:
         o['gather'] = {k: x['gather'][k] for k in ('ms', 'GBps_into_root', 'payload_bytes_per_rank', 'ranks', 'backend')}
@@ -34,7 +36,7 @@ def trim(x):
         o['repeats_us_device'] = {k: round(v * 1e3, 3) for k, v in x['repeats']['ms_per_step_device'].items()}
     if 'cold_region' in x:
         o['cold_region_us_per_step'] = round(x['cold_region']['ms_per_step'] * 1e3, 2)
-    o['roofline_frac_wall'] = r.get('frac_wall')
+    o['frac_contract_region'] = r.get('frac_contract_region', r.get('frac_wall'))
     if 'c1_single_env' in x:
         o['c1_steps_per_s'] = {k: v['value'] for k, v in x['c1_single_env'].items()}
     if 'cpu_baseline' in x:
