@@ -87,7 +87,7 @@ int layout_lds(ngw_handle* h) {
         // batched step.  The ring is used when the reset has no shuffled-subset pass (those draw hundreds of words per lane:
         // register blocks, PhiloxRegs) and when its LDS does not cost a resident wave per CU (C5: 76 KB + 8 KB would halve the occupancy).
         h->off_rng = 0xFFFFFFFFu;                                      // = PhiloxRegs
-        if (h->spec.n_passes == 0) {
+        if (h->spec.n_passes == 0) {                                   // (register blocks here too: a C2 reset of every env 23.5 -> 25 us, profiles/r05_ab.md)
             const uint32_t ring_dw = (uint32_t)(NGW_EPB * 32);
             if (h->lidar_fused && !alias && tile_dw >= ring_dw) h->off_rng = p.off_ltile;
             else if (h->lidar_fused && alias && tile_dw >= cand_dw + ring_dw) h->off_rng = p.off_ltile + cand_dw;

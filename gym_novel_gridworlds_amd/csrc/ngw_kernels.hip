@@ -80,7 +80,7 @@ constexpr int EPB = NGW_EPB;   // envs per block = wavefront width
 // PhiloxRegs: one block at a time in registers.  For resets with a shuffled-subset pass (hundreds of draws per lane - the
 // lanes run dry at different draws whatever the buffer, and a 32-word refill per lane would execute the 8-block burst
 // 64 times over: C5 50 -> 151 us per step), and wherever the ring's 8 KB of LDS would cost a resident wave per CU.
-constexpr int PHILOX_RING = 32;
+constexpr int PHILOX_RING = 32;                                                   // (16: a C2 reset of every env 23.5 -> 30 us - too many lanes need a second fill)
 
 __device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                              uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
@@ -378,9 +378,13 @@ __device__ __forceinline__ uint32_t reset_lane(const ResetArgs a, MP mp, LDS_AS 
     RNG px;
     px.init(a.seed, env_global, episode, rng_ring);
     for (int k = 0; k < K; k++) inv[k] = 0;                                        // :119
-    for (int r = 0; r < S; r++)                                                    // :129-130 wall ring around air
-        for (int c = 0; c < S; c++)
-            mp[r * S + c] = (r == 0 || c == 0 || r == S - 1 || c == S - 1) ? (int8_t)wall_item : (int8_t)0;
+    {   // :129-130 wall ring around air: the interior's air row by row, then the ring's 4 (S - 1) cells - no comparison per cell (a C2 reset of
+        // every env 23.5 -> 21.6 us, one lane per wave 30.3 -> 27 us; FenceRestriction 53.6 -> 51.3 us: profiles/r05_ab.md)
+        for (int r = 1; r < S - 1; r++)
+            for (int c = 1; c < S - 1; c++) mp[r * S + c] = (int8_t)0;
+        for (int c = 0; c < S; c++) { mp[c] = (int8_t)wall_item; mp[(S - 1) * S + c] = (int8_t)wall_item; }
+        for (int r = 1; r < S - 1; r++) { mp[r * S] = (int8_t)wall_item; mp[r * S + S - 1] = (int8_t)wall_item; }
+    }
     for (int w = 0; w < a.CW; w++) {                                               // :136-138 all interior candidates
         int left = ncand - w * 32;
         cand[w * EPB] = left >= 32 ? 0xFFFFFFFFu : (left > 0 ? ((1u << left) - 1u) : 0u);
@@ -1157,6 +1161,17 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     STAMP(6);
     STAMP_FLUSH(a);
 #endif
+}
+
+// a store into the HOST's memory (the write-through targets, NgwWT): system scope - written through every cache level at once (global_store ... sc0 sc1),
+// so that "the wave's stores are acknowledged" (s_waitcnt) means "the host can see them".  A plain store may sit dirty in this XCD's L2 until the
+// kernel ends: wire_done's counter would then announce data that has not left the chip (seen with 2 MB of observation rows per launch).
+template <class T> __device__ __forceinline__ void stgs(void* base, uint32_t off, T v) {
+    __hip_atomic_store((GLOBAL_AS T*)((GLOBAL_AS char*)base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ... 16 bytes of it (no 128-bit atomic store in the language: the instruction with the same cache bits)
+__device__ __forceinline__ void stgs16(void* base, uint32_t off, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" : : "v"(off), "v"(v), "s"(base) : "memory");
 }
 
 #include "ngw_boards.inc"

@@ -173,10 +173,13 @@ def test_bit_row_lidar_with_terminal_capture_and_the_switch():
         del os.environ['NGW_LIDAR_BOARDS']
 
 
-@pytest.mark.parametrize('n,slices', [(20000, ''), (9000, '3')])
-def test_bit_row_lidar_behind_the_pipelined_host_step(n, slices, monkeypatch):
-    """LidarInFront(VecNovelGridworld).step() on a big batch: the packed host step runs the batch in slices (shifted base pointers for the
-    kernel's hot path, a block offset for its cold path), each slice's launch builds its part of the observation rows."""
+@pytest.mark.parametrize('n,slices,dtype', [(20000, '', np.int16), (9000, '3', np.int16), (8192, '', np.int32), (16384, '', 'packed'), (4096, '', np.int16)])
+def test_bit_row_lidar_behind_the_pipelined_host_step(n, slices, dtype, monkeypatch):
+    """LidarInFront(VecNovelGridworld).step() on a big batch.  Default: the step kernel's write-through form - with a batch of whole wavefronts it
+    also stores the observation rows straight into the caller's page-locked buffer (system-scope stores: before they were, a few 64-byte segments
+    of 2 MB of rows were still in the GPU's L2 when the launch's sequence number reached the host - the n = 8192 case here caught it), otherwise
+    the rows are copied behind the launch.  `slices`: the pipelined form (shifted base pointers for the kernel's hot path, a block offset for its
+    cold path), each slice's launch builds its part of the observation rows."""
     import gym_novel_gridworlds_amd as G
     from oracle.ngw_oracle import Oracle, lidar
     if slices:
@@ -184,10 +187,11 @@ def test_bit_row_lidar_behind_the_pipelined_host_step(n, slices, monkeypatch):
     spec = T.build_spec('axe10')
     A, S, K = len(spec.actions_id), spec.map_size, len(spec.items_id)
     v = G.VecNovelGridworld(spec=spec, num_envs=n, seed=6, autoreset=True, horizon=14)
-    w = G.LidarInFront(v, num_beams=8, dtype=np.int16, copy=False)
+    w = G.LidarInFront(v, num_beams=8, dtype=dtype, copy=False)
     o = Oracle(spec.compile(), n, seed=6, autoreset=True, horizon=14)
     cc = w._lidar.compile(spec)
-    first = w.reset(); o.reset()
+    wide = (lambda x: v.lidar_widen(x)) if dtype == 'packed' else (lambda x: x)   # (packed rows come back as the pair (beams uint8, inventory int16))
+    first = wide(w.reset()); o.reset()
     assert (first == lidar(cc, S, K, o.st.map, o.st.loc, o.st.facing, o.st.inv)).all()
     stag = (np.arange(n) * 5 % 14).astype(np.int32)
     v.set_state(0, step_count=stag); o.st.step_count[:] = stag
@@ -195,6 +199,7 @@ def test_bit_row_lidar_behind_the_pipelined_host_step(n, slices, monkeypatch):
     for t in range(45):
         a = rs.randint(0, A, size=n).astype(np.int32)
         obs, reward, done, info = w.step(a); o.step(a)
+        obs = wide(obs)
         assert (reward == o.reward).all() and (done == o.done.astype(bool)).all(), t
         exp = lidar(cc, S, K, o.st.map, o.st.loc, o.st.facing, o.st.inv)
         bad = np.nonzero((obs != exp).any(1))[0]
