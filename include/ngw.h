@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NGW_ABI_VERSION 3    /* 3: ngw_host_step_layout_packed reports nine offsets (an int32 reward section); the lidar rows default to int32 */
+#define NGW_ABI_VERSION 3    /* 3: the narrow wire format carries int32 rewards (ngw_host_step_layout_packed: section 3); the lidar rows default to int32 */
 
 #define NGW_MAX_ITEMS 24        /* reference asserts len(items) <= max_items = 20 (pogostick_v1_env.py:75,220) */
 #define NGW_MAX_ACTIONS 48
@@ -360,12 +360,17 @@ int ngw_unpack_obs(ngw_handle* h, const void* payloads_dev, int32_t world, int8_
  * page-locked block holds everything a step returns; ngw_host_step_layout_packed gives its section offsets (index: 0 map int8
  * [n][S*S], 1 inventory int32 [n][K], 2 pose uint32 [n] = r | c << 8 | facing << 16 | selected << 24, 3 reward int32 [n] (ABI 3: the
  * type ngw_step_host returns whatever the batch size; int16 before), 4 done uint8 [n], 5 info uint32 [n] (NGW_INFO_*), 6 error flags
- * uint32; sections padded to 256 bytes, offsets8[7] = the block's size).
+ * uint32 followed by one uint32 the library uses itself (the sequence number of the last finished step: the call polls it instead of
+ * synchronising the stream); sections padded to 256 bytes, offsets8[7] = the block's size).
  * ngw_step_host_packed(h, actions, block, with_map): int32 actions from host memory are validated and narrowed to bytes on the way
  * into a buffer the step kernel reads in place (no copy call); map and inventory are refreshed by deltas as in ngw_step_host (the block
  * is a mirror the caller hands in call after call; with_map = 0 skips the map's delta for this call); the dense sections 2-6 - 13 B per
  * env instead of the 26 B of the int32 arrays - are stored straight into the block by the device once the block is a mirror (mapped
  * into the GPU's address space; the first call on a block, and a block that cannot be mapped, bring them across with one copy).
+ * In that steady state the call is ONE launch: the step kernel itself stores what the step changes into the block (system-scope
+ * stores) - cells, inventory slots, the rows of envs that start an episode, the dense sections, and the fused lidar rows when
+ * ngw_lidar_host_rows registered a buffer and n_envs is a multiple of 64 - and the call returns when the kernel's last block has
+ * published its sequence number; a refill launch behind the step may still be running then (it touches nothing the caller sees).
  * Widening (pose bytes -> int32 arrays) is the caller's, when he needs it. */
 int ngw_host_step_layout_packed(ngw_handle* h, uint64_t* offsets8);
 int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block, int with_map);
