@@ -55,7 +55,8 @@ def test_bit_row_lidar_follows_every_launch(cfg, S, n, H, prefetch, depth):
     spec = T.build_spec(cfg, S)
     A = len(spec.actions_id)
     v, o, cc = _pair(spec, n, 23, H, prefetch, depth)
-    assert v.step_reads_map_in_place                                    # the bit-row path: no map is staged for the fused lidar step
+    import os
+    assert v.step_reads_map_in_place or os.environ.get('NGW_LIDAR_BOARDS') == '0'   # the bit-row path: no map is staged for the fused lidar step (unless the suite runs under the A/B switch)
     check = _checker(v, o, cc, spec)
     v.reset(); o.reset(); check('reset')
     stag = (np.arange(n) * 7 % H).astype(np.int32)                      # episode ends spread over the waves: single-lane copies in the cold path
