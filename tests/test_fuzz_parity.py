@@ -26,6 +26,7 @@ def check(v, o, where, lid=None):
         from oracle.ngw_oracle import lidar
         cc, S, K = lid
         got = v.lidar_observation()
+        got = v.lidar_widen(got) if isinstance(got, tuple) else got
         exp = lidar(cc, S, K, o.st.map, o.st.loc, o.st.facing, o.st.inv)
         bad = np.nonzero((got != exp).any(1))[0]
         assert bad.size == 0, "%s: lidar rows differ for %d envs, first env %d" % (where, bad.size, bad[0])
@@ -54,20 +55,21 @@ def one_case(rs, cfg, case):
     spec = T.build_spec(cfg)
     A = len(spec.actions_id)
     S = spec.map_size
-    n = int(rs.choice([1, 37, 64, 65, 200, 513, 1500])) if S <= 16 else int(rs.choice([1, 64, 130, 300]))
+    n = int(rs.choice([1, 37, 64, 65, 128, 200, 513, 1024, 1500])) if S <= 16 else int(rs.choice([1, 64, 130, 256, 300]))   # (whole-wavefront batches: the write-through step also delivers the lidar rows)
     horizon = int(rs.choice([0, 7, 23, 64, 90]))
     autoreset = bool(rs.randint(0, 4)) or horizon > 0
     prefetch = rs.choice(['auto', 0, 3, 16])
     prefetch = prefetch if prefetch == 'auto' else int(prefetch)
     seed, base = int(rs.randint(0, 2 ** 31)), int(rs.randint(0, 10 ** 6))
     depth = int(rs.choice([0, 0, 1, 2, 4]))                 # prepared episodes per env (0 = automatic)
+    term = bool(rs.randint(0, 5) == 0)                      # terminal-observation capture on (the cold paths copy the rows an episode ended in first)
     # half the cases take the big-batch form of the host step (one page-locked block, delta refresh) at these small sizes too
     zc = os.environ.pop('NGW_ZC_BYTES', None)
     small_block = bool(rs.randint(0, 2))
     if small_block:
         os.environ['NGW_ZC_BYTES'] = '2048'
     try:
-        v = _make(spec, n, seed, autoreset, horizon, prefetch, base, depth)
+        v = _make(spec, n, seed, autoreset, horizon, prefetch, base, depth, term)
     finally:
         os.environ.pop('NGW_ZC_BYTES', None)
         if zc is not None:
@@ -75,9 +77,9 @@ def one_case(rs, cfg, case):
     return _run_case(rs, cfg, case, spec, v, n, A, S, horizon, autoreset, prefetch, depth, seed, base, small_block)
 
 
-def _make(spec, n, seed, autoreset, horizon, prefetch, base, depth):
+def _make(spec, n, seed, autoreset, horizon, prefetch, base, depth, term=False):
     return VecNovelGridworld(spec=spec, num_envs=n, seed=seed, autoreset=autoreset, horizon=horizon, reset_prefetch=prefetch, env_index_base=base,
-                          reset_prefetch_depth=depth)
+                          reset_prefetch_depth=depth, terminal_capture=term)
 
 
 def _run_case(rs, cfg, case, spec, v, n, A, S, horizon, autoreset, prefetch, depth, seed, base, small_block):
@@ -86,8 +88,9 @@ def _run_case(rs, cfg, case, spec, v, n, A, S, horizon, autoreset, prefetch, dep
     lid = None
     if rs.randint(0, 3) == 0:                               # one case in three runs with the fused lidar epilogue
         from gym_novel_gridworlds_amd.lidar import LidarConfig
-        lc = LidarConfig(spec, int(rs.choice([4, 8])))
-        v.lidar_configure(lc, fused=True)
+        lc = LidarConfig(spec, int(rs.choice([4, 8, 8])))
+        fmt = [np.int16, np.int32, 'packed'][int(rs.randint(0, 3))]
+        v.lidar_configure(lc, fused=True, dtype=fmt)
         lid = (lc.compile(spec), S, len(spec.items_id))
     tag = '%s case %d (n=%d H=%d auto=%d prefetch=%s depth=%d lidar=%d block=%d)' % (cfg, case, n, horizon, autoreset, prefetch, depth, lid is not None, small_block)
     if not both_reset(v, o, None, tag):
@@ -114,6 +117,11 @@ def _run_case(rs, cfg, case, spec, v, n, A, S, horizon, autoreset, prefetch, dep
                     if not ofail[0]:
                         assert (obs['map'].reshape(n, -1) == o.st.map).all() and (obs['inventory_items_quantity'] == o.st.inv).all(), tag + ': host observation'
                         assert (obs['agent_location'] == o.st.loc).all() and (obs['agent_facing_id'] == o.st.facing).all(), tag + ': host observation'
+                        if lid is not None:                 # the rows the host step itself delivered (write-through / copy behind the launch)
+                            from oracle.ngw_oracle import lidar as _lidar
+                            got = v.lidar_observation()
+                            got = v.lidar_widen(got) if isinstance(got, tuple) else got
+                            assert (got == _lidar(lid[0], lid[1], lid[2], o.st.map, o.st.loc, o.st.facing, o.st.inv)).all(), tag + ': lidar rows of the host step'
             elif kind == 'dev':
                 k = int(rs.randint(1, 9))
                 an = rs.randint(0, A, size=(k, n)).astype(np.int32)
