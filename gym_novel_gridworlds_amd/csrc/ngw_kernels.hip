@@ -1053,22 +1053,30 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
         }
         if (!__any(action)) return;
     }
+    // A whole wavefront of envs that ALL get a new episode (an unmasked reset; a refill behind a batch that ended its episodes together): nothing of
+    // the old rows survives, so they are not staged - the prologue's round trip and S*S + 4 K bytes per env less (a C2 reset of every env 21.6 -> 20.x us).
+    const bool all_new = (int64_t)EPB <= a.n - env0 &&
+                         ((MODE == NGW_MODE_RESET && !a.reset_mask) || (MODE == NGW_MODE_REFILL && __all(action != 0)));
     u32x4 buf[PB];
     const u32x4* gin = reinterpret_cast<const u32x4*>(a.b.map + env0 * a.S2);
-    pieces_load(buf, gin, 0, npieces, tid);
+    if (!all_new) pieces_load(buf, gin, 0, npieces, tid);
     if (live) {
-        const int2 rc = reinterpret_cast<const int2*>(a.b.loc)[e];
-        r = rc.x; c = rc.y;
-        f = a.b.facing[e];
+        if (!all_new) {
+            const int2 rc = reinterpret_cast<const int2*>(a.b.loc)[e];
+            r = rc.x; c = rc.y;
+            f = a.b.facing[e];
+        }
         if (MODE != NGW_MODE_REFILL) {
-            sel = a.b.selected[e];
-            steps = a.b.step_count[e];
+            if (!all_new) {
+                sel = a.b.selected[e];
+                steps = a.b.step_count[e];
+            }
             episode = a.b.episode[e];
         }
         if (MODE == NGW_MODE_RESET) action = a.reset_mask ? (int)a.reset_mask[e] : 1;
     }
     u32x4 iq[IQ];
-    {
+    if (!all_new) {
         const u32x4* gi = reinterpret_cast<const u32x4*>(a.b.inv + env0 * K);
 #pragma unroll
         for (int j = 0; j < IQ; j++) iq[j] = (j * EPB < 16 * K) ? gi[min(tid + EPB * j, 16 * K - 1)] : u32x4{0u, 0u, 0u, 0u};
@@ -1076,12 +1084,14 @@ __global__ void __launch_bounds__(NGW_EPB) ngw_kernel(const NgwDevSpec* __restri
     STAMP(1);
     // ---- land them in LDS
     if (tid < NGW_MAX_PLACE / 4) lds[a.off_act + tid] = psv;
-    pieces_lds<true, MAPMODE>(buf, a, lds_map, 0, npieces, tid);
-    for (int base = EPB * PB; base < npieces; base += EPB * PB) {                  // big maps: further rounds
-        pieces_load(buf, gin, base, npieces, tid);
-        pieces_lds<true, MAPMODE>(buf, a, lds_map, base, npieces, tid);
+    if (!all_new) {
+        pieces_lds<true, MAPMODE>(buf, a, lds_map, 0, npieces, tid);
+        for (int base = EPB * PB; base < npieces; base += EPB * PB) {              // big maps: further rounds
+            pieces_load(buf, gin, base, npieces, tid);
+            pieces_lds<true, MAPMODE>(buf, a, lds_map, base, npieces, tid);
+        }
+        inv_lds<true>(iq, a, lds_inv, tid);
     }
-    inv_lds<true>(iq, a, lds_inv, tid);
     if (LIDAR && tid < LIDAR_ITEM_DW) lds[a.off_litem + tid] = lit;
     __syncthreads();
     STAMP(2);
