@@ -628,6 +628,7 @@ int ngw_reset_host(ngw_handle* h, const uint8_t* mask_host, int8_t* map, int32_t
         }
         if (!seen) HIP_TRY(hipStreamSynchronize(h->stream));
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        h->solo_mirror_valid = true;                                    // (the reset kernel has just written every row of the mirror: a one-env step loop starts from it without a copy)
         const NgwMirror& m = h->mir;
         if (map) memcpy(map, m.map, n * S2);
         if (loc) memcpy(loc, m.loc, n * 8);

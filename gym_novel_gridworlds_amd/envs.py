@@ -41,6 +41,7 @@ class _NovelGridworldEnv(_EnvBase):
         self._vec_cache = {}                                 # compiled-spec key -> device handle (most recently used last)
         self._seed = None
         self._episode_base = 0
+        self._fp_cache = {}
         sp = self._spec
         self.env_id = sp.env_id
         self.env = env                                       # env to restore in reset (pogostick_v1_env.py:29, :89-109)
@@ -120,38 +121,53 @@ class _NovelGridworldEnv(_EnvBase):
         if self._vec is not None and not full_check and now == self._vec_fp:
             return self._vec
         sp = self._sync_spec()      # callers may REBIND the public tables (env.items_quantity = {...}): the spec follows the env's attributes
-        key = (sp.map_size, tuple(sp.items_id.items()), tuple(sp.actions_id.items()), tuple(sp.items_quantity.items()),
-               tuple(sorted(sp.entities)), repr(sp.axe), repr(sp.additem), repr(sp.start_inventory), sp.reward_done,
-               sp.reward_intermediate, repr(sp.replace), repr(sp.fence), repr(sp.fence_pred), repr(sp.reset_passes), repr(sp.fire_wall), repr(sp.crate),
-               tuple(sorted(sp.unbreakable_items)), repr(sp.recipes), repr(sp.break_increase))
+        fp = self._vec_fp
+        if self._vec is not None and fp is not None and now[1:] == fp[1:]:
+            # only the map size may differ from what the current handle was built for (the reference's own loop, tests/random_action.py:51-64,
+            # changes it every ten steps): the rest of the key - a dozen reprs of small tables - is the current one's
+            key = (sp.map_size,) + self._vec_key[1:]
+        else:
+            key = (sp.map_size, tuple(sp.items_id.items()), tuple(sp.actions_id.items()), tuple(sp.items_quantity.items()),
+                   tuple(sorted(sp.entities)), repr(sp.axe), repr(sp.additem), repr(sp.start_inventory), sp.reward_done,
+                   sp.reward_intermediate, repr(sp.replace), repr(sp.fence), repr(sp.fence_pred), repr(sp.reset_passes), repr(sp.fire_wall), repr(sp.crate),
+                   tuple(sorted(sp.unbreakable_items)), repr(sp.recipes), repr(sp.break_increase))
         if self._vec is None or key != self._vec_key:
             # a handle per compiled spec, kept: the reference's own loop (tests/random_action.py:51-64) changes map_size every
             # ten steps, and building a device handle costs milliseconds.  The episode counter travels with the env, not
-            # the handle, so no (seed, episode) stream is ever replayed.
-            if self._vec is not None:
-                self._episode_base = int(self._vec.get_state(0, 1)['episode'][0])
+            # the handle, so no (seed, episode) stream is ever replayed: `_episode_base` counts this env's resets on the host
+            # (every reset1() advances the device's counter by one, whatever its outcome) and a handle that comes back into
+            # use is told where the env stands.
             if self._seed is None:                          # reproducible under np.random.seed(), like the reference
                 self._seed = int(np.random.randint(0, 2 ** 31 - 1))
+            if self._vec is not None and hasattr(self._vec, 'sync'):
+                # the handle that goes out of use may still have its resident step loop on the device (it ends by itself after 300 us without a
+                # command): ended now, so that the incoming handle's launches do not queue up behind it (HIP maps streams onto a few hardware queues)
+                self._vec.sync()
             vec = self._vec_cache.pop(key, None)
             if vec is None:
                 import copy as _copy
                 vec = self._make_backend(_copy.deepcopy(sp), self._seed)
+                vec._adapter_episode = 0
                 while len(self._vec_cache) >= self._VEC_CACHE:     # oldest out
                     self._vec_cache.pop(next(iter(self._vec_cache))).close()
             self._vec_cache[key] = vec                          # (re-inserted: most recently used last)
             self._vec, self._vec_key = vec, key
             self._dev_state_of = None
-            if self._episode_base:
+            if getattr(vec, '_adapter_episode', 0) != self._episode_base:
                 vec.set_state(0, episode=np.array([self._episode_base], np.uint32))
+                vec._adapter_episode = self._episode_base
         if now != self._vec_fp:                              # (reset() re-checks the key every time: the snapshot only when a table changed)
-            self._vec_fp = copy.deepcopy(now)
+            snap = self._fp_cache.get(key)                   # (a handle that comes back: its tables' snapshot too, if nothing was edited meanwhile)
+            if snap is None or snap != now:
+                snap = self._fp_cache[key] = copy.deepcopy(now)
+                while len(self._fp_cache) > 2 * self._VEC_CACHE:
+                    self._fp_cache.pop(next(iter(self._fp_cache)))
+            self._vec_fp = snap
         return self._vec
 
     _VEC_CACHE = 16
 
     def _close_backend(self):
-        if self._vec is not None:
-            self._episode_base = int(self._vec.get_state(0, 1)['episode'][0])
         for vec in self._vec_cache.values():
             vec.close()
         self._vec_cache.clear()
@@ -252,6 +268,8 @@ class _NovelGridworldEnv(_EnvBase):
         self.last_reward = 0
         self.last_done = False
         vec = self._backend(full_check=True)
+        self._episode_base += 1                              # (the device's episode counter advances with the call, whatever its outcome)
+        vec._adapter_episode = self._episode_base
         vec.reset1()                                         # one C-ABI call that also brings the state back; AssertionError(PLACEMENT_MESSAGE) when items do not fit
         self._pull(vec)
         obs = self.get_observation()
