@@ -194,7 +194,7 @@ class VecNovelGridworld:
         and leaves the env as it was - the reference, too, asserts before it changes anything.  The state is undefined until the
         next reset(), as after construction."""
         old_h, old_attrs = self._h, dict(self.__dict__)
-        for name in VecNovelGridworld._HOST_ATTRS + ('_host', '_step_args', '_step1_args', '_step1_fn', '_step1_mv', '_state1_mv', '_reset1_args', '_last_state_views', '_lidar_host', '_view_host', '_last_actions', '_packed_block', '_steps_stale'):
+        for name in VecNovelGridworld._HOST_ATTRS + ('_host', '_step_args', '_step1_args', '_step1_fn', '_step1_mv', '_state1_mv', '_reset1_args', '_last_state_views', '_lidar_host', '_view_host', '_last_actions', '_packed_block', '_packed_call', '_steps_stale'):
             self.__dict__.pop(name, None)
         self._h = C.c_void_p()
         try:
@@ -334,7 +334,10 @@ class VecNovelGridworld:
         if block is not None:
             # big batch, narrow wire format (ngw_step_host_packed): the actions are narrowed to bytes on their way into a buffer the step
             # kernel reads in place, map / inventory come back as deltas, pose + reward + done + info as 11 B per env in one copy
-            rc = _cabi.lib().ngw_step_host_packed(self._h, C.c_void_p(a.__array_interface__['data'][0]), _cabi._ptr(block, np.uint8), int(bool(with_obs)))
+            fn = self.__dict__.get('_packed_call')
+            if fn is None:                                            # (the library entry and the block's pointer: looked up / built once)
+                fn = self.__dict__['_packed_call'] = (_cabi.lib().ngw_step_host_packed, _cabi._ptr(block, np.uint8))
+            rc = fn[0](self._h, a.ctypes.data, fn[1], 1 if with_obs else 0)
             if rc:
                 _cabi.check(rc)
             self._last_actions = a
