@@ -281,10 +281,26 @@ def main():
     # 110 us eager), so regions shorter than 100 launches are issued eagerly, from one C-ABI call (tools/short_run.py).
     # (Tried: event-record nodes inside the graph to time a replay without its launch latency - two such nodes cost ~80 us per
     #  replay on this runtime, more than they explain.)
-    # (Round 5 re-measured: short graphs are now captured without a closing refill - ngw_graph_build's "open" graphs - and a 20-step replay after
-    #  the first costs 87-88 us against 92-99 us eager, but the first replay, which is the contract region, costs 121 us: driver-form lines
-    #  14.2 / 14.7 G with the graph against 14.2 G eager, contract region 12.6-12.8 G against 14 G.  The threshold stays.)
-    use_graph = args.mode == 'step' and args.launch == 'graph' and steps >= 100
+    # Round 5: short graphs are captured without a closing refill (ngw_graph_build's "open" graphs: the library keeps the refill cadence between replays)
+    # and the threshold came down to 16 steps.  A 20-step replay costs ONE host call (13 us) and 85-92 us fence to fence (the first replay of an
+    # instantiated graph 92-121 us: that is the contract region, `value_contract`); the eager loop is bound by the HOST's launch rate, which differs
+    # from box to box of the pool - 2.7 / 3.7 / 4.3 us per empty-kernel launch seen in this round's runs - and gave 10.7 / 13.5 / 14.2 G in three
+    # driver-form lines where the graph form gave 13.1 - 14.7 G (and the eager form 14.5 G on a box whose host launches in 2.6 us).  `value` is the median
+    # of the contract region and the repeats either way.
+    use_graph = args.mode == 'step' and args.launch == 'graph' and steps >= 16
+    host_launch_us = None
+    if use_graph and steps < 100:
+        # ... and for such a short region the form follows the host this process runs on: what an EMPTY kernel of the step's launch shape costs the host
+        # loop per launch, measured here (64 launches, the shortest of four regions; no env state is touched).  Below ~3.2 us the eager loop keeps up with
+        # the ~3.75 us the device needs per step and has no first-replay cost; above it the region would be bound by the host, and the graph is used.
+        import ctypes as C
+        from gym_novel_gridworlds_amd import _cabi
+        fl = _cabi.lib().ngw_debug_launch_floor
+        fl.argtypes, fl.restype = [C.c_void_p, C.c_int32, C.c_int, C.POINTER(C.c_double)], C.c_int
+        us = C.c_double(0)
+        _cabi.check(fl(v._h, 64, 0, C.byref(us)))
+        host_launch_us = round(us.value, 3)
+        use_graph = host_launch_us > 3.2
     ptrs = []
     if args.mode == 'step' or not args.no_side:
         # i.i.d. uniform int32 actions over len(actions_id), seed 1234 (+rank), resident in HBM before the timed region
@@ -461,9 +477,10 @@ def main():
             floor_us = max(us_g.value + (life_us or 0.0), 0.0 if use_graph else us_e.value)
             roofline['floor'] = {'empty_kernel_launch_period_us': {'hipGraph replay': round(us_g.value, 4), 'eager': round(us_e.value, 4)},
                                  'launch_form_of_this_region': 'hipGraph replay' if use_graph else 'eager',
+                                 'host_launch_us_probe_before_the_region': host_launch_us,
                                  'launches': int(kfl), 'stamped_wave_life_us': life_us, 'stamped_wave_life_us_with_stamp_cost': wl.get('median_us'), 'wave_life_source': wl.get('source'),
                                  'floor_us': round(floor_us, 4),
-                                 'what': 'floor = max(empty-kernel launch period replayed from a graph + the median life of a wave of the step kernel (in-kernel clock '
+                                 'what': 'floor = max(empty-kernel launch period replayed from a graph (the shortest of a few regions of the same length as the timed one) + the median life of a wave of the step kernel (in-kernel clock '
                                          'stamps, profiles/), and - for an eagerly launched region - the empty-kernel launch period of the host loop): EMPTY kernels '
                                          'in the step kernel\'s launch shape, issued back to back on this handle in this run (HIP event pair).  What one launch per '
                                          'step() costs when nothing but latency is left'}
