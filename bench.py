@@ -285,22 +285,10 @@ def main():
     # and the threshold came down to 16 steps.  A 20-step replay costs ONE host call (13 us) and 85-92 us fence to fence (the first replay of an
     # instantiated graph 92-121 us: that is the contract region, `value_contract`); the eager loop is bound by the HOST's launch rate, which differs
     # from box to box of the pool - 2.7 / 3.7 / 4.3 us per empty-kernel launch seen in this round's runs - and gave 10.7 / 13.5 / 14.2 G in three
-    # driver-form lines where the graph form gave 13.1 - 14.7 G (and the eager form 14.5 G on a box whose host launches in 2.6 us).  `value` is the median
-    # of the contract region and the repeats either way.
+    # driver-form lines where the graph form gave 13.1 - 14.7 G.  Even a host that launches in 2.5 us on average jitters: twelve eager regions in a row
+    # ran at 3.5 - 5.5 us per step on the device's own clock (the device waiting for launches), twelve replays at 3.86 (+ the regions that hold the
+    # all-env reset: 5.4): `repeats.regions_in_order`.  `value` is the median of the contract region and the repeats either way.
     use_graph = args.mode == 'step' and args.launch == 'graph' and steps >= 16
-    host_launch_us = None
-    if use_graph and steps < 100:
-        # ... and for such a short region the form follows the host this process runs on: what an EMPTY kernel of the step's launch shape costs the host
-        # loop per launch, measured here (64 launches, the shortest of four regions; no env state is touched).  Below ~3.2 us the eager loop keeps up with
-        # the ~3.75 us the device needs per step and has no first-replay cost; above it the region would be bound by the host, and the graph is used.
-        import ctypes as C
-        from gym_novel_gridworlds_amd import _cabi
-        fl = _cabi.lib().ngw_debug_launch_floor
-        fl.argtypes, fl.restype = [C.c_void_p, C.c_int32, C.c_int, C.POINTER(C.c_double)], C.c_int
-        us = C.c_double(0)
-        _cabi.check(fl(v._h, 64, 0, C.byref(us)))
-        host_launch_us = round(us.value, 3)
-        use_graph = host_launch_us > 3.2
     ptrs = []
     if args.mode == 'step' or not args.no_side:
         # i.i.d. uniform int32 actions over len(actions_id), seed 1234 (+rank), resident in HBM before the timed region
@@ -397,6 +385,7 @@ def main():
             wall.append((time.perf_counter() - tr0) / steps * 1e3)
             dev.append(v.timing_end() / steps)
         assert v.error_flags() == 0
+        wall_seq, dev_seq = [dt / steps * 1e3] + reduce_max(list(wall)), [dev_ms / steps] + reduce_max(list(dev))
         wall_m, dev_m = reduce_max(sorted(wall)), reduce_max(sorted(dev))
         med = lambda xs: xs[len(xs) // 2]
         repeats = {'n': args.repeats, 'ms_per_step_wall': {'median': round(med(wall_m), 6), 'min': round(wall_m[0], 6), 'max': round(wall_m[-1], 6)},
@@ -410,6 +399,8 @@ def main():
     dev_all = [dev_ms / steps] + (repeats['_dev_all'] if repeats else [])
     if repeats:
         del repeats['_wall_all'], repeats['_dev_all']
+        # every region in the order it ran (the contract region first): which of them held the all-env reset and the refill shows here
+        repeats['regions_in_order'] = {'ms_per_step_wall': [round(x, 6) for x in wall_seq], 'ms_per_step_device': [round(x, 6) for x in dev_seq]}
     ms_step = sorted(wall_all)[len(wall_all) // 2] if args.mode == 'step' else dt / steps * 1e3
     dev_step = sorted(dev_all)[len(dev_all) // 2] if args.mode == 'step' else dev_ms / steps
 
@@ -477,7 +468,6 @@ def main():
             floor_us = max(us_g.value + (life_us or 0.0), 0.0 if use_graph else us_e.value)
             roofline['floor'] = {'empty_kernel_launch_period_us': {'hipGraph replay': round(us_g.value, 4), 'eager': round(us_e.value, 4)},
                                  'launch_form_of_this_region': 'hipGraph replay' if use_graph else 'eager',
-                                 'host_launch_us_probe_before_the_region': host_launch_us,
                                  'launches': int(kfl), 'stamped_wave_life_us': life_us, 'stamped_wave_life_us_with_stamp_cost': wl.get('median_us'), 'wave_life_source': wl.get('source'),
                                  'floor_us': round(floor_us, 4),
                                  'what': 'floor = max(empty-kernel launch period replayed from a graph (the shortest of a few regions of the same length as the timed one) + the median life of a wave of the step kernel (in-kernel clock '
