@@ -84,7 +84,7 @@ for W, mode in (('driver', 'step'), ('C2', 'step'), ('C3', 'step'), ('C4', 'step
     if not f:
         continue
     base = 'C2' if W == 'driver' else W.split('_')[0]
-    out.append('## %s (%s), %s mode - kernel_stats.csv\n' % ("the driver's command: 20 eager steps, 5 warm-up" if W == 'driver' else W, WL[base][2], mode))
+    out.append('## %s (%s), %s mode - kernel_stats.csv\n' % ("the driver's command: 20 steps (one replay of a 20-node graph per region since the end of round 5), 5 warm-up" if W == 'driver' else W, WL[base][2], mode))
     ln = bench_line('stats_%s.log' % W)
     if ln:
         out.append('bench line of the traced run: %.2f G env-steps/s, %.2f us per batched step, %d resets of every env in the timed region\n'
