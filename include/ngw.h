@@ -337,7 +337,10 @@ int ngw_timing_mark(ngw_handle* h);
 
 /* hipGraph stepping for launch-bound loops: captures n_steps consecutive ngw_step_device launches whose
  * actions are read from actions_dev + i * step_stride (int32 elements) into one executable graph, then replays it.
- * Semantically identical to calling ngw_step_device n_steps * reps times with those action rows. */
+ * Semantically identical to calling ngw_step_device n_steps * reps times with those action rows.  Prepared next episodes: a graph
+ * that is at least half the refill cadence long carries its refills (every replay ends with one, so that it leaves the cadence where
+ * it found it); a shorter one is captured without any and ngw_graph_launch issues them between the replays, whenever the next replay
+ * would overrun the cadence. */
 int ngw_graph_build(ngw_handle* h, const int32_t* actions_dev, int64_t step_stride, int32_t n_steps);
 int ngw_graph_launch(ngw_handle* h, int32_t reps);
 
