@@ -157,6 +157,9 @@ int upload_reset_u(ngw_handle* h) {
             q.off_ltab = off; off += NGW_EPB * (nr + 4u);                           // the lanes' bit rows, [64][NR + 4] words: rows come back by index from here
         }
         h->ns_lds = (size_t)off * 4;
+        if (getenv("NGW_DEBUG_LDS"))
+            fprintf(stderr, "[ngw] LDS per wavefront, in-place step kernel: %zu B (S = %d, bit-row lidar %d: inventory rows + candidate masks + placement sequence%s)\n", h->ns_lds, h->proto.S,
+                    (int)h->boards_on, h->boards_on ? " + item tables + observation tile + bit-row scratch" : "");
         HIP_TRY(hipMemcpyAsync(&h->dspec->lp_ns, &q, sizeof(q), hipMemcpyDefault, h->stream));
     }
     if (h->proto.BS) {

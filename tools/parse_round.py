@@ -303,6 +303,12 @@ for F in ('int16', 'packed', 'int32'):                    # the stamped timeline
         ld.append('```')
         ld += [x.rstrip() for x in open(lg) if 'amdgpu.ids' not in x]
         ld.append('```\n')
+ll = os.path.join(ROOT, 'gpurun_out', ROUND, 'lds_layout.log')
+if os.path.exists(ll):
+    ld.append('## LDS per wavefront (`NGW_DEBUG_LDS=1`, packed rows; 160 KB per CU, one wavefront per workgroup)\n')
+    ld.append('```')
+    ld += [x.rstrip() for x in open(ll) if x.startswith('[ngw]') or x.startswith('==')]
+    ld.append('```\n')
 for W in ('', '_C2', '_C3', '_C5'):
     lr = os.path.join(ROOT, 'gpurun_out', ROUND, 'lidar_rate%s.log' % W)
     if os.path.exists(lr):

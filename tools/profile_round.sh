@@ -62,10 +62,11 @@ done
 # 6. in-kernel clock stamps of the step kernel (diagnostics build): the median wave life that bench.py's roofline.floor adds to the empty-kernel launch period
 NGW_STAMP_JSON=$OUT/wave_life.json NGW_LIB=$PWD/gym_novel_gridworlds_amd/libngw_hip_stamps.so python3 tools/stamp_timeline.py C2 C3 C4 C5 > $OUT/stamps_step.log 2>&1 || echo "stamps failed"
 # 7. untraced rates of the fused lidar step, per workload
-mkdir -p gpurun_out/$ROUND
+mkdir -p gpurun_out/$ROUND; rm -f gpurun_out/$ROUND/lds_layout.log
 for W in C2 C3 C5; do
   NGW_LIDAR_SWEEP=0 python3 tools/lidar_rate.py 65536 $W > gpurun_out/$ROUND/lidar_rate_$W.log 2>&1 || echo "lidar_rate $W failed"
 done
+for W in C2 C3 C5; do echo "== $W" >> gpurun_out/$ROUND/lds_layout.log; NGW_DEBUG_LDS=1 python3 bench.py --no-cpu-baseline --no-side --steps 16 --warmup 2 --workload $W --lidar packed 2>&1 >/dev/null | grep '^\[ngw\]' | sort -u >> gpurun_out/$ROUND/lds_layout.log; done
 (git rev-parse --short HEAD 2>/dev/null || cat COMMIT 2>/dev/null || echo unknown) > $OUT/commit.txt
 date -u +%Y-%m-%dT%H:%MZ > $OUT/date.txt
 find $OUT -name "*.db" -delete 2>/dev/null
