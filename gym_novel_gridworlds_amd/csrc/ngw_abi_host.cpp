@@ -407,6 +407,10 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
             for (size_t i = 0; i < n; i++)
                 if (actions_host[i] < 0 || actions_host[i] >= A) return fail(NGW_E_INVALID_ACTION, "%d is not in list", (int)actions_host[i]);   // pogostick_v1_env.py:236
         }
+#ifdef NGW_HOSTTRACE
+        static double wA = 0, wB = 0, wC = 0; static int wn = 0;
+        const double w1 = pnow();                                      // actions validated and narrowed
+#endif
         uint8_t* const blk = static_cast<uint8_t*>(block);
         if (h->wt_block != block) {
             if (!h->wt_count) {
@@ -437,6 +441,9 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
         h->launch_act_u8 = false; h->launch_wire = false;
         if (lrc) return lrc;
         // (no event for the action buffer's slot: this call returns only after the kernel has published its sequence number)
+#ifdef NGW_HOSTTRACE
+        const double w2 = pnow();                                      // the launch is enqueued
+#endif
         if (lrows && !h->wt_rows) {
             HIP_TRY(hipMemcpyAsync(h->lidar_host_rows, h->lidar_out, n * lrb, hipMemcpyDefault, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
@@ -453,6 +460,17 @@ int ngw_step_host_packed(ngw_handle* h, const int32_t* actions_host, void* block
             if (!seen) HIP_TRY(hipStreamSynchronize(h->stream));
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);                       // the block's reads stay behind the poll
+#ifdef NGW_HOSTTRACE
+        {
+            const double w3 = pnow();                                  // the sequence word has arrived: the block is written
+            wA += w1 - p0; wB += w2 - w1; wC += w3 - w2;
+            if (++wn == 200) {
+                fprintf(stderr, "[hosttrace packed, write-through, %zu envs] narrow actions %.2f us, enqueue %.2f us, wait for the device %.2f us (lidar rows %s)\n", n, wA / wn, wB / wn, wC / wn,
+                        lrows ? (h->wt_rows ? "by write-through" : "copied behind the launch") : "none");
+                wA = wB = wC = 0; wn = 0;
+            }
+        }
+#endif
         h->mirror_valid = true; h->shadow_stale = true;
         return NGW_OK;
     }
